@@ -1,0 +1,155 @@
+/*
+ * isx.h — C ABI of libisx, the MI355X-native integrating-sphere ray tracer.
+ *
+ * This is the drop-in boundary for ONE hot path of bdagnillo/altair-raytracing:
+ * the per-ray trace loop + port-escape test + detector flux histogram
+ * (SURVEY.md §8).  The reference has no FFI of its own; the entry points below
+ * are what a maintainer's ROOT-macro (or cgo/ctypes) stub would bind in place of
+ *
+ *   AOpticsManager::TraceNonSequential(ARay&/ARayArray*)   flux_at_observer/fluxAtObserverOptimize.C:254,295
+ *   isRayPassingThroughExitPort()                          flux_at_observer/fluxAtObserver.C:162-166
+ *   Detector::setPosition / Detector::checkIntersection    flux_at_observer/fluxAtObserver.C:49-107
+ *   hitCount++ / fraction = hit/n                          flux_at_observer/fluxAtObserverOptimize.C:309-312,571
+ *   trace-once endpoint binning                            flux_at_observer/fluxAtObserverFast.C:1269-1315
+ *   BRDF::SampleDirection + second trace                   flux_at_observer/nonLambertianFlux.C:147-208,253-268
+ *   addDetectorDisk / isRayHittingDetector                 integratingSphereDetectorSweep.C:134-172
+ *
+ * Rules of the boundary: plain C types only, caller owns every host buffer,
+ * the library owns device memory between isx_init()/isx_shutdown(), calls are
+ * blocking unless they take a stream, no exception ever crosses the ABI, every
+ * function returns 0 or a negative isx_status.  There is NO CPU fallback: if no
+ * gfx950 device (or the HIP runtime) is available every compute entry point
+ * returns ISX_ERR_NO_DEVICE.
+ */
+#ifndef ISX_H
+#define ISX_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ISX_ABI_VERSION 1
+
+typedef enum isx_status {
+  ISX_OK = 0,
+  ISX_ERR_NO_DEVICE = -1,   /* HIP runtime/device missing: the product never falls back to the CPU */
+  ISX_ERR_BAD_CONFIG = -2,  /* geometry/grid parameters out of the supported domain */
+  ISX_ERR_BAD_ARG = -3,     /* null pointer, zero size ... */
+  ISX_ERR_HIP = -4,         /* a HIP call failed; isx_last_hip_error() has the code */
+  ISX_ERR_NOT_INIT = -5,
+  ISX_ERR_TOO_LARGE = -6    /* n_rays per call above ISX_MAX_RAYS_PER_CALL */
+} isx_status;
+
+/* One launch may trace at most this many rays (per-block 32-bit LDS bins). */
+#define ISX_MAX_RAYS_PER_CALL (1ull << 40)
+
+/* source_model */
+#define ISX_SOURCE_PENCIL 0 /* fluxAtObserver*.C: identical rays from src along dir            */
+#define ISX_SOURCE_BRDF 1   /* nonLambertianFlux.C:235-304: primary trace, BRDF re-scatter, 2nd trace */
+
+/*
+ * Geometry + surface + source + detector grid.  Field meaning follows the
+ * reference constants: fluxAtObserverOptimize.C:33-41 (THETA_MAX, MAX_REFLECTIONS,
+ * INNER/OUTER_RADIUS, REFLECTANCE, ROUGHNESS), :192-230 (setupOpticsManager),
+ * :456-461,495 (n, exitPortZ, bins, detector size), fluxAtObserver.C:352-358 (grid).
+ * Lengths in cm (AOpticsManager::cm() == 1).
+ */
+typedef struct isx_config {
+  double r_in;           /* TGeoSphere rmin (100.1)                                   */
+  double r_out;          /* TGeoSphere rmax (101)                                     */
+  double theta_max_deg;  /* TGeoSphere theta2: shell spans polar angle [0,theta_max]  */
+  double reflectance;    /* AMirror::SetReflectance                                   */
+  double roughness_rad;  /* ABorderSurfaceCondition::SetGaussianRoughness (sigma)     */
+  double box_half;       /* TGeoBBox half edge                                        */
+  int32_t lambertian;    /* ABorderSurfaceCondition::EnableLambertian                 */
+  int32_t max_points;    /* AOpticsManager::SetLimit                                  */
+  double src[3];         /* ARay start point                                          */
+  double dir[3];         /* ARay direction (normalised by the library)                */
+  int32_t n_theta;       /* detector grid rows: theta_i=(i+.5)*90/n_theta              */
+  int32_t n_phi;         /* detector grid cols: phi_j=(j+.5)*360/n_phi                 */
+  double det_diameter;   /* Detector::width (used as a DIAMETER, fluxAtObserver.C:106) */
+  double det_distance;   /* Detector::setPosition radius (100)                        */
+  double exit_port_z;    /* exitPortZ (-100); also the point the detectors face       */
+  int32_t source_model;  /* ISX_SOURCE_*                                              */
+  int32_t reserved0;
+  double brdf[3];        /* BRDF(roughness, specular, diffuse) nonLambertianFlux.C:211 */
+} isx_config;
+
+/* Ray census of one call (all ranks' census add up). */
+typedef struct isx_stats {
+  uint64_t launched;
+  uint64_t exited;          /* left the world box (ARayArray::GetExited)                  */
+  uint64_t counted_below_z; /* exited with lastPoint.z < exit_port_z ("rays exiting port") */
+  uint64_t absorbed;
+  uint64_t suspended;       /* more than max_points track points                          */
+  uint64_t bin_increments;  /* sum of the histogram this call added                        */
+  uint64_t wall_hits;       /* mirror interactions (bounces) traced                        */
+  double t_kernel_ms;       /* HIP-event time of the kernels of this call, on their stream */
+} isx_stats;
+
+/* Fill cfg with the reference's constants for src(-60,0,-75), dir(5,0,0), port 170 deg
+ * (fluxAtObserverOptimize.C:33-41,892-896; 180x90 grid, 40 cm detector at 100 cm). */
+void isx_default_config(isx_config* cfg);
+
+/* Select device `device` (ordinal as seen by HIP), create stream + workspaces.      */
+int isx_init(int device);
+void isx_shutdown(void);
+const char* isx_strerror(int status);
+int isx_last_hip_error(void);
+int isx_abi_version(void);
+/* Name/arch/CU count of the bound device (buf may be NULL). Returns CU count or <0. */
+int isx_device_info(char* buf, int buflen);
+
+/*
+ * Trace rays [first_ray, first_ray+n_rays) of stream `seed` and add, for every
+ * detector position (i,j), the number of traced rays whose final line hits that
+ * detector (Detector::checkIntersection) into hits[i*n_phi+j].
+ * Replaces the per-position loop fluxAtObserverOptimize.C:542-579 / the
+ * trace-once loops fluxAtObserverFast.C:1143-1315.
+ * hits: caller-owned host buffer [n_theta*n_phi], ZEROED by the callee.
+ */
+int isx_fluxmap(const isx_config* cfg, uint64_t n_rays, uint64_t seed, uint64_t first_ray,
+                uint64_t* hits, isx_stats* stats);
+
+/*
+ * Same, but ACCUMULATES (+=) into a device-resident histogram d_hits
+ * [n_theta*n_phi] of uint64 (e.g. a torch tensor the caller will all-reduce
+ * over RCCL) on the library's stream; returns after the kernels are enqueued.
+ * isx_sync() waits; isx_take_stats() then returns the census + event time of
+ * everything enqueued since the previous isx_take_stats().
+ */
+int isx_fluxmap_device(const isx_config* cfg, uint64_t n_rays, uint64_t seed, uint64_t first_ray,
+                       uint64_t* d_hits);
+int isx_sync(void);
+int isx_take_stats(isx_stats* stats);
+/* The hipStream_t the library launches on (so callers can order work after it). */
+void* isx_stream(void);
+
+/*
+ * Per-ray end states, for parity tests against the oracle: status (isx_ray_status),
+ * last point, final direction, number of track points.  Host buffers sized n_rays.
+ */
+typedef enum isx_ray_status { ISX_RAY_EXITED = 1, ISX_RAY_ABSORBED = 2, ISX_RAY_SUSPENDED = 3 } isx_ray_status;
+int isx_trace_endstates(const isx_config* cfg, uint64_t n_rays, uint64_t seed, uint64_t first_ray,
+                        int32_t* status, int32_t* n_points, double* last_point /*[n][3]*/,
+                        double* direction /*[n][3]*/);
+
+/*
+ * Physical-disc sweep (integratingSphereDetectorSweep.C:31-105,145-172): n_disc
+ * discs (centre[3], unit axis[3]) of radius `radius`, half thickness `half_thick`;
+ * hits[k] = number of rays whose forward exit segment enters disc k's volume.
+ */
+int isx_disc_sweep(const isx_config* cfg, const double* centers_axes /*[n_disc][6]*/, int32_t n_disc,
+                   double radius, double half_thick, uint64_t n_rays, uint64_t seed, uint64_t first_ray,
+                   uint64_t* hits, isx_stats* stats);
+
+/* Host-side detector table exactly as Detector::setPosition builds it
+ * (fluxAtObserver.C:49-68): out[(i*n_phi+j)*6] = x,y,z,nx,ny,nz.  No GPU needed. */
+int isx_detector_table(const isx_config* cfg, double* out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ISX_H */
