@@ -1,0 +1,501 @@
+// isx_api.hip — C ABI of libisx (include/isx.h) over the gfx950 kernels.
+//
+// Host-side "geometry setup" here replaces setupOpticsManager()
+// (fluxAtObserverOptimize.C:192-230) and Detector::setPosition (fluxAtObserver.C:49-68):
+// it only evaluates closed-form constants and the detector table; all ray work is on the GPU.
+// There is no CPU compute path: without a device every entry point returns ISX_ERR_NO_DEVICE.
+#include "../../include/isx.h"
+#include "isx_kernels.hpp"
+
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+
+using namespace isx;
+
+namespace {
+
+struct State {
+  bool init = false;
+  int device = -1;
+  int cu_count = 0;
+  hipStream_t stream = nullptr;
+  int last_hip = 0;
+  // detector tables (device) + the config they were built for
+  isx_config tab_cfg{};
+  bool have_tab = false;
+  double* d_table = nullptr;
+  double* d_rowtab = nullptr;
+  double* d_coltab = nullptr;
+  size_t cap_bins = 0, cap_rows = 0, cap_cols = 0;
+  unsigned long long* d_hist = nullptr;
+  size_t cap_hist = 0;
+  unsigned long long* d_stats = nullptr;  // [8]
+  // options
+  int bin_mode = 1;
+  int blocks_per_cu = 2;
+  int grid_blocks = 0;  // 0 = auto
+  // timing of enqueued-but-not-collected launches
+  std::vector<hipEvent_t> ev_pool;
+  size_t ev_used = 0;
+  uint64_t launched_pending = 0;
+} S;
+
+#define HIPCHK(expr)                                 \
+  do {                                               \
+    hipError_t e_ = (expr);                          \
+    if (e_ != hipSuccess) {                          \
+      S.last_hip = (int)e_;                          \
+      return ISX_ERR_HIP;                            \
+    }                                                \
+  } while (0)
+
+int prepare_geom(const isx_config* c, Geom* g) {
+  if (!(c->r_in > 0) || !(c->r_out > c->r_in)) return ISX_ERR_BAD_CONFIG;
+  if (!(c->theta_max_deg > 90.0) || !(c->theta_max_deg < 180.0)) return ISX_ERR_BAD_CONFIG;
+  if (!(c->box_half > c->r_out)) return ISX_ERR_BAD_CONFIG;
+  if (c->max_points < 1) return ISX_ERR_BAD_CONFIG;
+  if (c->source_model != ISX_SOURCE_PENCIL && c->source_model != ISX_SOURCE_BRDF) return ISX_ERR_BAD_CONFIG;
+  g->rin2 = c->r_in * c->r_in;
+  g->rout2 = c->r_out * c->r_out;
+  const double th = c->theta_max_deg * M_PI / 180.0;
+  const double ct = std::cos(th);
+  const double tt = std::tan(th);
+  g->zcut_in = c->r_in * ct;
+  g->zcut_out = c->r_out * ct;
+  g->k2 = tt * tt;
+  g->ninv_rin = -1.0 / c->r_in;
+  g->inv_rout = 1.0 / c->r_out;
+  g->H = c->box_half;
+  g->rho = c->reflectance;
+  g->sigma = c->roughness_rad;
+  g->lambertian = c->lambertian;
+  g->limit = c->max_points;
+  g->source_model = c->source_model;
+  g->pad = 0;
+  for (int k = 0; k < 3; ++k) g->src[k] = c->src[k];
+  const double dx = c->dir[0], dy = c->dir[1], dz = c->dir[2];
+  const double mag = std::sqrt(dx * dx + dy * dy + dz * dz);
+  if (!(mag > 0)) return ISX_ERR_BAD_CONFIG;
+  g->dir0[0] = dx / mag; g->dir0[1] = dy / mag; g->dir0[2] = dz / mag;
+  g->brdf_theta_scale = c->brdf[0] * M_PI / 6;
+  const double sum = c->brdf[1] + c->brdf[2];
+  g->brdf_spec = sum != 0 ? c->brdf[1] / sum : 0.0;
+  return ISX_OK;
+}
+
+// Detector::setPosition, operation for operation (fluxAtObserver.C:49-68)
+void det_set_position(double theta, double phi, double radius, double portz, double* d) {
+  const double theta_rad = theta * M_PI / 180.0;
+  const double phi_rad = phi * M_PI / 180.0;
+  const double x = radius * std::sin(theta_rad) * std::cos(phi_rad);
+  const double y = radius * std::sin(theta_rad) * std::sin(phi_rad);
+  const double z = portz - radius * std::cos(theta_rad);
+  const double dx = x - 0;
+  const double dy = y - 0;
+  const double dz = z - (portz);
+  const double mag = std::sqrt(dx * dx + dy * dy + dz * dz);
+  d[0] = x; d[1] = y; d[2] = z;
+  d[3] = -dy / mag; d[4] = dx / mag; d[5] = dz / mag;
+}
+
+int check_grid(const isx_config* c) {
+  if (c->n_theta < 1 || c->n_phi < 1) return ISX_ERR_BAD_CONFIG;
+  if ((long long)c->n_theta * c->n_phi > 36000) return ISX_ERR_BAD_CONFIG;  // LDS histogram: 4 B/bin
+  if (!(c->det_diameter > 0) || !(c->det_distance > 0)) return ISX_ERR_BAD_CONFIG;
+  return ISX_OK;
+}
+
+void host_tables(const isx_config* c, std::vector<double>& table, std::vector<double>& rowtab,
+                 std::vector<double>& coltab) {
+  const int nt = c->n_theta, np = c->n_phi;
+  table.resize((size_t)nt * np * 6);
+  rowtab.resize((size_t)nt * 4);
+  coltab.resize((size_t)np * 2);
+  for (int i = 0; i < nt; ++i) {
+    const double theta = (i + 0.5) * 90.0 / nt;
+    const double theta_rad = theta * M_PI / 180.0;
+    rowtab[4 * i + 0] = std::sin(theta_rad);
+    rowtab[4 * i + 1] = std::cos(theta_rad);
+    rowtab[4 * i + 2] = c->exit_port_z - c->det_distance * std::cos(theta_rad);
+    rowtab[4 * i + 3] = c->det_distance * std::sin(theta_rad);
+    for (int j = 0; j < np; ++j) {
+      const double phi = (j + 0.5) * 360.0 / np;
+      det_set_position(theta, phi, c->det_distance, c->exit_port_z, &table[6 * ((size_t)i * np + j)]);
+    }
+  }
+  for (int j = 0; j < np; ++j) {
+    const double phi = (j + 0.5) * 360.0 / np;
+    const double phi_rad = phi * M_PI / 180.0;
+    coltab[2 * j + 0] = std::cos(phi_rad);
+    coltab[2 * j + 1] = std::sin(phi_rad);
+  }
+}
+
+bool same_grid(const isx_config& a, const isx_config& b) {
+  return a.n_theta == b.n_theta && a.n_phi == b.n_phi && a.det_distance == b.det_distance &&
+         a.exit_port_z == b.exit_port_z;
+}
+
+int ensure_tables(const isx_config* c) {
+  if (S.have_tab && same_grid(S.tab_cfg, *c)) return ISX_OK;
+  std::vector<double> table, rowtab, coltab;
+  host_tables(c, table, rowtab, coltab);
+  HIPCHK(hipStreamSynchronize(S.stream));
+  if (table.size() > S.cap_bins) {
+    if (S.d_table) HIPCHK(hipFree(S.d_table));
+    HIPCHK(hipMalloc(&S.d_table, table.size() * sizeof(double)));
+    S.cap_bins = table.size();
+  }
+  if (rowtab.size() > S.cap_rows) {
+    if (S.d_rowtab) HIPCHK(hipFree(S.d_rowtab));
+    HIPCHK(hipMalloc(&S.d_rowtab, rowtab.size() * sizeof(double)));
+    S.cap_rows = rowtab.size();
+  }
+  if (coltab.size() > S.cap_cols) {
+    if (S.d_coltab) HIPCHK(hipFree(S.d_coltab));
+    HIPCHK(hipMalloc(&S.d_coltab, coltab.size() * sizeof(double)));
+    S.cap_cols = coltab.size();
+  }
+  HIPCHK(hipMemcpy(S.d_table, table.data(), table.size() * sizeof(double), hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(S.d_rowtab, rowtab.data(), rowtab.size() * sizeof(double), hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(S.d_coltab, coltab.data(), coltab.size() * sizeof(double), hipMemcpyHostToDevice));
+  S.tab_cfg = *c;
+  S.have_tab = true;
+  return ISX_OK;
+}
+
+int get_event(hipEvent_t* ev) {
+  if (S.ev_used == S.ev_pool.size()) {
+    hipEvent_t e;
+    HIPCHK(hipEventCreate(&e));
+    S.ev_pool.push_back(e);
+  }
+  *ev = S.ev_pool[S.ev_used++];
+  return ISX_OK;
+}
+
+int pick_grid(uint64_t n) {
+  if (S.grid_blocks > 0) return S.grid_blocks;
+  const int full = S.cu_count * S.blocks_per_cu;
+  // keep >= 16 rays per lane so the refill loop has something to refill from
+  const uint64_t want = (n + (uint64_t)kBlock * 16 - 1) / ((uint64_t)kBlock * 16);
+  if (want < 1) return 1;
+  return want < (uint64_t)full ? (int)want : full;
+}
+
+// enqueue one persistent kernel accumulating into d_hist (device) and S.d_stats
+int enqueue(int sink, const isx_config* c, uint64_t n, uint64_t seed, uint64_t first, unsigned long long* d_hist,
+            int nbins_override, const double* d_discs, double disc_r, double disc_h) {
+  Geom g;
+  int rc = prepare_geom(c, &g);
+  if (rc) return rc;
+  if (n > ISX_MAX_RAYS_PER_CALL) return ISX_ERR_TOO_LARGE;
+  DetGrid d;
+  std::memset(&d, 0, sizeof(d));
+  d.portz = c->exit_port_z;
+  size_t lds = 0;
+  if (sink == SINK_FLUX) {
+    rc = check_grid(c);
+    if (rc) return rc;
+    rc = ensure_tables(c);
+    if (rc) return rc;
+    d.n_theta = c->n_theta; d.n_phi = c->n_phi; d.nbins = c->n_theta * c->n_phi; d.bin_mode = S.bin_mode;
+    d.half_w2 = (c->det_diameter / 2) * (c->det_diameter / 2);
+    d.rho_d = c->det_diameter / 2;
+    d.R = c->det_distance;
+    d.table = S.d_table; d.rowtab = S.d_rowtab; d.coltab = S.d_coltab;
+    lds = (((size_t)d.nbins * 4 + 15) & ~(size_t)15) + (size_t)(4 * d.n_theta + 2 * d.n_phi) * 8 + 64;
+  } else {
+    if (nbins_override < 1 || nbins_override > 36000) return ISX_ERR_BAD_ARG;
+    d.nbins = nbins_override;
+    d.discs = d_discs; d.disc_r = disc_r; d.disc_h = disc_h;
+    lds = (((size_t)d.nbins * 4 + 15) & ~(size_t)15) + 64;
+  }
+  if (n == 0) return ISX_OK;
+  Work wk;
+  wk.seed = seed; wk.first = first; wk.n = n; wk.hist = d_hist; wk.stats = S.d_stats;
+  const int grid = pick_grid(n);
+  hipEvent_t e0, e1;
+  rc = get_event(&e0); if (rc) return rc;
+  rc = get_event(&e1); if (rc) return rc;
+  const void* fn = sink == SINK_FLUX ? (const void*)isx_trace_bin_kernel
+                   : sink == SINK_DZ ? (const void*)isx_trace_dz_kernel : (const void*)isx_trace_disc_kernel;
+  HIPCHK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  HIPCHK(hipEventRecord(e0, S.stream));
+  if (sink == SINK_FLUX) hipLaunchKernelGGL(isx_trace_bin_kernel, dim3(grid), dim3(kBlock), lds, S.stream, g, d, wk);
+  else if (sink == SINK_DZ) hipLaunchKernelGGL(isx_trace_dz_kernel, dim3(grid), dim3(kBlock), lds, S.stream, g, d, wk);
+  else hipLaunchKernelGGL(isx_trace_disc_kernel, dim3(grid), dim3(kBlock), lds, S.stream, g, d, wk);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipEventRecord(e1, S.stream));
+  S.launched_pending += n;
+  return ISX_OK;
+}
+
+int ensure_hist(size_t nb) {
+  if (nb > S.cap_hist) {
+    HIPCHK(hipStreamSynchronize(S.stream));
+    if (S.d_hist) HIPCHK(hipFree(S.d_hist));
+    HIPCHK(hipMalloc(&S.d_hist, nb * sizeof(unsigned long long)));
+    S.cap_hist = nb;
+  }
+  return ISX_OK;
+}
+
+int collect_stats(isx_stats* out) {
+  HIPCHK(hipStreamSynchronize(S.stream));
+  double ms = 0;
+  for (size_t k = 0; k + 1 < S.ev_used; k += 2) {
+    float t = 0;
+    HIPCHK(hipEventElapsedTime(&t, S.ev_pool[k], S.ev_pool[k + 1]));
+    ms += t;
+  }
+  S.ev_used = 0;
+  unsigned long long h[8];
+  HIPCHK(hipMemcpy(h, S.d_stats, sizeof(h), hipMemcpyDeviceToHost));
+  HIPCHK(hipMemset(S.d_stats, 0, sizeof(h)));
+  S.launched_pending = 0;
+  if (out) {
+    out->launched = h[0]; out->exited = h[1]; out->counted_below_z = h[2]; out->absorbed = h[3];
+    out->suspended = h[4]; out->bin_increments = h[5]; out->wall_hits = h[6];
+    out->t_kernel_ms = ms;
+  }
+  return ISX_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int isx_abi_version(void) { return ISX_ABI_VERSION; }
+
+void isx_default_config(isx_config* c) {
+  if (!c) return;
+  std::memset(c, 0, sizeof(*c));
+  // fluxAtObserverOptimize.C:33-41 and sweepSeries() :892-896
+  c->r_in = 100.1; c->r_out = 101.0; c->theta_max_deg = 170.0;
+  c->reflectance = 0.99; c->roughness_rad = 0.01; c->box_half = 300.0;
+  c->lambertian = 1; c->max_points = 50000;
+  c->src[0] = -60; c->src[1] = 0; c->src[2] = -75;
+  c->dir[0] = 5; c->dir[1] = 0; c->dir[2] = 0;
+  c->n_theta = 180; c->n_phi = 90;
+  c->det_diameter = 40.0; c->det_distance = 100.0; c->exit_port_z = -100.0;
+  c->source_model = ISX_SOURCE_PENCIL;
+  c->brdf[0] = 0.3; c->brdf[1] = 0.4; c->brdf[2] = 0.6;  // nonLambertianFlux.C:211
+}
+
+const char* isx_strerror(int s) {
+  switch (s) {
+    case ISX_OK: return "ok";
+    case ISX_ERR_NO_DEVICE: return "no HIP device available (libisx has no CPU fallback)";
+    case ISX_ERR_BAD_CONFIG: return "configuration outside the supported domain";
+    case ISX_ERR_BAD_ARG: return "bad argument";
+    case ISX_ERR_HIP: return "HIP runtime error (see isx_last_hip_error)";
+    case ISX_ERR_NOT_INIT: return "isx_init() has not been called";
+    case ISX_ERR_TOO_LARGE: return "too many rays for one call";
+    default: return "unknown status";
+  }
+}
+
+int isx_last_hip_error(void) { return S.last_hip; }
+
+int isx_init(int device) {
+  if (S.init) {
+    if (device == S.device) return ISX_OK;
+    isx_shutdown();
+  }
+  int count = 0;
+  hipError_t e = hipGetDeviceCount(&count);
+  if (e != hipSuccess || count <= 0) { S.last_hip = (int)e; return ISX_ERR_NO_DEVICE; }
+  if (device < 0 || device >= count) return ISX_ERR_BAD_ARG;
+  HIPCHK(hipSetDevice(device));
+  hipDeviceProp_t prop;
+  HIPCHK(hipGetDeviceProperties(&prop, device));
+  S.cu_count = prop.multiProcessorCount;
+  HIPCHK(hipStreamCreateWithFlags(&S.stream, hipStreamNonBlocking));
+  HIPCHK(hipMalloc(&S.d_stats, 8 * sizeof(unsigned long long)));
+  HIPCHK(hipMemset(S.d_stats, 0, 8 * sizeof(unsigned long long)));
+  S.device = device;
+  S.init = true;
+  S.have_tab = false;
+  if (const char* m = std::getenv("ISX_BIN_MODE")) S.bin_mode = std::atoi(m) != 0;
+  return ISX_OK;
+}
+
+void isx_shutdown(void) {
+  if (!S.init) return;
+  (void)hipStreamSynchronize(S.stream);
+  for (hipEvent_t e : S.ev_pool) (void)hipEventDestroy(e);
+  S.ev_pool.clear();
+  S.ev_used = 0;
+  if (S.d_table) (void)hipFree(S.d_table);
+  if (S.d_rowtab) (void)hipFree(S.d_rowtab);
+  if (S.d_coltab) (void)hipFree(S.d_coltab);
+  if (S.d_hist) (void)hipFree(S.d_hist);
+  if (S.d_stats) (void)hipFree(S.d_stats);
+  S.d_table = S.d_rowtab = S.d_coltab = nullptr;
+  S.d_hist = S.d_stats = nullptr;
+  S.cap_bins = S.cap_rows = S.cap_cols = S.cap_hist = 0;
+  (void)hipStreamDestroy(S.stream);
+  S.stream = nullptr;
+  S.init = false;
+  S.have_tab = false;
+}
+
+int isx_device_info(char* buf, int buflen) {
+  if (!S.init) return ISX_ERR_NOT_INIT;
+  hipDeviceProp_t prop;
+  HIPCHK(hipGetDeviceProperties(&prop, S.device));
+  if (buf && buflen > 0) std::snprintf(buf, (size_t)buflen, "%s %s cu=%d", prop.name, prop.gcnArchName, prop.multiProcessorCount);
+  return prop.multiProcessorCount;
+}
+
+int isx_set_option(const char* key, int64_t value) {
+  if (!key) return ISX_ERR_BAD_ARG;
+  if (!std::strcmp(key, "bin_mode")) { S.bin_mode = value != 0; return ISX_OK; }
+  if (!std::strcmp(key, "blocks_per_cu")) { if (value < 1 || value > 8) return ISX_ERR_BAD_ARG; S.blocks_per_cu = (int)value; return ISX_OK; }
+  if (!std::strcmp(key, "grid_blocks")) { if (value < 0 || value > 65535) return ISX_ERR_BAD_ARG; S.grid_blocks = (int)value; return ISX_OK; }
+  return ISX_ERR_BAD_ARG;
+}
+
+void* isx_stream(void) { return (void*)S.stream; }
+
+int isx_sync(void) {
+  if (!S.init) return ISX_ERR_NOT_INIT;
+  HIPCHK(hipStreamSynchronize(S.stream));
+  return ISX_OK;
+}
+
+int isx_take_stats(isx_stats* stats) {
+  if (!S.init) return ISX_ERR_NOT_INIT;
+  return collect_stats(stats);
+}
+
+int isx_fluxmap_device(const isx_config* cfg, uint64_t n_rays, uint64_t seed, uint64_t first_ray, uint64_t* d_hits) {
+  if (!S.init) return ISX_ERR_NOT_INIT;
+  if (!cfg || !d_hits) return ISX_ERR_BAD_ARG;
+  return enqueue(SINK_FLUX, cfg, n_rays, seed, first_ray, (unsigned long long*)d_hits, 0, nullptr, 0, 0);
+}
+
+int isx_fluxmap(const isx_config* cfg, uint64_t n_rays, uint64_t seed, uint64_t first_ray, uint64_t* hits,
+                isx_stats* stats) {
+  if (!S.init) return ISX_ERR_NOT_INIT;
+  if (!cfg || !hits) return ISX_ERR_BAD_ARG;
+  int rc = check_grid(cfg);
+  if (rc) return rc;
+  const size_t nb = (size_t)cfg->n_theta * cfg->n_phi;
+  rc = ensure_hist(nb);
+  if (rc) return rc;
+  // census of anything enqueued earlier must not leak into this call
+  rc = collect_stats(nullptr);
+  if (rc) return rc;
+  HIPCHK(hipMemsetAsync(S.d_hist, 0, nb * sizeof(unsigned long long), S.stream));
+  rc = enqueue(SINK_FLUX, cfg, n_rays, seed, first_ray, S.d_hist, 0, nullptr, 0, 0);
+  if (rc) return rc;
+  HIPCHK(hipMemcpyAsync(hits, S.d_hist, nb * sizeof(unsigned long long), hipMemcpyDeviceToHost, S.stream));
+  return collect_stats(stats);
+}
+
+int isx_trace_endstates(const isx_config* cfg, uint64_t n, uint64_t seed, uint64_t first, int32_t* status,
+                        int32_t* n_points, double* last_point, double* direction) {
+  if (!S.init) return ISX_ERR_NOT_INIT;
+  if (!cfg || !status || !n_points || !last_point || !direction) return ISX_ERR_BAD_ARG;
+  if (n == 0) return ISX_OK;
+  if (n > (1ull << 28)) return ISX_ERR_TOO_LARGE;
+  Geom g;
+  int rc = prepare_geom(cfg, &g);
+  if (rc) return rc;
+  int32_t *d_st = nullptr, *d_np = nullptr;
+  double *d_lp = nullptr, *d_dir = nullptr;
+  HIPCHK(hipMalloc(&d_st, n * 4));
+  HIPCHK(hipMalloc(&d_np, n * 4));
+  HIPCHK(hipMalloc(&d_lp, n * 24));
+  HIPCHK(hipMalloc(&d_dir, n * 24));
+  const int blk = 256;
+  const unsigned grid = (unsigned)((n + blk - 1) / blk);
+  hipLaunchKernelGGL(isx_endstates_kernel, dim3(grid), dim3(blk), 0, S.stream, g, seed, first, n, d_st, d_np, d_lp, d_dir);
+  hipError_t e = hipGetLastError();
+  if (e == hipSuccess) e = hipMemcpyAsync(status, d_st, n * 4, hipMemcpyDeviceToHost, S.stream);
+  if (e == hipSuccess) e = hipMemcpyAsync(n_points, d_np, n * 4, hipMemcpyDeviceToHost, S.stream);
+  if (e == hipSuccess) e = hipMemcpyAsync(last_point, d_lp, n * 24, hipMemcpyDeviceToHost, S.stream);
+  if (e == hipSuccess) e = hipMemcpyAsync(direction, d_dir, n * 24, hipMemcpyDeviceToHost, S.stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(S.stream);
+  (void)hipFree(d_st); (void)hipFree(d_np); (void)hipFree(d_lp); (void)hipFree(d_dir);
+  if (e != hipSuccess) { S.last_hip = (int)e; return ISX_ERR_HIP; }
+  return ISX_OK;
+}
+
+int isx_mathprobe(int op, const double* a, const double* b, const double* c, double* out, int32_t n) {
+  if (!S.init) return ISX_ERR_NOT_INIT;
+  if (!a || !out || n <= 0) return ISX_ERR_BAD_ARG;
+  double *da = nullptr, *db = nullptr, *dc = nullptr, *dout = nullptr;
+  const size_t bytes = (size_t)n * 8;
+  HIPCHK(hipMalloc(&da, bytes)); HIPCHK(hipMalloc(&db, bytes)); HIPCHK(hipMalloc(&dc, bytes)); HIPCHK(hipMalloc(&dout, bytes));
+  HIPCHK(hipMemcpy(da, a, bytes, hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(db, b ? b : a, bytes, hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(dc, c ? c : a, bytes, hipMemcpyHostToDevice));
+  hipLaunchKernelGGL(isx_mathprobe_kernel, dim3((n + 255) / 256), dim3(256), 0, S.stream, op, da, db, dc, dout, n);
+  hipError_t e = hipGetLastError();
+  if (e == hipSuccess) e = hipStreamSynchronize(S.stream);
+  if (e == hipSuccess) e = hipMemcpy(out, dout, bytes, hipMemcpyDeviceToHost);
+  (void)hipFree(da); (void)hipFree(db); (void)hipFree(dc); (void)hipFree(dout);
+  if (e != hipSuccess) { S.last_hip = (int)e; return ISX_ERR_HIP; }
+  return ISX_OK;
+}
+
+int isx_detector_table(const isx_config* cfg, double* out) {
+  if (!cfg || !out) return ISX_ERR_BAD_ARG;
+  if (cfg->n_theta < 1 || cfg->n_phi < 1) return ISX_ERR_BAD_CONFIG;
+  for (int i = 0; i < cfg->n_theta; ++i) {
+    const double theta = (i + 0.5) * 90.0 / cfg->n_theta;
+    for (int j = 0; j < cfg->n_phi; ++j) {
+      const double phi = (j + 0.5) * 360.0 / cfg->n_phi;
+      det_set_position(theta, phi, cfg->det_distance, cfg->exit_port_z, out + 6 * ((size_t)i * cfg->n_phi + j));
+    }
+  }
+  return ISX_OK;
+}
+
+int isx_disc_sweep(const isx_config* cfg, const double* centers_axes, int32_t n_disc, double radius, double half_thick,
+                   uint64_t n_rays, uint64_t seed, uint64_t first_ray, uint64_t* hits, isx_stats* stats) {
+  if (!S.init) return ISX_ERR_NOT_INIT;
+  if (!cfg || !centers_axes || !hits || n_disc < 1) return ISX_ERR_BAD_ARG;
+  if (cfg->source_model != ISX_SOURCE_PENCIL) return ISX_ERR_BAD_CONFIG;
+  if (!(radius > 0) || !(half_thick > 0)) return ISX_ERR_BAD_ARG;
+  int rc = ensure_hist((size_t)n_disc);
+  if (rc) return rc;
+  rc = collect_stats(nullptr);
+  if (rc) return rc;
+  double* d_discs = nullptr;
+  HIPCHK(hipMalloc(&d_discs, (size_t)n_disc * 6 * sizeof(double)));
+  hipError_t e = hipMemcpy(d_discs, centers_axes, (size_t)n_disc * 6 * sizeof(double), hipMemcpyHostToDevice);
+  if (e == hipSuccess) e = hipMemsetAsync(S.d_hist, 0, (size_t)n_disc * sizeof(unsigned long long), S.stream);
+  if (e != hipSuccess) { (void)hipFree(d_discs); S.last_hip = (int)e; return ISX_ERR_HIP; }
+  rc = enqueue(SINK_DISC, cfg, n_rays, seed, first_ray, S.d_hist, n_disc, d_discs, radius, half_thick);
+  if (rc == ISX_OK) {
+    e = hipMemcpyAsync(hits, S.d_hist, (size_t)n_disc * sizeof(unsigned long long), hipMemcpyDeviceToHost, S.stream);
+    if (e != hipSuccess) { S.last_hip = (int)e; rc = ISX_ERR_HIP; }
+  }
+  const int rc2 = collect_stats(stats);
+  (void)hipFree(d_discs);
+  return rc ? rc : rc2;
+}
+
+int isx_exit_dz_hist(const isx_config* cfg, uint64_t n_rays, uint64_t seed, uint64_t first_ray, int32_t nbins,
+                     uint64_t* hist, isx_stats* stats) {
+  if (!S.init) return ISX_ERR_NOT_INIT;
+  if (!cfg || !hist || nbins < 1) return ISX_ERR_BAD_ARG;
+  int rc = ensure_hist((size_t)nbins);
+  if (rc) return rc;
+  rc = collect_stats(nullptr);
+  if (rc) return rc;
+  HIPCHK(hipMemsetAsync(S.d_hist, 0, (size_t)nbins * sizeof(unsigned long long), S.stream));
+  rc = enqueue(SINK_DZ, cfg, n_rays, seed, first_ray, S.d_hist, nbins, nullptr, 0, 0);
+  if (rc) return rc;
+  HIPCHK(hipMemcpyAsync(hist, S.d_hist, (size_t)nbins * sizeof(unsigned long long), hipMemcpyDeviceToHost, S.stream));
+  return collect_stats(stats);
+}
+
+}  // extern "C"

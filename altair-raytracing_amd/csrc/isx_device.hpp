@@ -1,0 +1,401 @@
+// isx_device.hpp — gfx950 device code of the integrating-sphere tracer (product code).
+//
+// Numeric contract: every value that can reach a branch or an output is
+// computed with IEEE binary64 +,-,*,/,sqrt and EXPLICIT fma() in exactly the expression
+// order of the specification; the translation unit is built with -ffp-contract=off so
+// hipcc adds no fused operation of its own.  Anything marked "cull" is conservative
+// pre-selection and never decides a result.
+//
+// Reference behaviour replaced (see include/isx.h for the full list):
+//   AOpticsManager::TraceNonSequential  fluxAtObserverOptimize.C:254,295 (ROBAST, behaviour inferred)
+//   port test                            fluxAtObserver.C:162-166
+//   Detector::checkIntersection          fluxAtObserver.C:70-107
+//   BRDF                                 nonLambertianFlux.C:147-208
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace isx {
+
+struct V3 { double x, y, z; };
+
+enum : int { K_NONE = 0, K_INNER = 1, K_OUTER = 2, K_CONE = 3, K_BOX = 4 };
+enum : int { ST_EXITED = 1, ST_ABSORBED = 2, ST_SUSPENDED = 3 };
+
+// Kernel-argument block: prepared geometry (host computes it with the spec's expressions).
+struct Geom {
+  double rin2, rout2, zcut_in, zcut_out, k2, ninv_rin, inv_rout, H, rho, sigma;
+  double src[3], dir0[3];
+  double brdf_theta_scale;  // rough * M_PI / 6   (nonLambertianFlux.C:178)
+  double brdf_spec;         // specular/(specular+diffuse) (:157-159)
+  int lambertian, limit, source_model, pad;
+};
+
+__device__ __forceinline__ double dot3(const V3& a, const V3& b) { return fma(a.x, b.x, fma(a.y, b.y, a.z * b.z)); }
+__device__ __forceinline__ V3 axpy(double t, const V3& v, const V3& p) {
+  V3 q;
+  q.x = fma(t, v.x, p.x); q.y = fma(t, v.y, p.y); q.z = fma(t, v.z, p.z);
+  return q;
+}
+
+// ---------------------------------------------------------------- Philox4x32-10
+__device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0,
+                                              uint32_t k1, uint32_t w[4]) {
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+    const uint64_t p0 = (uint64_t)0xD2511F53u * c0;
+    const uint64_t p1 = (uint64_t)0xCD9E8D57u * c2;
+    const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0;
+    const uint32_t n1 = (uint32_t)p1;
+    const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
+    const uint32_t n3 = (uint32_t)p0;
+    c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+    k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+  }
+  w[0] = c0; w[1] = c1; w[2] = c2; w[3] = c3;
+}
+__device__ __forceinline__ void draw_block(uint64_t seed, uint64_t ray, uint32_t block, uint32_t stream, uint32_t w[4]) {
+  philox4x32_10((uint32_t)ray, (uint32_t)(ray >> 32), block, stream, (uint32_t)seed, (uint32_t)(seed >> 32), w);
+}
+__device__ __forceinline__ double u01(uint32_t w) { return ((double)w + 0.5) * 0x1.0p-32; }
+
+// ---------------------------------------------------------------- elementary functions
+__device__ __forceinline__ double kern_sin(double x) {
+  const double S1 = -1.66666666666666324348e-01, S2 = 8.33333333332248946124e-03, S3 = -1.98412698298579493134e-04,
+               S4 = 2.75573137070700676789e-06, S5 = -2.50507602534068634195e-08, S6 = 1.58969099521155010221e-10;
+  const double z = x * x;
+  const double r = fma(z, fma(z, fma(z, fma(z, S6, S5), S4), S3), S2);
+  const double v = z * x;
+  return fma(v, fma(z, r, S1), x);
+}
+__device__ __forceinline__ double kern_cos(double x) {
+  const double C1 = 4.16666666666666019037e-02, C2 = -1.38888888888741095749e-03, C3 = 2.48015872894767294178e-05,
+               C4 = -2.75573143513906633035e-07, C5 = 2.08757232129817482790e-09, C6 = -1.13596475577881948265e-11;
+  const double z = x * x;
+  const double r = z * fma(z, fma(z, fma(z, fma(z, fma(z, C6, C5), C4), C3), C2), C1);
+  const double hz = 0.5 * z;
+  const double w = 1.0 - hz;
+  return w + (((1.0 - w) - hz) + z * r);
+}
+__device__ __forceinline__ void quadrant(int k, double s, double c, double& so, double& co) {
+  const bool swap = (k & 1) != 0;
+  const double a = swap ? c : s;   // candidate for sin
+  const double b = swap ? s : c;   // candidate for cos
+  // k&3: 0:(s,c) 1:(c,-s) 2:(-s,-c) 3:(-c,s)
+  const bool negs = (k & 2) != 0;            // sin negated for k=2,3
+  const bool negc = ((k + 1) & 2) != 0;      // cos negated for k=1,2
+  so = negs ? -a : a;
+  co = negc ? -b : b;
+}
+__device__ __forceinline__ void sincos2pi(double u, double& s, double& c) {
+  const double PIO2 = 1.57079632679489655800e+00;
+  const double t = 4.0 * u;
+  const double kd = floor(t + 0.5);
+  const double r = t - kd;
+  const double x = r * PIO2;
+  quadrant((int)kd, kern_sin(x), kern_cos(x), s, c);
+}
+__device__ __forceinline__ void sincos_cw(double x, double& s, double& c) {
+  const double INVPIO2 = 6.36619772367581382433e-01;
+  const double PIO2_1 = 1.57079632673412561417e+00;
+  const double PIO2_1T = 6.07710050650619224932e-11;
+  const double kd = floor(fma(x, INVPIO2, 0.5));
+  double r = fma(-kd, PIO2_1, x);
+  r = fma(-kd, PIO2_1T, r);
+  quadrant((int)kd, kern_sin(r), kern_cos(r), s, c);
+}
+__device__ __forceinline__ double log_pos(double x) {
+  const double LN2_HI = 6.93147180369123816490e-01, LN2_LO = 1.90821492927058770002e-10;
+  const double Lg1 = 6.666666666666735130e-01, Lg2 = 3.999999999940941908e-01, Lg3 = 2.857142874366239149e-01,
+               Lg4 = 2.222219843214978396e-01, Lg5 = 1.818357216161805012e-01, Lg6 = 1.531383769920937332e-01,
+               Lg7 = 1.479819860511658591e-01;
+  const uint64_t bits = (uint64_t)__double_as_longlong(x);
+  int e = (int)(bits >> 52) - 1023;
+  const uint64_t mant = bits & 0x000FFFFFFFFFFFFFull;
+  const bool big = mant > 0x6A09E667F3BCCull;
+  const uint64_t mb = mant | (big ? 0x3FE0000000000000ull : 0x3FF0000000000000ull);
+  e += big ? 1 : 0;
+  const double m = __longlong_as_double((long long)mb);
+  const double f = m - 1.0;
+  const double s = f / (2.0 + f);
+  const double z = s * s;
+  const double w = z * z;
+  const double t1 = w * fma(w, fma(w, Lg6, Lg4), Lg2);
+  const double t2 = z * fma(w, fma(w, fma(w, Lg7, Lg5), Lg3), Lg1);
+  const double R = t2 + t1;
+  const double hfsq = 0.5 * f * f;
+  const double dk = (double)e;
+  return dk * LN2_HI - ((hfsq - (s * (hfsq + R) + dk * LN2_LO)) - f);
+}
+
+// ---------------------------------------------------------------- next boundary
+__device__ __forceinline__ void consider(double t, const V3& q, int kind, double& best, V3& bq, int& bk) {
+  if (t > 0.0 && t < best) { best = t; bq = q; bk = kind; }
+}
+
+// Generic nearest boundary (all surfaces).  Rare path: port transits, rim, outer sphere, box.
+__device__ inline int next_hit_generic(const Geom& g, const V3 p, const V3 v, const int on, V3& q_out) {
+  const double b = dot3(p, v);
+  const double pp = dot3(p, p);
+  double best = __builtin_inf();
+  V3 bq = p;
+  int bk = K_BOX;
+  {
+    const double ci = pp - g.rin2;
+    const double di = fma(b, b, -ci);
+    if (di >= 0.0) {
+      const double s = sqrt(di);
+      const double tn = -b - s, tf = s - b;
+      if ((on == K_INNER && b < 0.0) || (on == K_NONE && ci < 0.0)) {
+        const V3 q = axpy(tf, v, p);
+        if (q.z >= g.zcut_in) { q_out = q; return K_INNER; }
+      }
+      const bool skip_n = (on == K_INNER && b < 0.0);
+      const bool skip_f = (on == K_INNER && !(b < 0.0));
+      if (!skip_n) { const V3 q = axpy(tn, v, p); if (q.z >= g.zcut_in) consider(tn, q, K_INNER, best, bq, bk); }
+      if (!skip_f) { const V3 q = axpy(tf, v, p); if (q.z >= g.zcut_in) consider(tf, q, K_INNER, best, bq, bk); }
+    }
+  }
+  {
+    const double co = pp - g.rout2;
+    const double dO = fma(b, b, -co);
+    if (dO >= 0.0) {
+      const double s = sqrt(dO);
+      const double tn = -b - s, tf = s - b;
+      const bool skip_n = (on == K_OUTER && b < 0.0);
+      const bool skip_f = (on == K_OUTER && !(b < 0.0));
+      if (!skip_n) { const V3 q = axpy(tn, v, p); if (q.z >= g.zcut_out) consider(tn, q, K_OUTER, best, bq, bk); }
+      if (!skip_f) { const V3 q = axpy(tf, v, p); if (q.z >= g.zcut_out) consider(tf, q, K_OUTER, best, bq, bk); }
+    }
+  }
+  {
+    const double A = fma(-g.k2, v.z * v.z, fma(v.x, v.x, v.y * v.y));
+    const double B = fma(-g.k2, p.z * v.z, fma(p.x, v.x, p.y * v.y));
+    const double C = fma(-g.k2, p.z * p.z, fma(p.x, p.x, p.y * p.y));
+    double tc0 = 0.0, tc1 = 0.0;
+    int nc = 0;
+    if (on == K_CONE) {
+      if (A != 0.0) { tc0 = (-2.0 * B) / A; nc = 1; }
+    } else if (A == 0.0) {
+      if (B != 0.0) { tc0 = (-C) / (2.0 * B); nc = 1; }
+    } else {
+      const double D = fma(B, B, -(A * C));
+      if (D >= 0.0) {
+        const double sD = sqrt(D);
+        tc0 = (-B - sD) / A;
+        tc1 = (-B + sD) / A;
+        nc = 2;
+      }
+    }
+    if (nc >= 1) {
+      const V3 q = axpy(tc0, v, p);
+      const double rr = dot3(q, q);
+      if (q.z < 0.0 && rr >= g.rin2 && rr <= g.rout2) consider(tc0, q, K_CONE, best, bq, bk);
+    }
+    if (nc >= 2) {
+      const V3 q = axpy(tc1, v, p);
+      const double rr = dot3(q, q);
+      if (q.z < 0.0 && rr >= g.rin2 && rr <= g.rout2) consider(tc1, q, K_CONE, best, bq, bk);
+    }
+  }
+  if (bk != K_BOX) { q_out = bq; return bk; }
+  const double inf = __builtin_inf();
+  const double tx = v.x > 0.0 ? (g.H - p.x) / v.x : (v.x < 0.0 ? (-g.H - p.x) / v.x : inf);
+  const double ty = v.y > 0.0 ? (g.H - p.y) / v.y : (v.y < 0.0 ? (-g.H - p.y) / v.y : inf);
+  const double tz = v.z > 0.0 ? (g.H - p.z) / v.z : (v.z < 0.0 ? (-g.H - p.z) / v.z : inf);
+  double t = tx;
+  if (ty < t) t = ty;
+  if (tz < t) t = tz;
+  q_out = axpy(t, v, p);
+  return K_BOX;
+}
+
+// Hot path = Rule S1 of the spec: inside/on the inner ball heading inward, far root on the
+// mirror patch.  Anything else falls to the generic search (which re-derives the same numbers).
+__device__ __forceinline__ int next_hit(const Geom& g, const V3& p, const V3& v, const int on, V3& q_out) {
+  const double b = dot3(p, v);
+  const double pp = dot3(p, p);
+  const double ci = pp - g.rin2;
+  const double di = fma(b, b, -ci);
+  const bool s1 = (di >= 0.0) && ((on == K_INNER && b < 0.0) || (on == K_NONE && ci < 0.0));
+  if (s1) {
+    const double s = sqrt(di);
+    const double tf = s - b;
+    const V3 q = axpy(tf, v, p);
+    if (q.z >= g.zcut_in) { q_out = q; return K_INNER; }
+  }
+  return next_hit_generic(g, p, v, on, q_out);
+}
+
+// ---------------------------------------------------------------- surface interaction
+__device__ __forceinline__ void onb(const V3& n, V3& t1, V3& t2) {
+  const double sg = copysign(1.0, n.z);
+  const double a = -1.0 / (sg + n.z);
+  const double b = (n.x * n.y) * a;
+  t1.x = fma(sg * n.x, n.x * a, 1.0);
+  t1.y = sg * b;
+  t1.z = -(sg * n.x);
+  t2.x = b;
+  t2.y = fma(n.y, n.y * a, sg);
+  t2.z = -n.y;
+}
+
+__device__ __forceinline__ V3 surface_normal(const Geom& g, int kind, const V3& q) {
+  V3 n;
+  if (kind == K_INNER) {
+    n.x = q.x * g.ninv_rin; n.y = q.y * g.ninv_rin; n.z = q.z * g.ninv_rin;
+  } else if (kind == K_OUTER) {
+    n.x = q.x * g.inv_rout; n.y = q.y * g.inv_rout; n.z = q.z * g.inv_rout;
+  } else {
+    const double gz = g.k2 * q.z;
+    const double nn = sqrt(fma(q.x, q.x, fma(q.y, q.y, gz * gz)));
+    n.x = -q.x / nn; n.y = -q.y / nn; n.z = gz / nn;
+  }
+  return n;
+}
+
+// returns false if absorbed; otherwise v is the re-emitted direction
+__device__ __forceinline__ bool interact(const Geom& g, int kind, const V3& q, V3& v, uint64_t seed, uint64_t ray,
+                                         uint32_t j, uint32_t stream) {
+  uint32_t wl[4];
+  draw_block(seed, ray, 2u * j, stream, wl);
+  if (!(u01(wl[2]) < g.rho)) return false;
+  const V3 n = surface_normal(g, kind, q);
+  V3 w;
+  if (g.lambertian) {
+    // cosine-law re-emission about the geometric normal; roughness does not act on a
+    // Lambertian border
+    V3 A, Bv;
+    onb(n, A, Bv);
+    const double u1 = u01(wl[0]), u2 = u01(wl[1]);
+    const double r = sqrt(u1);
+    const double z = sqrt(1.0 - u1);
+    double sf, cf;
+    sincos2pi(u2, sf, cf);
+    const double x = r * cf, y = r * sf;
+    w.x = fma(x, A.x, fma(y, Bv.x, z * n.x));
+    w.y = fma(x, A.y, fma(y, Bv.y, z * n.y));
+    w.z = fma(x, A.z, fma(y, Bv.z, z * n.z));
+  } else {
+    V3 M = n;
+    if (g.sigma != 0.0) {
+      V3 A, Bv;
+      onb(n, A, Bv);
+      uint32_t wr[4];
+      draw_block(seed, ray, 2u * j + 1u, stream, wr);
+      const double u1 = u01(wr[0]), u2 = u01(wr[1]), u3 = u01(wr[2]);
+      const double R = sqrt(-2.0 * log_pos(u1));
+      double s2, c2;
+      sincos2pi(u2, s2, c2);
+      const double delta = g.sigma * (R * c2);
+      double sd, cd, sp, cp;
+      sincos_cw(delta, sd, cd);
+      sincos2pi(u3, sp, cp);
+      V3 e;
+      e.x = fma(cp, A.x, sp * Bv.x); e.y = fma(cp, A.y, sp * Bv.y); e.z = fma(cp, A.z, sp * Bv.z);
+      M.x = fma(cd, n.x, sd * e.x); M.y = fma(cd, n.y, sd * e.y); M.z = fma(cd, n.z, sd * e.z);
+    }
+    const double d2 = -2.0 * dot3(v, M);
+    w = axpy(d2, M, v);
+  }
+  const double dn = dot3(w, n);
+  if (dn <= 0.0) w = axpy(-2.0 * dn, n, w);
+  v = w;
+  return true;
+}
+
+// ---------------------------------------------------------------- BRDF re-scatter (TVector3 op order, no fma)
+__device__ __forceinline__ V3 tv_orthogonal(const V3& a) {
+  const double xx = a.x < 0.0 ? -a.x : a.x, yy = a.y < 0.0 ? -a.y : a.y, zz = a.z < 0.0 ? -a.z : a.z;
+  V3 r;
+  if (xx < yy) {
+    if (xx < zz) { r.x = 0; r.y = a.z; r.z = -a.y; } else { r.x = a.y; r.y = -a.x; r.z = 0; }
+  } else {
+    if (yy < zz) { r.x = -a.z; r.y = 0; r.z = a.x; } else { r.x = a.y; r.y = -a.x; r.z = 0; }
+  }
+  return r;
+}
+__device__ __forceinline__ V3 tv_cross(const V3& a, const V3& p) {
+  V3 r;
+  r.x = a.y * p.z - p.y * a.z; r.y = a.z * p.x - p.z * a.x; r.z = a.x * p.y - p.x * a.y;
+  return r;
+}
+__device__ __forceinline__ V3 tv_unit(const V3& a) {
+  const double tot2 = a.x * a.x + a.y * a.y + a.z * a.z;
+  const double tot = (tot2 > 0) ? 1.0 / sqrt(tot2) : 1.0;
+  V3 r;
+  r.x = a.x * tot; r.y = a.y * tot; r.z = a.z * tot;
+  return r;
+}
+__device__ __forceinline__ V3 tv_setmag1(const V3& a) {
+  double f = sqrt(a.x * a.x + a.y * a.y + a.z * a.z);
+  if (f == 0) return a;
+  f = 1.0 / f;
+  V3 r;
+  r.x = a.x * f; r.y = a.y * f; r.z = a.z * f;
+  return r;
+}
+
+__device__ inline V3 brdf_sample(const Geom& g, const V3 normal, const V3 incident, uint64_t seed, uint64_t ray) {
+  uint32_t w[4];
+  draw_block(seed, ray, 0u, 1u, w);
+  if (u01(w[0]) < g.brdf_spec) {
+    const double a = 2 * (incident.x * normal.x + incident.y * normal.y + incident.z * normal.z);
+    V3 refl;
+    refl.x = incident.x - a * normal.x; refl.y = incident.y - a * normal.y; refl.z = incident.z - a * normal.z;
+    refl = tv_setmag1(refl);
+    const double Rg = sqrt(-2.0 * log_pos(u01(w[1])));
+    double s2, c2;
+    sincos2pi(u01(w[2]), s2, c2);
+    const double theta = g.brdf_theta_scale * (Rg * c2);
+    double st, ct, sp, cp;
+    sincos_cw(theta, st, ct);
+    sincos2pi(u01(w[3]), sp, cp);
+    const V3 p1 = tv_orthogonal(refl);
+    const V3 p2 = tv_cross(refl, p1);
+    V3 res;
+    res.x = refl.x + st * (cp * p1.x + sp * p2.x);
+    res.y = refl.y + st * (cp * p1.y + sp * p2.y);
+    res.z = refl.z + st * (cp * p1.z + sp * p2.z);
+    return tv_setmag1(res);
+  } else {
+    const double u = u01(w[1]);
+    const double ct = sqrt(u), st = sqrt(1.0 - u);
+    double sp, cp;
+    sincos2pi(u01(w[3]), sp, cp);
+    const V3 uu = tv_orthogonal(normal);
+    const V3 vv = tv_cross(normal, uu);
+    const double x = st * cp, y = st * sp, z = ct;
+    V3 res;
+    res.x = x * uu.x + y * vv.x + z * normal.x;
+    res.y = x * uu.y + y * vv.y + z * normal.y;
+    res.z = x * uu.z + y * vv.z + z * normal.z;
+    return tv_unit(res);
+  }
+}
+
+// ---------------------------------------------------------------- detector test (exact; fluxAtObserver.C:70-107)
+// det = x,y,z,nx,ny,nz exactly as Detector::setPosition stores them; plain +,-,*,/ in source order.
+__device__ __forceinline__ bool check_intersection(const double* __restrict__ det, double half_w2, const V3& lp,
+                                                   const V3& dir) {
+  const double x = det[0], y = det[1], z = det[2], nx = det[3], ny = det[4], nz = det[5];
+  const double dot = dir.x * nx + dir.y * ny + dir.z * nz;
+  if (fabs(dot) < 1e-10) return false;
+  const double dx = lp.x - x;
+  const double dy = lp.y - y;
+  const double dz = lp.z - z;
+  const double t = -(dx * nx + dy * ny + dz * nz) / dot;
+  const double ix = lp.x + dir.x * t;
+  const double iy = lp.y + dir.y * t;
+  const double iz = lp.z + dir.z * t;
+  const double rx = ix - x;
+  const double ry = iy - y;
+  const double rz = iz - z;
+  const double ux = ny * rz - nz * ry;
+  const double uy = nz * rx - nx * rz;
+  const double uz = nx * ry - ny * rx;
+  const double r2 = ux * ux + uy * uy + uz * uz;
+  return r2 <= half_w2;
+}
+
+}  // namespace isx

@@ -1,0 +1,456 @@
+// isx_kernels.hpp — gfx950 kernels: persistent-wave trace loop + wave-cooperative detector binning.
+//
+// Execution model:
+//   * one ray per lane, ray state in VGPRs; every wave owns a contiguous range of ray
+//     indices and refills dead lanes from it (no atomics on the refill path), so lanes stay
+//     busy although the bounce count per ray is geometric (mean ~57, tail >> mean);
+//   * RNG is Philox4x32-10 keyed by (seed) and counted by (ray index, draw block, stream):
+//     a ray's history does not depend on which lane/wave/GPU traces it;
+//   * when a lane's ray leaves through the port, its line (last point, final direction)
+//     is broadcast with v_readlane and ALL 64 lanes of the wave test detector positions
+//     for it (one detector per lane per step) - no divergence in the binning, and the
+//     increments of one step go to 64 different bins;
+//   * bins live in a per-block LDS histogram (u32[n_theta*n_phi] = 64.8 KB for 180x90),
+//     flushed once per block with global 64-bit atomics.
+#pragma once
+#include "isx_device.hpp"
+
+namespace isx {
+
+struct DetGrid {
+  int n_theta, n_phi, nbins, bin_mode;  // bin_mode 0: brute exact, 1: culled + classified
+  double half_w2;                       // (width/2)*(width/2)   fluxAtObserver.C:106
+  double rho_d;                         // width/2
+  double R;                             // detector distance from (0,0,portz)
+  double portz;                         // exitPortZ
+  const double* table;                  // [nbins][6]  x,y,z,nx,ny,nz (Detector::setPosition)
+  const double* rowtab;                 // [n_theta][4] sin(theta), cos(theta), z_i, A_i=R*sin
+  const double* coltab;                 // [n_phi][2]   cos(phi), sin(phi)
+  // SINK_DISC: physical discs (integratingSphereDetectorSweep.C:145-172); nbins == n_disc
+  const double* discs;                  // [n_disc][6] centre, unit axis
+  double disc_r, disc_h;
+};
+
+enum : int { SINK_FLUX = 0, SINK_DZ = 1, SINK_DISC = 2 };
+
+struct Work {
+  uint64_t seed, first, n;
+  unsigned long long* hist;   // [nbins] global accumulators (+=)
+  unsigned long long* stats;  // [8]: launched, exited, counted, absorbed, suspended, increments, wall_hits
+};
+
+constexpr int kBlock = 512;
+constexpr int kWavesPerBlock = kBlock / 64;
+
+__device__ __forceinline__ double readlane_f64(double x, int lane) {
+  const long long b = __double_as_longlong(x);
+  const int lo = __builtin_amdgcn_readlane((int)(b & 0xffffffffll), lane);
+  const int hi = __builtin_amdgcn_readlane((int)(b >> 32), lane);
+  return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+}
+
+// ------------------------------------------------------------------ cull helpers (never decide a result)
+// atan2 in f32, |error| < 2e-5 rad (checked in tests/test_cull_math.py against numpy)
+__device__ __forceinline__ float atan2_cull(float y, float x) {
+  const float ax = fabsf(x), ay = fabsf(y);
+  const float mx = fmaxf(ax, ay), mn = fminf(ax, ay);
+  const float a = mx > 0.f ? mn / mx : 0.f;
+  const float s = a * a;
+  float r = fmaf(s, fmaf(s, fmaf(s, fmaf(s, fmaf(s, -0.01172120f, 0.05265332f), -0.11643287f), 0.19354346f), -0.33262347f),
+                 0.99997726f) * a;
+  if (ay > ax) r = 1.57079637f - r;
+  if (x < 0.f) r = 3.14159274f - r;
+  if (y < 0.f) r = -r;
+  return r;
+}
+
+// Fast sign test of r2 - (w/2)^2 without the division:  r2*dot^2 = dd*dot^2 - 2*num*dot*dv + num^2.
+// Returns +1 hit, 0 miss, -1 "too close to call" (caller runs the exact reference-order test).
+__device__ __forceinline__ int classify(const DetGrid& d, const double* __restrict__ rowt, const double* __restrict__ colt,
+                                        int i, int j, const V3& P, const V3& V) {
+  const double S = rowt[4 * i + 0], Cc = rowt[4 * i + 1], z = rowt[4 * i + 2], A = rowt[4 * i + 3];
+  const double cph = colt[2 * j + 0], sph = colt[2 * j + 1];
+  const double nx = -(S * sph), ny = S * cph, nz = -Cc;
+  const double dx = P.x - A * cph, dy = P.y - A * sph, dz = P.z - z;
+  const double dot = fma(V.x, nx, fma(V.y, ny, V.z * nz));
+  const double num = fma(dx, nx, fma(dy, ny, dz * nz));
+  const double dv = fma(dx, V.x, fma(dy, V.y, dz * V.z));
+  const double dd = fma(dx, dx, fma(dy, dy, dz * dz));
+  const double dot2 = dot * dot;
+  const double t1 = dd * dot2;
+  const double t2 = (2.0 * num) * (dot * dv);
+  const double t3 = num * num;
+  const double rhs = d.half_w2 * dot2;
+  const double diff = (t1 - t2) + (t3 - rhs);
+  const double band = 1e-9 * (fabs(t1) + fabs(t2) + t3 + rhs);
+  if (fabs(dot) < 1e-4 || fabs(diff) <= band) return -1;
+  return diff < 0.0 ? 1 : 0;
+}
+
+// ------------------------------------------------------------------ binning of one exit line by a whole wave
+// P,V are wave-uniform.  Returns the number of bins incremented (wave-uniform).
+__device__ __forceinline__ uint32_t bin_brute(const DetGrid& d, uint32_t* __restrict__ hist, const V3& P, const V3& V,
+                                              int lane) {
+  uint32_t inc = 0;
+  for (int b0 = 0; b0 < d.nbins; b0 += 64) {
+    const int b = b0 + lane;
+    bool hit = false;
+    if (b < d.nbins) hit = check_intersection(d.table + 6 * (size_t)b, d.half_w2, P, V);
+    if (hit) atomicAdd(&hist[b], 1u);
+    inc += (uint32_t)__popcll(__ballot(hit));
+  }
+  return inc;
+}
+
+__device__ inline uint32_t bin_culled(const DetGrid& d, uint32_t* __restrict__ hist,
+                                            const double* __restrict__ rowt, const double* __restrict__ colt,
+                                            const V3 P, const V3 V, int lane) {
+  // ---- line vs the sphere of detector centres S(O,R), O=(0,0,portz): all wave-uniform
+  V3 w; w.x = P.x; w.y = P.y; w.z = P.z - d.portz;
+  const double wv = dot3(w, V);
+  V3 h; h.x = fma(-wv, V.x, w.x); h.y = fma(-wv, V.y, w.y); h.z = fma(-wv, V.z, w.z);
+  const double dO2 = dot3(h, h);
+  const double R2 = d.R * d.R;
+  const double dO = sqrt(dO2);
+  const double a1 = dO + d.rho_d;
+  if (!(a1 < 0.999 * d.R)) return bin_brute(d, hist, P, V, lane);
+  const double sF = sqrt(R2 - dO2);
+  const double smin = sqrt(R2 - a1 * a1);
+  const double a0 = fmax(0.0, dO - d.rho_d);
+  const double smax = sqrt(R2 - a0 * a0);
+  const double ext = fmax(sF - smin, smax - sF);
+  // every detector centre within rho_d of the line lies within chord ch of a piercing point
+  const double ch2 = fma(ext, ext, d.rho_d * d.rho_d) * (1.0 + 1e-6) + 1e-6;
+  if (!(4.0 * (R2 - dO2) > 4.04 * ch2)) return bin_brute(d, hist, P, V, lane);
+  const double ch = sqrt(ch2);
+  const float dphi = 6.28318530718f / (float)d.n_phi;
+  const float inv_dphi = 1.0f / dphi;
+  uint32_t inc = 0;
+#pragma unroll 1
+  for (int side = 0; side < 2; ++side) {
+    const double s = side == 0 ? (sF - wv) : (-sF - wv);
+    const V3 F = axpy(s, V, P);
+    if (F.z - ch > d.portz) continue;  // cap entirely above every detector row
+    const double AF2 = fma(F.x, F.x, F.y * F.y);
+    const double AF = sqrt(AF2);
+    float phiF = atan2_cull((float)F.y, (float)F.x);
+    if (phiF < 0.f) phiF += 6.28318530718f;
+    const float jf = phiF * inv_dphi - 0.5f;
+#pragma unroll 1
+    for (int i0 = 0; i0 < d.n_theta; i0 += 64) {
+      const int i = i0 + lane;
+      int jlo = 0, cnt = 0;
+      if (i < d.n_theta) {
+        const double zi = rowt[4 * i + 2], Ai = rowt[4 * i + 3];
+        const double dzi = zi - F.z;
+        const double num = fma(Ai, Ai, fma(dzi, dzi, AF2)) - ch2;
+        const double den = 2.0 * Ai * AF;
+        if (num <= -den) { jlo = 0; cnt = d.n_phi; }
+        else if (num > den) { cnt = 0; }
+        else {
+          float K = (float)(num / den) - 1e-5f;
+          K = fminf(1.f, fmaxf(-1.f, K));
+          const float dl = atan2_cull(sqrtf(fmaxf(0.f, 1.f - K * K)), K) + 1e-3f;
+          const float hw = dl * inv_dphi;
+          const int lo = (int)ceilf(jf - hw), hi = (int)floorf(jf + hw);
+          jlo = lo; cnt = hi - lo + 1;
+          if (cnt < 0) cnt = 0;
+          if (cnt >= d.n_phi) { jlo = 0; cnt = d.n_phi; }
+        }
+      }
+      const unsigned long long m = __ballot(cnt > 0);
+      if (m == 0ull) continue;
+      const int first = __builtin_ctzll(m), last = 63 - __builtin_clzll(m);
+      int gmax = cnt;
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) gmax = max(gmax, __shfl_xor(gmax, o));
+      const int gsh = gmax <= 8 ? 3 : (gmax <= 16 ? 4 : (gmax <= 32 ? 5 : 6));
+      const int G = 1 << gsh, rpi = 64 >> gsh;
+      for (int c0 = 0; c0 < gmax; c0 += 64) {
+        for (int r0 = first; r0 <= last; r0 += rpi) {
+          const int rl = r0 + (lane >> gsh);
+          const int k = (lane & (G - 1)) + c0;
+          const int jlo_r = __shfl(jlo, rl & 63), cnt_r = __shfl(cnt, rl & 63);
+          const bool act = (rl <= last) && (k < cnt_r);
+          bool hit = false;
+          int bin = 0;
+          if (act) {
+            const int ii = i0 + rl;
+            int j = jlo_r + k;
+            if (j < 0) j += d.n_phi;
+            if (j >= d.n_phi) j -= d.n_phi;
+            if (j >= d.n_phi) j -= d.n_phi;
+            bin = ii * d.n_phi + j;
+            const int c = classify(d, rowt, colt, ii, j, P, V);
+            hit = c > 0;
+            if (c < 0) hit = check_intersection(d.table + 6 * (size_t)bin, d.half_w2, P, V);
+          }
+          if (hit) atomicAdd(&hist[bin], 1u);
+          inc += (uint32_t)__popcll(__ballot(hit));
+        }
+      }
+    }
+  }
+  return inc;
+}
+
+// ------------------------------------------------------------------ per-lane ray state
+struct Ray {
+  V3 p, v;
+  V3 prev;          // start of the current segment (only kept for SINK_DISC)
+  uint64_t id;
+  uint32_t j;       // mirror interactions of the current trace
+  int npts, on;
+  int phase;        // 0 primary, 2 scattered (source_model 1)
+};
+
+__device__ __forceinline__ void ray_start(const Geom& g, Ray& r, uint64_t id) {
+  r.id = id; r.j = 0; r.npts = 1; r.on = K_NONE; r.phase = 0;
+  r.p.x = g.src[0]; r.p.y = g.src[1]; r.p.z = g.src[2];
+  r.v.x = g.dir0[0]; r.v.y = g.dir0[1]; r.v.z = g.dir0[2];
+}
+
+// One step: next boundary + interaction.  Returns 0 while running, else the end status of
+// the CURRENT trace.
+template <bool KEEP_PREV = false>
+__device__ __forceinline__ int ray_step(const Geom& g, Ray& r, uint64_t seed) {
+  V3 q;
+  const int kind = next_hit(g, r.p, r.v, r.on, q);
+  if (KEEP_PREV) r.prev = r.p;
+  r.p = q;
+  r.npts++;
+  if (kind == K_BOX) { r.on = K_BOX; return ST_EXITED; }
+  r.on = kind;
+  const bool alive = interact(g, kind, q, r.v, seed, r.id, r.j, (uint32_t)r.phase);
+  r.j++;
+  if (!alive) return ST_ABSORBED;
+  if (r.npts > g.limit) return ST_SUSPENDED;
+  return 0;
+}
+
+// nonLambertianFlux.C:253-268: restart from the primary's last point along a BRDF-sampled direction
+__device__ __forceinline__ void ray_rescatter(const Geom& g, Ray& r, uint64_t seed) {
+  V3 d0; d0.x = g.dir0[0]; d0.y = g.dir0[1]; d0.z = g.dir0[2];
+  const V3 normal = tv_unit(r.p);
+  const V3 nd = brdf_sample(g, normal, d0, seed, r.id);
+  const double mag = sqrt(nd.x * nd.x + nd.y * nd.y + nd.z * nd.z);
+  r.v.x = nd.x / mag; r.v.y = nd.y / mag; r.v.z = nd.z / mag;
+  r.on = (r.on == K_BOX) ? K_NONE : r.on;
+  r.npts = 1; r.j = 0; r.phase = 2;
+}
+
+// ------------------------------------------------------------------ physical disc test (SINK_DISC)
+// forward segment [0,tmax] of p+t*v enters the tube {|axial|<=h, radial<=r} about centre c, unit axis a.
+// Replaces AFocalSurface(TGeoTube) + isRayHittingDetector (integratingSphereDetectorSweep.C:134-172).
+__device__ __forceinline__ bool segment_hits_tube(const V3& p, const V3& v, double tmax, const double* __restrict__ ca,
+                                                  double r, double h) {
+  V3 c, a, w;
+  c.x = ca[0]; c.y = ca[1]; c.z = ca[2]; a.x = ca[3]; a.y = ca[4]; a.z = ca[5];
+  w.x = p.x - c.x; w.y = p.y - c.y; w.z = p.z - c.z;
+  const double ws = dot3(w, a), vs = dot3(v, a);
+  double t0 = 0.0, t1 = tmax;
+  if (vs != 0.0) {
+    double ta = (-h - ws) / vs, tb = (h - ws) / vs;
+    if (ta > tb) { const double tmp = ta; ta = tb; tb = tmp; }
+    if (ta > t0) t0 = ta;
+    if (tb < t1) t1 = tb;
+  } else if (fabs(ws) > h) return false;
+  if (t0 > t1) return false;
+  const double A = dot3(v, v) - vs * vs;
+  const double B = dot3(w, v) - ws * vs;
+  const double C = dot3(w, w) - ws * ws - r * r;
+  if (A <= 0.0) return C <= 0.0;
+  const double D = fma(B, B, -(A * C));
+  if (D < 0.0) return false;
+  const double sD = sqrt(D);
+  const double ra = (-B - sD) / A, rb = (-B + sD) / A;
+  if (ra > t0) t0 = ra;
+  if (rb < t1) t1 = rb;
+  return t0 <= t1;
+}
+
+__device__ __forceinline__ uint32_t bin_discs(const DetGrid& d, uint32_t* __restrict__ hist, const V3& P0, const V3& P1,
+                                              const V3& V, int lane) {
+  V3 dl; dl.x = P1.x - P0.x; dl.y = P1.y - P0.y; dl.z = P1.z - P0.z;
+  const double tmax = dot3(dl, V);
+  uint32_t inc = 0;
+  for (int b0 = 0; b0 < d.nbins; b0 += 64) {
+    const int b = b0 + lane;
+    bool hit = false;
+    if (b < d.nbins) hit = segment_hits_tube(P0, V, tmax, d.discs + 6 * (size_t)b, d.disc_r, d.disc_h);
+    if (hit) atomicAdd(&hist[b], 1u);
+    inc += (uint32_t)__popcll(__ballot(hit));
+  }
+  return inc;
+}
+
+// ------------------------------------------------------------------ persistent trace kernel, one per sink
+//   SINK_FLUX: 180x90 detector flux map (the headline path)
+//   SINK_DZ  : histogram of the exit direction's z component (distributionSphereDetectorSweep.C:54,91)
+//   SINK_DISC: physical disc sweep (integratingSphereDetectorSweep.C)
+template <int SINK>
+__device__ __forceinline__ void persistent_body(const Geom& g, const DetGrid& d, const Work& wk) {
+  extern __shared__ __align__(16) unsigned char smem[];
+  uint32_t* hist = reinterpret_cast<uint32_t*>(smem);
+  const size_t off_row = ((size_t)d.nbins * 4 + 15) & ~(size_t)15;
+  double* rowt = reinterpret_cast<double*>(smem + off_row);
+  double* colt = rowt + (SINK == SINK_FLUX ? 4 * d.n_theta : 0);
+  unsigned long long* sstat = reinterpret_cast<unsigned long long*>(colt + (SINK == SINK_FLUX ? 2 * d.n_phi : 0));
+
+  const int tid = threadIdx.x;
+  for (int b = tid; b < d.nbins; b += kBlock) hist[b] = 0u;
+  if (SINK == SINK_FLUX) {
+    for (int b = tid; b < 4 * d.n_theta; b += kBlock) rowt[b] = d.rowtab[b];
+    for (int b = tid; b < 2 * d.n_phi; b += kBlock) colt[b] = d.coltab[b];
+  }
+  if (tid < 8) sstat[tid] = 0ull;
+  __syncthreads();
+
+  const int lane = tid & 63;
+  const uint64_t wave = (uint64_t)blockIdx.x * kWavesPerBlock + (uint64_t)(tid >> 6);
+  const uint64_t nwaves = (uint64_t)gridDim.x * kWavesPerBlock;
+  // contiguous ray range of this wave: [next,end)
+  const uint64_t q = wk.n / nwaves, rem = wk.n % nwaves;
+  uint64_t next = wk.first + wave * q + (wave < rem ? wave : rem);
+  const uint64_t end = next + q + (wave < rem ? 1 : 0);
+
+  Ray r;
+  ray_start(g, r, 0);
+  r.prev = r.p;
+  bool alive = false;
+  uint32_t n_launched = 0, n_exited = 0, n_counted = 0, n_abs = 0, n_susp = 0;
+  unsigned long long n_wall = 0, n_inc = 0;
+
+  for (;;) {
+    // ---- refill dead lanes from this wave's range
+    const unsigned long long dead = __ballot(!alive);
+    if (dead) {
+      if (next < end) {
+        const uint32_t rank =
+            __builtin_amdgcn_mbcnt_hi((uint32_t)(dead >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)dead, 0u));
+        if (!alive) {
+          const uint64_t id = next + rank;
+          if (id < end) { ray_start(g, r, id); alive = true; n_launched++; }
+        }
+        next += (uint64_t)__popcll(dead);
+      }
+      if (__ballot(alive) == 0ull) break;
+    }
+    // ---- one boundary + interaction per live lane
+    bool bin_me = false;
+    if (alive) {
+      int st = ray_step<SINK == SINK_DISC>(g, r, wk.seed);
+      if (st != 0 && g.source_model == 1 && r.phase == 0) {
+        n_wall += r.j;
+        ray_rescatter(g, r, wk.seed);
+        st = 0;
+      }
+      if (st != 0) {
+        alive = false;
+        n_wall += r.j;
+        if (st == ST_EXITED) {
+          n_exited++;
+          const bool below = r.p.z < d.portz;  // isRayPassingThroughExitPort, fluxAtObserver.C:162-166
+          if (below) n_counted++;
+          bin_me = (SINK == SINK_DISC) ? true : below;
+        } else if (st == ST_ABSORBED) n_abs++;
+        else n_susp++;
+      }
+    }
+    if (SINK == SINK_DZ) {
+      // per-lane: TH1D(nbins,-1,1)->Fill(dz)
+      bool hit = false;
+      int b = 0;
+      if (bin_me) {
+        const double f = (r.v.z + 1.0) * 0.5 * (double)d.nbins;
+        b = (int)floor(f);
+        hit = b >= 0 && b < d.nbins;
+      }
+      if (hit) atomicAdd(&hist[b], 1u);
+      n_inc += (unsigned long long)__popcll(__ballot(hit));
+    } else {
+      // ---- wave-cooperative binning of every line that left in this step
+      unsigned long long em = __ballot(bin_me);
+      while (em) {
+        const int src = __builtin_ctzll(em);
+        em &= em - 1ull;
+        V3 P, V;
+        P.x = readlane_f64(r.p.x, src); P.y = readlane_f64(r.p.y, src); P.z = readlane_f64(r.p.z, src);
+        V.x = readlane_f64(r.v.x, src); V.y = readlane_f64(r.v.y, src); V.z = readlane_f64(r.v.z, src);
+        if (SINK == SINK_DISC) {
+          V3 P0;
+          P0.x = readlane_f64(r.prev.x, src); P0.y = readlane_f64(r.prev.y, src); P0.z = readlane_f64(r.prev.z, src);
+          n_inc += bin_discs(d, hist, P0, P, V, lane);
+        } else {
+          n_inc += d.bin_mode == 0 ? bin_brute(d, hist, P, V, lane) : bin_culled(d, hist, rowt, colt, P, V, lane);
+        }
+      }
+    }
+  }
+
+  // ---- census + histogram flush
+  atomicAdd(&sstat[0], (unsigned long long)n_launched);
+  atomicAdd(&sstat[1], (unsigned long long)n_exited);
+  atomicAdd(&sstat[2], (unsigned long long)n_counted);
+  atomicAdd(&sstat[3], (unsigned long long)n_abs);
+  atomicAdd(&sstat[4], (unsigned long long)n_susp);
+  atomicAdd(&sstat[6], n_wall);
+  if (lane == 0) atomicAdd(&sstat[5], n_inc);
+  __syncthreads();
+  for (int b = tid; b < d.nbins; b += kBlock) {
+    const uint32_t c = hist[b];
+    if (c) atomicAdd(&wk.hist[b], (unsigned long long)c);
+  }
+  if (tid < 7) {
+    const unsigned long long c = sstat[tid];
+    if (c) atomicAdd(&wk.stats[tid], c);
+  }
+}
+
+extern "C" __global__ void __launch_bounds__(kBlock)
+isx_trace_bin_kernel(const Geom g, const DetGrid d, const Work wk) { persistent_body<SINK_FLUX>(g, d, wk); }
+extern "C" __global__ void __launch_bounds__(kBlock)
+isx_trace_dz_kernel(const Geom g, const DetGrid d, const Work wk) { persistent_body<SINK_DZ>(g, d, wk); }
+extern "C" __global__ void __launch_bounds__(kBlock)
+isx_trace_disc_kernel(const Geom g, const DetGrid d, const Work wk) { persistent_body<SINK_DISC>(g, d, wk); }
+
+// ------------------------------------------------------------------ per-ray end states (parity tests)
+extern "C" __global__ void __launch_bounds__(256)
+isx_endstates_kernel(const Geom g, uint64_t seed, uint64_t first, uint64_t n, int32_t* __restrict__ status,
+                     int32_t* __restrict__ npts, double* __restrict__ lp, double* __restrict__ dir) {
+  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  Ray r;
+  ray_start(g, r, first + i);
+  int st;
+  for (;;) {
+    st = ray_step(g, r, seed);
+    if (st != 0 && g.source_model == 1 && r.phase == 0) { ray_rescatter(g, r, seed); st = 0; }
+    if (st != 0) break;
+  }
+  status[i] = st;
+  npts[i] = r.npts;
+  lp[3 * i] = r.p.x; lp[3 * i + 1] = r.p.y; lp[3 * i + 2] = r.p.z;
+  dir[3 * i] = r.v.x; dir[3 * i + 1] = r.v.y; dir[3 * i + 2] = r.v.z;
+}
+
+// ------------------------------------------------------------------ device-side self test of the numeric contract
+// out[k] for k in [0,n): op 0 sqrt(a), 1 a/b, 2 fma(a,b,c), 3 log_pos(a), 4/5 sincos2pi(a), 6/7 sincos_cw(a)
+extern "C" __global__ void isx_mathprobe_kernel(int op, const double* __restrict__ a, const double* __restrict__ b,
+                                                const double* __restrict__ c, double* __restrict__ out, int n) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  double s, co;
+  switch (op) {
+    case 0: out[i] = sqrt(a[i]); break;
+    case 1: out[i] = a[i] / b[i]; break;
+    case 2: out[i] = fma(a[i], b[i], c[i]); break;
+    case 3: out[i] = log_pos(a[i]); break;
+    case 4: sincos2pi(a[i], s, co); out[i] = s; break;
+    case 5: sincos2pi(a[i], s, co); out[i] = co; break;
+    case 6: sincos_cw(a[i], s, co); out[i] = s; break;
+    default: sincos_cw(a[i], s, co); out[i] = co; break;
+  }
+}
+
+}  // namespace isx

@@ -1,0 +1,206 @@
+#!/usr/bin/env python3
+"""bench.py — the reference's headline metric on MI355X: Mrays/s for the 180x90 flux map at
+src(-60,0,-75), port 170 deg (BASELINE.json: metric / configs[1]: 5e7 rays per GPU).
+
+    python bench.py --gpus 1 --steps 5 --warmup 1
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+A "step" = one pass of the hot path over one batch: every rank traces `--rays` rays (its own
+contiguous slice of the global ray-index stream of that step, so results do not depend on N),
+bins them into the 180x90 detector histogram on its GPU, and the histograms are summed with
+ONE all-reduce over RCCL (torch.distributed backend "nccl").  Weak scaling: per-GPU work is
+fixed.  Prints one JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s
+FP64_VALU_PEAK_TFLOPS = 78.6   # MI355X vector FP64 peak
+# Work model frozen in BASELINE.md §2 / DESIGN.md §5 (brute-force binning convention):
+F_BOUNCE, N_BOUNCE, P_EXIT, F_DISC = 200.0, 57.5, 0.4235, 40.0
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--rays", type=int, default=50_000_000, help="rays per GPU per step (BASELINE configs[1])")
+    ap.add_argument("--seed", type=lambda s: int(s, 0), default=0x5EED0001)
+    ap.add_argument("--cpu-rays", type=int, default=-1, help="oracle sample size for cpu_baseline (0: skip, -1: auto)")
+    ap.add_argument("--reduce", choices=["auto", "device", "host"], default="auto",
+                    help="where the histogram lives for the all-reduce")
+    return ap.parse_args()
+
+
+def cpu_baseline(seed, n_req):
+    """Oracle (CPU restatement, kind 'port') timed on this host's cores on a bounded sample."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle
+    cfg = oracle.default_config()
+    threads = oracle.lib().isxo_max_threads()
+    if n_req < 0:
+        # calibrate: ~15 s of CPU work
+        t0 = time.time()
+        oracle.fluxmap(cfg, 100_000, seed)
+        dt = max(time.time() - t0, 1e-3)
+        n_req = int(min(max(100_000 * 15.0 / dt, 200_000), 20_000_000))
+    t0 = time.time()
+    _, st = oracle.fluxmap(cfg, n_req, seed)
+    dt = time.time() - t0
+    return {"value": n_req / dt / 1e6, "unit": "Mrays/s", "cores": threads, "kind": "port",
+            "sample": f"{n_req} rays of the same workload (180x90 map, src(-60,0,-75), port 170deg), "
+                      f"oracle/libisx_oracle.so, OpenMP {threads} threads, {dt:.1f} s"}
+
+
+def main():
+    a = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != a.gpus and world > 1:
+        raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}")
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (no CPU fallback exists in the product path)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    import altair_raytracing_amd as isx
+    isx.load()
+    isx.init(local_rank)
+    devname, cus = isx.device_info()
+    cfg = isx.default_config()
+    nb = cfg.n_theta * cfg.n_phi
+    n = a.rays
+
+    hist_dev = torch.zeros(nb, dtype=torch.int64, device=dev)
+
+    def barrier():
+        if world > 1:
+            dist.barrier(device_ids=[local_rank])
+        torch.cuda.synchronize()
+
+    # --- pick the reduce path: device-resident histogram if this process's two HIP runtimes
+    # (torch's and libisx's) agree on device pointers, else bounce 130 KB through the host.
+    mode = a.reduce
+    if mode == "auto":
+        try:
+            probe = torch.zeros(nb, dtype=torch.int64, device=dev)
+            torch.cuda.synchronize()
+            isx.fluxmap_device(cfg, 4096, a.seed, 0, probe.data_ptr())
+            isx.sync()
+            isx.take_stats()
+            want, _ = isx.fluxmap(cfg, 4096, a.seed, 0)
+            torch.cuda.synchronize()
+            mode = "device" if np.array_equal(probe.cpu().numpy().astype(np.uint64), want.reshape(-1)) else "host"
+        except Exception:
+            mode = "host"
+    if world > 1:
+        flag = torch.tensor([1 if mode == "device" else 0], device=dev)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        mode = "device" if int(flag.item()) == 1 else "host"
+
+    kernel_ms, census = [], []
+
+    def step(s):
+        """trace + bin this rank's slice of step s, then all-reduce the 180x90 histogram."""
+        first = (s * world + rank) * n
+        if mode == "device":
+            hist_dev.zero_()
+            torch.cuda.synchronize()
+            isx.fluxmap_device(cfg, n, a.seed, first, hist_dev.data_ptr())
+            isx.sync()
+            st = isx.take_stats()
+        else:
+            h, st = isx.fluxmap(cfg, n, a.seed, first)
+            hist_dev.copy_(torch.from_numpy(h.reshape(-1).astype(np.int64)))
+        if world > 1:
+            dist.all_reduce(hist_dev, op=dist.ReduceOp.SUM)
+        kernel_ms.append(st.t_kernel_ms)
+        census.append(st)
+
+    for s in range(a.warmup):
+        step(s)
+    kernel_ms.clear()
+    census.clear()
+
+    barrier()
+    t0 = time.perf_counter()
+    for s in range(a.warmup, a.warmup + a.steps):
+        step(s)
+    barrier()
+    dt = time.perf_counter() - t0
+    t = torch.tensor([dt], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    dt = float(t.item())
+
+    total_hits = int(hist_dev.sum().item())
+    if rank == 0:
+        rays_total = n * world * a.steps
+        value = rays_total / dt / 1e6
+        k_ms = float(np.mean(kernel_ms)) if kernel_ms else float("nan")
+        # --- roofline of the dominant kernel (isx_trace_bin_kernel), per launch
+        alg_bytes = nb * 8.0                       # the only mandatory HBM traffic: one 180x90 u64 histogram
+        hbm_gbs = alg_bytes / (k_ms * 1e-3) / 1e9
+        f_ray = N_BOUNCE * F_BOUNCE + P_EXIT * nb * F_DISC
+        fp64_tflops = n * f_ray / (k_ms * 1e-3) / 1e12
+        traffic = None
+        pmc = os.path.join(ROOT, "profiles", "pmc_summary.json")
+        if os.path.exists(pmc):
+            try:
+                traffic = json.load(open(pmc)).get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        st = census[-1]
+        out = {
+            "metric": "Mrays/sec whole-node, 180x90 fluxmap src(-60,0,-75); achieved HBM GB/s vs peak",
+            "value": value, "unit": "Mrays/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": f"{n} rays/GPU/step, pencil source src(-60,0,-75) dir(5,0,0) -> Lambertian wall "
+                                   f"(rho .99, port 170deg), 180x90 detector map, 40 cm disc at 100 cm "
+                                   f"(BASELINE configs[1])",
+                       "rays_per_gpu_per_step": n, "grid": [cfg.n_theta, cfg.n_phi], "seed": hex(a.seed),
+                       "parallelism": f"rays sharded over {world} GPU(s), one RCCL all-reduce of the histogram",
+                       "reduce_path": mode, "device": devname},
+            "roofline": {"bound": "hbm", "achieved": hbm_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": hbm_gbs / HBM_PEAK_GBS, "traffic": traffic,
+                         "kernel": "isx_trace_bin_kernel", "kernel_ms": k_ms, "algorithmic_bytes_per_launch": alg_bytes,
+                         "note": "the path reads nothing and writes one 129.6 KB histogram per launch: HBM is not "
+                                 "the binding resource (SURVEY.md §8d); see roofline_fp64"},
+            "roofline_fp64": {"bound": "valu_fp64", "achieved": fp64_tflops, "peak": FP64_VALU_PEAK_TFLOPS,
+                              "unit": "TFLOP/s", "frac": fp64_tflops / FP64_VALU_PEAK_TFLOPS,
+                              "flop_per_ray_model": f_ray,
+                              "note": "algorithmic FP64 flop of the reference algorithm (brute-force 16200 disc "
+                                      "tests per exiting ray, BASELINE.md §2); the kernel culls, so executed flop "
+                                      "are far fewer and frac may exceed what executed-op counters show"},
+            "census_last_step": {"launched": st.launched, "counted_below_z": st.counted_below_z,
+                                 "wall_hits": st.wall_hits, "bin_increments": st.bin_increments},
+            "hist_sum_last_step": total_hits,
+        }
+        if world == 1 and a.cpu_rays != 0:
+            out["cpu_baseline"] = cpu_baseline(a.seed, a.cpu_rays)
+        print(json.dumps(out))
+    isx.shutdown()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

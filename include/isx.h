@@ -127,6 +127,15 @@ int isx_take_stats(isx_stats* stats);
 /* The hipStream_t the library launches on (so callers can order work after it). */
 void* isx_stream(void);
 
+/* Tuning/diagnostic switches.  "bin_mode": 1 (default) culled + classified binning,
+ * 0 brute-force reference-order test of every detector position; "blocks_per_cu";
+ * "grid_blocks" (0 = auto).  None of them changes any result. */
+int isx_set_option(const char* key, int64_t value);
+
+/* Device-side probe of the numeric contract (tests): out[i] = op(a[i],b[i],c[i]) with
+ * op 0 sqrt, 1 a/b, 2 fma, 3 log, 4/5 sin/cos(2*pi*a), 6/7 sin/cos(a). */
+int isx_mathprobe(int op, const double* a, const double* b, const double* c, double* out, int32_t n);
+
 /*
  * Per-ray end states, for parity tests against the oracle: status (isx_ray_status),
  * last point, final direction, number of track points.  Host buffers sized n_rays.
@@ -144,6 +153,14 @@ int isx_trace_endstates(const isx_config* cfg, uint64_t n_rays, uint64_t seed, u
 int isx_disc_sweep(const isx_config* cfg, const double* centers_axes /*[n_disc][6]*/, int32_t n_disc,
                    double radius, double half_thick, uint64_t n_rays, uint64_t seed, uint64_t first_ray,
                    uint64_t* hits, isx_stats* stats);
+
+/*
+ * Exit-direction by-product (distributionSphereDetectorSweep.C:54,91): histogram of the z
+ * component of the final direction of every ray counted below exit_port_z,
+ * TH1D(nbins,-1,1) binning.  hist: host buffer [nbins], zeroed by the callee.
+ */
+int isx_exit_dz_hist(const isx_config* cfg, uint64_t n_rays, uint64_t seed, uint64_t first_ray, int32_t nbins,
+                     uint64_t* hist, isx_stats* stats);
 
 /* Host-side detector table exactly as Detector::setPosition builds it
  * (fluxAtObserver.C:49-68): out[(i*n_phi+j)*6] = x,y,z,nx,ny,nz.  No GPU needed. */

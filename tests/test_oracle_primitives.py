@@ -1,0 +1,98 @@
+"""Oracle primitives: RNG known answers, elementary functions vs libm, detector arithmetic.
+(CPU only; pins the oracle before anything is compared with it.)"""
+import ctypes as C
+import math
+
+import numpy as np
+
+
+# Random123 kat_vectors for philox4x32 with 10 rounds
+PHILOX_KAT = [
+    ([0, 0, 0, 0], [0, 0], [0x6627E8D5, 0xE169C58D, 0xBC57AC4C, 0x9B00DBD8]),
+    ([0xFFFFFFFF] * 4, [0xFFFFFFFF] * 2, [0x408F276D, 0x41C83B0E, 0xA20BC7C6, 0x6D5451FD]),
+    ([0x243F6A88, 0x85A308D3, 0x13198A2E, 0x03707344], [0xA4093822, 0x299F31D0],
+     [0xD16CFE09, 0x94FDCCEB, 0x5001E420, 0x24126EA1]),
+]
+
+
+def test_philox_known_answers(orc):
+    for ctr, key, want in PHILOX_KAT:
+        assert orc.philox(ctr, key) == want
+
+
+def test_u01_open_interval(orc):
+    L = orc.lib()
+    assert L.isxo_u01(0) == 2.0 ** -33
+    assert L.isxo_u01(0xFFFFFFFF) == 1.0 - 2.0 ** -33
+    assert L.isxo_u01(0x80000000) == 0.5 + 2.0 ** -33
+
+
+def test_log_accuracy(orc):
+    L = orc.lib()
+    rng = np.random.default_rng(11)
+    xs = np.concatenate([rng.random(20000), 2.0 ** -rng.integers(1, 33, 2000) * (1 + rng.random(2000)) / 2])
+    worst = 0.0
+    for x in xs:
+        if x <= 0:
+            continue
+        ref = math.log(x)
+        if ref != 0:
+            worst = max(worst, abs(L.isxo_log(float(x)) - ref) / abs(ref))
+    assert worst < 4.5e-16
+
+
+def test_sincos2pi_accuracy(orc):
+    rng = np.random.default_rng(12)
+    worst = 0.0
+    for u in np.concatenate([rng.random(20000), [0.0, 0.125, 0.25, 0.375, 0.5, 0.625, 0.75, 0.875, 1 - 2.0 ** -33]]):
+        s, c = orc.sincos2pi(float(u))
+        worst = max(worst, abs(s - math.sin(2 * math.pi * u)), abs(c - math.cos(2 * math.pi * u)))
+        assert abs(s * s + c * c - 1) < 5e-16
+    assert worst < 1.5e-15  # includes the rounding of 2*pi*u in the libm argument
+
+
+def test_sincos_accuracy(orc):
+    rng = np.random.default_rng(13)
+    worst = 0.0
+    for x in np.concatenate([(rng.random(20000) - 0.5) * 40, [0.0, 1e-9, -1e-9, math.pi / 4, -math.pi / 2]]):
+        s, c = orc.sincos(float(x))
+        worst = max(worst, abs(s - math.sin(x)), abs(c - math.cos(x)))
+    assert worst < 4e-16
+
+
+def test_detector_table_matches_formula(orc):
+    """Detector::setPosition (fluxAtObserver.C:49-68) evaluated independently with numpy/libm."""
+    cfg = orc.default_config()
+    tab = orc.detector_table(cfg).reshape(180, 90, 6)
+    for i, j in [(0, 0), (17, 3), (90, 45), (179, 89), (120, 7)]:
+        theta = (i + 0.5) * 90.0 / 180
+        phi = (j + 0.5) * 360.0 / 90
+        tr, pr = theta * math.pi / 180.0, phi * math.pi / 180.0
+        x = 100.0 * math.sin(tr) * math.cos(pr)
+        y = 100.0 * math.sin(tr) * math.sin(pr)
+        z = -100.0 - 100.0 * math.cos(tr)
+        mag = math.sqrt(x * x + y * y + (z + 100.0) * (z + 100.0))
+        want = [x, y, z, -y / mag, x / mag, (z + 100.0) / mag]
+        assert list(tab[i, j]) == want
+    # the quirk the reference has: the normal is the radial direction rotated 90 deg about z
+    n = tab[..., 3:6]
+    d = tab[..., 0:3] - np.array([0, 0, -100.0])
+    assert np.allclose(np.einsum("ijk,ijk->ij", n, d) / 100.0, np.cos(np.deg2rad((np.arange(180) + .5) * .5))[:, None] ** 2,
+                       atol=1e-12)
+
+
+def test_check_intersection_geometry(orc):
+    """Hit iff the infinite line meets the detector plane within width/2 of the centre (fluxAtObserver.C:70-107)."""
+    L = orc.lib()
+    det = (C.c_double * 6)(0.0, 0.0, -200.0, 0.0, 0.0, -1.0)
+
+    def hit(p, d, w=40.0):
+        return L.isxo_check_intersection(det, w, (C.c_double * 3)(*p), (C.c_double * 3)(*d))
+
+    assert hit((0, 0, -300), (0, 0, -1)) == 1          # behind the plane: still a hit (no t>0 test)
+    assert hit((19.9, 0, -300), (0, 0, -1)) == 1
+    assert hit((20.0, 0, -300), (0, 0, -1)) == 1       # boundary: r2 <= (w/2)^2
+    assert hit((20.0000001, 0, -300), (0, 0, -1)) == 0
+    assert hit((0, 0, -300), (1, 0, 0)) == 0            # parallel: |dot| < 1e-10
+    assert hit((0, 0, -300), (1, 0, 1e-11)) == 0
+    assert hit((5, 5, -150), (0.1, -0.2, -0.97), 10.0) == 0
