@@ -90,9 +90,13 @@ int prepare_geom(const isx_config* c, Geom* g) {
 void det_set_position(double theta, double phi, double radius, double portz, double* d) {
   const double theta_rad = theta * M_PI / 180.0;
   const double phi_rad = phi * M_PI / 180.0;
-  const double x = radius * std::sin(theta_rad) * std::cos(phi_rad);
-  const double y = radius * std::sin(theta_rad) * std::sin(phi_rad);
-  const double z = portz - radius * std::cos(theta_rad);
+  // the reference is built by g++ -O2 (ACLiC), which turns sin(a),cos(a) into ONE sincos(a)
+  double st, ct, sp, cp;
+  ::sincos(theta_rad, &st, &ct);
+  ::sincos(phi_rad, &sp, &cp);
+  const double x = radius * st * cp;
+  const double y = radius * st * sp;
+  const double z = portz - radius * ct;
   const double dx = x - 0;
   const double dy = y - 0;
   const double dz = z - (portz);
@@ -117,10 +121,12 @@ void host_tables(const isx_config* c, std::vector<double>& table, std::vector<do
   for (int i = 0; i < nt; ++i) {
     const double theta = (i + 0.5) * 90.0 / nt;
     const double theta_rad = theta * M_PI / 180.0;
-    rowtab[4 * i + 0] = std::sin(theta_rad);
-    rowtab[4 * i + 1] = std::cos(theta_rad);
-    rowtab[4 * i + 2] = c->exit_port_z - c->det_distance * std::cos(theta_rad);
-    rowtab[4 * i + 3] = c->det_distance * std::sin(theta_rad);
+    double st, ct;
+    ::sincos(theta_rad, &st, &ct);
+    rowtab[4 * i + 0] = st;
+    rowtab[4 * i + 1] = ct;
+    rowtab[4 * i + 2] = c->exit_port_z - c->det_distance * ct;
+    rowtab[4 * i + 3] = c->det_distance * st;
     for (int j = 0; j < np; ++j) {
       const double phi = (j + 0.5) * 360.0 / np;
       det_set_position(theta, phi, c->det_distance, c->exit_port_z, &table[6 * ((size_t)i * np + j)]);
@@ -129,8 +135,7 @@ void host_tables(const isx_config* c, std::vector<double>& table, std::vector<do
   for (int j = 0; j < np; ++j) {
     const double phi = (j + 0.5) * 360.0 / np;
     const double phi_rad = phi * M_PI / 180.0;
-    coltab[2 * j + 0] = std::cos(phi_rad);
-    coltab[2 * j + 1] = std::sin(phi_rad);
+    ::sincos(phi_rad, &coltab[2 * j + 1], &coltab[2 * j + 0]);
   }
 }
 

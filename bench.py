@@ -45,15 +45,20 @@ def cpu_baseline(seed, n_req):
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle
     cfg = oracle.default_config()
-    threads = oracle.lib().isxo_max_threads()
+    # the GPU box gives one GPU's job a 16-core share of the host: never spawn more workers than that
+    try:
+        avail = len(os.sched_getaffinity(0))
+    except AttributeError:
+        avail = os.cpu_count() or 1
+    threads = max(1, min(avail, oracle.lib().isxo_max_threads(), int(os.environ.get("ISX_CPU_THREADS", "16"))))
     if n_req < 0:
         # calibrate: ~15 s of CPU work
         t0 = time.time()
-        oracle.fluxmap(cfg, 100_000, seed)
+        oracle.fluxmap(cfg, 100_000, seed, 0, threads)
         dt = max(time.time() - t0, 1e-3)
         n_req = int(min(max(100_000 * 15.0 / dt, 200_000), 20_000_000))
     t0 = time.time()
-    _, st = oracle.fluxmap(cfg, n_req, seed)
+    _, st = oracle.fluxmap(cfg, n_req, seed, 0, threads)
     dt = time.time() - t0
     return {"value": n_req / dt / 1e6, "unit": "Mrays/s", "cores": threads, "kind": "port",
             "sample": f"{n_req} rays of the same workload (180x90 map, src(-60,0,-75), port 170deg), "

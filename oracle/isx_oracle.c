@@ -474,9 +474,14 @@ static void trace_ray(const isxo_config* c, const geom* g, uint64_t seed, uint64
 static void det_set_position(double theta, double phi, double radius, double portz, double d[6]) {
   double theta_rad = theta * M_PI / 180.0;
   double phi_rad = phi * M_PI / 180.0;
-  double x = radius * sin(theta_rad) * cos(phi_rad);
-  double y = radius * sin(theta_rad) * sin(phi_rad);
-  double z = portz - radius * cos(theta_rad);
+  /* g++ -O2 (ACLiC) merges sin(a),cos(a) into one sincos(a) call; glibc's sincos differs from
+   * separate sin/cos by 1 ulp for a few arguments, so the call is made explicit here. */
+  double st, ct, sp, cp;
+  sincos(theta_rad, &st, &ct);
+  sincos(phi_rad, &sp, &cp);
+  double x = radius * st * cp;
+  double y = radius * st * sp;
+  double z = portz - radius * ct;
   double dx = x - 0;
   double dy = y - 0;
   double dz = z - (portz);

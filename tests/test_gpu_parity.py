@@ -210,8 +210,10 @@ def test_full_size_properties(isx, golden):
     frac = h / n
     assert abs(frac.sum() / m["sum_fraction"] - 1) < 0.015
     prof, gold = frac.mean(axis=1), np.array(m["theta_profile"])
-    rel = np.abs(prof[:150] / gold[:150] - 1)
-    assert rel.max() < 0.04, rel.max()
+    # the golden rows are phi-means of 90 independent 50 000-ray binomial estimates
+    sigma = np.sqrt(np.maximum(gold, 1e-7) / (m["rays_per_position"] * m["n_phi"]))
+    z = np.abs(prof - gold) / (sigma + 0.01 * gold)
+    assert z.max() < 5.0, (z.max(), int(z.argmax()))
 
 
 def test_disc_sweep_bit_exact(isx, orc):
