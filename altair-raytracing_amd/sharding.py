@@ -1,0 +1,50 @@
+"""Ray sharding across ranks (one process per GPU) + the single histogram all-reduce.
+
+Rays are independent and ray i always draws from Philox stream (seed, i), so ANY partition of
+the index range gives the same summed histogram.  Rank r of P traces the
+contiguous range shard(n, r, P); the only exchange is one SUM all-reduce of the
+[n_theta*n_phi] int64 histogram (+ the 7-word census) — torch.distributed backend "nccl"
+(= RCCL over xGMI) on GPUs, "gloo" in the CPU tests.
+
+The tracer itself is injected (`trace(cfg, count, seed, first) -> (hits, stats)`): on a GPU
+box that is altair_raytracing_amd.fluxmap; there is no CPU tracer in this package.
+"""
+from typing import Callable, Tuple
+
+import numpy as np
+
+
+def shard(n_total: int, rank: int, world: int) -> Tuple[int, int]:
+    """Contiguous split of [0,n_total): returns (first, count); the first n_total%world ranks get one extra ray."""
+    if world < 1 or not (0 <= rank < world) or n_total < 0:
+        raise ValueError("bad shard request")
+    q, r = divmod(n_total, world)
+    first = rank * q + min(rank, r)
+    return first, q + (1 if rank < r else 0)
+
+
+CENSUS_FIELDS = ("launched", "exited", "counted_below_z", "absorbed", "suspended", "bin_increments", "wall_hits")
+
+
+def fluxmap_sharded(trace: Callable, cfg, n_total: int, seed: int, first_ray: int = 0, device=None):
+    """Trace this rank's shard with `trace`, then all-reduce histogram and census over the default
+    process group (if initialised).  Returns (hits[n_theta,n_phi] uint64, census dict) — identical on every rank."""
+    import torch
+    import torch.distributed as dist
+
+    if dist.is_available() and dist.is_initialized():
+        rank, world = dist.get_rank(), dist.get_world_size()
+    else:
+        rank, world = 0, 1
+    first, count = shard(n_total, rank, world)
+    hits, st = trace(cfg, count, seed, first_ray + first)
+    census = np.array([getattr(st, k) for k in CENSUS_FIELDS], dtype=np.int64)
+    if world > 1:
+        buf = torch.from_numpy(np.concatenate([hits.reshape(-1).astype(np.int64), census]))
+        if device is not None:
+            buf = buf.to(device)
+        dist.all_reduce(buf, op=dist.ReduceOp.SUM)
+        buf = buf.cpu().numpy()
+        hits = buf[:-len(CENSUS_FIELDS)].astype(np.uint64).reshape(hits.shape)
+        census = buf[-len(CENSUS_FIELDS):]
+    return hits, dict(zip(CENSUS_FIELDS, (int(x) for x in census)))

@@ -1,0 +1,67 @@
+"""N>1 path on CPU: 2 and 3 gloo ranks shard the ray range, each traces its shard, ONE all-reduce
+sums histogram + census; the result must equal the single-rank run bit for bit.
+
+The tracer is injected into altair_raytracing_amd.sharding.fluxmap_sharded; here (no GPU) the
+test injects the ORACLE as the tracer — test infrastructure standing in for libisx, exactly the
+role bench.py gives libisx on a GPU box."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+N, SEED = 6000, 77
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ["OMP_NUM_THREADS"] = "2"
+    import torch.distributed as dist
+    import oracle
+    import altair_raytracing_amd as isx
+
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    cfg = oracle.default_config()
+    cfg.n_theta, cfg.n_phi = 60, 30
+
+    def trace(c, count, seed, first):
+        return oracle.fluxmap(c, count, seed, first, 2)
+
+    hits, census = isx.fluxmap_sharded(trace, cfg, N, SEED, first_ray=1000)
+    q.put((rank, hits, census))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_sharded_allreduce_equals_single_rank(world, orc):
+    import torch.multiprocessing as mp
+
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = [q.get(timeout=240) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    cfg = orc.default_config()
+    cfg.n_theta, cfg.n_phi = 60, 30
+    want, st = orc.fluxmap(cfg, N, SEED, 1000)
+    for rank, hits, census in got:
+        assert np.array_equal(hits, want), rank
+        assert census["launched"] == N and census["counted_below_z"] == st.counted_below_z
+        assert census["bin_increments"] == int(want.sum()) and census["wall_hits"] == st.wall_hits
