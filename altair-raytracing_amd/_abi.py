@@ -30,7 +30,7 @@ EXPORTS = [
     "isx_default_config", "isx_init", "isx_shutdown", "isx_strerror", "isx_last_hip_error", "isx_abi_version",
     "isx_device_info", "isx_fluxmap", "isx_fluxmap_device", "isx_sync", "isx_take_stats", "isx_stream",
     "isx_set_option", "isx_mathprobe", "isx_trace_endstates", "isx_disc_sweep", "isx_detector_table",
-    "isx_exit_dz_hist",
+    "isx_exit_dz_hist", "isx_fluxmap_per_position", "isx_trace_rays_detector",
 ]
 
 
@@ -104,6 +104,8 @@ def load():
     L.isx_disc_sweep.argtypes = [P(Config), P(dbl), i32, dbl, dbl, u64, u64, u64, P(u64), P(Stats)]
     L.isx_detector_table.argtypes = [P(Config), P(dbl)]
     L.isx_exit_dz_hist.argtypes = [P(Config), u64, u64, u64, i32, P(u64), P(Stats)]
+    L.isx_fluxmap_per_position.argtypes = [P(Config), u64, i32, u64, u64, u64, u64, P(u64), P(Stats)]
+    L.isx_trace_rays_detector.argtypes = [P(Config), P(dbl), dbl, u64, u64, u64, P(u64), P(Stats)]
     _lib = L
     return L
 
@@ -194,6 +196,27 @@ def exit_dz_hist(cfg, n_rays, seed, nbins=100, first_ray=0):
     _chk(load().isx_exit_dz_hist(C.byref(cfg), int(n_rays), int(seed), int(first_ray), int(nbins),
                                  _p(hist, C.c_uint64), C.byref(st)), "isx_exit_dz_hist")
     return hist, st
+
+
+def fluxmap_per_position(cfg, rays_per_position, seed, fold=1, first_group=0, n_groups=None, first_ray=0):
+    nb = cfg.n_theta * cfg.n_phi
+    if n_groups is None:
+        n_groups = nb // fold - first_group
+    hits = np.zeros(nb, dtype=np.uint64)
+    st = Stats()
+    _chk(load().isx_fluxmap_per_position(C.byref(cfg), int(rays_per_position), int(fold), int(first_group), int(n_groups),
+                                         int(seed), int(first_ray), _p(hits, C.c_uint64), C.byref(st)),
+         "isx_fluxmap_per_position")
+    return hits.reshape(cfg.n_theta, cfg.n_phi), st
+
+
+def trace_rays_detector(cfg, detector, width, n_rays, seed, first_ray=0):
+    det = np.ascontiguousarray(detector, dtype=np.float64).reshape(6)
+    h = C.c_uint64(0)
+    st = Stats()
+    _chk(load().isx_trace_rays_detector(C.byref(cfg), _p(det, C.c_double), float(width), int(n_rays), int(seed),
+                                        int(first_ray), C.byref(h), C.byref(st)), "isx_trace_rays_detector")
+    return int(h.value), st
 
 
 def detector_table(cfg):

@@ -192,8 +192,10 @@ int pick_grid(uint64_t n) {
 }
 
 // enqueue one persistent kernel accumulating into d_hist (device) and S.d_stats
+struct PerPos { uint64_t map_first = 0, rays_per_group = 0; int fold = 1; const double* d_table = nullptr; double width = 0; };
+
 int enqueue(int sink, const isx_config* c, uint64_t n, uint64_t seed, uint64_t first, unsigned long long* d_hist,
-            int nbins_override, const double* d_discs, double disc_r, double disc_h) {
+            int nbins_override, const double* d_discs, double disc_r, double disc_h, const PerPos* pp = nullptr) {
   Geom g;
   int rc = prepare_geom(c, &g);
   if (rc) return rc;
@@ -213,6 +215,25 @@ int enqueue(int sink, const isx_config* c, uint64_t n, uint64_t seed, uint64_t f
     d.R = c->det_distance;
     d.table = S.d_table; d.rowtab = S.d_rowtab; d.coltab = S.d_coltab;
     lds = (((size_t)d.nbins * 4 + 15) & ~(size_t)15) + (size_t)(4 * d.n_theta + 2 * d.n_phi) * 8 + 64;
+  } else if (sink == SINK_PERPOS) {
+    if (!pp || pp->rays_per_group < 1 || (pp->fold != 1 && pp->fold != 2)) return ISX_ERR_BAD_ARG;
+    if (pp->d_table) {  // caller-supplied detector list (traceRays with one Detector)
+      if (nbins_override < 1 || nbins_override > 36000 || pp->fold != 1) return ISX_ERR_BAD_ARG;
+      d.n_theta = nbins_override; d.n_phi = 1; d.nbins = nbins_override;
+      d.table = pp->d_table;
+      d.half_w2 = (pp->width / 2) * (pp->width / 2);
+    } else {
+      rc = check_grid(c);
+      if (rc) return rc;
+      if (pp->fold == 2 && (c->n_phi % 2) != 0) return ISX_ERR_BAD_CONFIG;
+      rc = ensure_tables(c);
+      if (rc) return rc;
+      d.n_theta = c->n_theta; d.n_phi = c->n_phi; d.nbins = c->n_theta * c->n_phi;
+      d.table = S.d_table;
+      d.half_w2 = (c->det_diameter / 2) * (c->det_diameter / 2);
+    }
+    d.map_first = pp->map_first; d.rays_per_group = pp->rays_per_group; d.fold = pp->fold;
+    lds = (((size_t)d.nbins * 4 + 15) & ~(size_t)15) + 64;
   } else {
     if (nbins_override < 1 || nbins_override > 36000) return ISX_ERR_BAD_ARG;
     d.nbins = nbins_override;
@@ -227,12 +248,14 @@ int enqueue(int sink, const isx_config* c, uint64_t n, uint64_t seed, uint64_t f
   rc = get_event(&e0); if (rc) return rc;
   rc = get_event(&e1); if (rc) return rc;
   const void* fn = sink == SINK_FLUX ? (const void*)isx_trace_bin_kernel
-                   : sink == SINK_DZ ? (const void*)isx_trace_dz_kernel : (const void*)isx_trace_disc_kernel;
+                   : sink == SINK_DZ ? (const void*)isx_trace_dz_kernel
+                   : sink == SINK_DISC ? (const void*)isx_trace_disc_kernel : (const void*)isx_trace_perpos_kernel;
   HIPCHK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   HIPCHK(hipEventRecord(e0, S.stream));
   if (sink == SINK_FLUX) hipLaunchKernelGGL(isx_trace_bin_kernel, dim3(grid), dim3(kBlock), lds, S.stream, g, d, wk);
   else if (sink == SINK_DZ) hipLaunchKernelGGL(isx_trace_dz_kernel, dim3(grid), dim3(kBlock), lds, S.stream, g, d, wk);
-  else hipLaunchKernelGGL(isx_trace_disc_kernel, dim3(grid), dim3(kBlock), lds, S.stream, g, d, wk);
+  else if (sink == SINK_DISC) hipLaunchKernelGGL(isx_trace_disc_kernel, dim3(grid), dim3(kBlock), lds, S.stream, g, d, wk);
+  else hipLaunchKernelGGL(isx_trace_perpos_kernel, dim3(grid), dim3(kBlock), lds, S.stream, g, d, wk);
   HIPCHK(hipGetLastError());
   HIPCHK(hipEventRecord(e1, S.stream));
   S.launched_pending += n;
@@ -485,6 +508,58 @@ int isx_disc_sweep(const isx_config* cfg, const double* centers_axes, int32_t n_
   }
   const int rc2 = collect_stats(stats);
   (void)hipFree(d_discs);
+  return rc ? rc : rc2;
+}
+
+int isx_fluxmap_per_position(const isx_config* cfg, uint64_t rays_per_position, int32_t fold, uint64_t first_group,
+                             uint64_t n_groups, uint64_t seed, uint64_t first_ray, uint64_t* hits, isx_stats* stats) {
+  if (!S.init) return ISX_ERR_NOT_INIT;
+  if (!cfg || !hits || rays_per_position < 1) return ISX_ERR_BAD_ARG;
+  int rc = check_grid(cfg);
+  if (rc) return rc;
+  if (fold != 1 && fold != 2) return ISX_ERR_BAD_ARG;
+  const size_t nb = (size_t)cfg->n_theta * cfg->n_phi;
+  const uint64_t groups_total = nb / (uint64_t)fold;
+  if (first_group > groups_total || n_groups > groups_total - first_group) return ISX_ERR_BAD_ARG;
+  if (n_groups > ISX_MAX_RAYS_PER_CALL / rays_per_position) return ISX_ERR_TOO_LARGE;
+  rc = ensure_hist(nb);
+  if (rc) return rc;
+  rc = collect_stats(nullptr);
+  if (rc) return rc;
+  HIPCHK(hipMemsetAsync(S.d_hist, 0, nb * sizeof(unsigned long long), S.stream));
+  PerPos pp;
+  pp.map_first = first_ray; pp.rays_per_group = rays_per_position; pp.fold = fold;
+  rc = enqueue(SINK_PERPOS, cfg, n_groups * rays_per_position, seed, first_ray + first_group * rays_per_position,
+               S.d_hist, 0, nullptr, 0, 0, &pp);
+  if (rc) return rc;
+  HIPCHK(hipMemcpyAsync(hits, S.d_hist, nb * sizeof(unsigned long long), hipMemcpyDeviceToHost, S.stream));
+  return collect_stats(stats);
+}
+
+int isx_trace_rays_detector(const isx_config* cfg, const double* detector, double width, uint64_t n_rays, uint64_t seed,
+                            uint64_t first_ray, uint64_t* hit_count, isx_stats* stats) {
+  if (!S.init) return ISX_ERR_NOT_INIT;
+  if (!cfg || !detector || !hit_count || !(width > 0)) return ISX_ERR_BAD_ARG;
+  int rc = ensure_hist(1);
+  if (rc) return rc;
+  rc = collect_stats(nullptr);
+  if (rc) return rc;
+  double* d_det = nullptr;
+  HIPCHK(hipMalloc(&d_det, 6 * sizeof(double)));
+  hipError_t e = hipMemcpy(d_det, detector, 6 * sizeof(double), hipMemcpyHostToDevice);
+  if (e == hipSuccess) e = hipMemsetAsync(S.d_hist, 0, sizeof(unsigned long long), S.stream);
+  if (e != hipSuccess) { (void)hipFree(d_det); S.last_hip = (int)e; return ISX_ERR_HIP; }
+  PerPos pp;
+  pp.map_first = first_ray; pp.rays_per_group = n_rays > 0 ? n_rays : 1; pp.fold = 1; pp.d_table = d_det; pp.width = width;
+  rc = enqueue(SINK_PERPOS, cfg, n_rays, seed, first_ray, S.d_hist, 1, nullptr, 0, 0, &pp);
+  unsigned long long h = 0;
+  if (rc == ISX_OK) {
+    e = hipMemcpyAsync(&h, S.d_hist, sizeof(h), hipMemcpyDeviceToHost, S.stream);
+    if (e != hipSuccess) { S.last_hip = (int)e; rc = ISX_ERR_HIP; }
+  }
+  const int rc2 = collect_stats(stats);
+  (void)hipFree(d_det);
+  *hit_count = h;
   return rc ? rc : rc2;
 }
 

@@ -29,9 +29,15 @@ struct DetGrid {
   // SINK_DISC: physical discs (integratingSphereDetectorSweep.C:145-172); nbins == n_disc
   const double* discs;                  // [n_disc][6] centre, unit axis
   double disc_r, disc_h;
+  // SINK_PERPOS: the reference's per-position maps (fluxAtObserverOptimize.C:542-579): rays
+  // [map_first + g*rays_per_group, +rays_per_group) belong to detector group g and are tested
+  // against that group's detector(s) only.  fold 1: group g = bin g.  fold 2 ("twofold",
+  // fluxAtObserverFast.C:336-408): group g -> bins (i,j) and (i,j+n_phi/2), i=g/(n_phi/2).
+  uint64_t map_first, rays_per_group;
+  int fold, pad1;
 };
 
-enum : int { SINK_FLUX = 0, SINK_DZ = 1, SINK_DISC = 2 };
+enum : int { SINK_FLUX = 0, SINK_DZ = 1, SINK_DISC = 2, SINK_PERPOS = 3 };
 
 struct Work {
   uint64_t seed, first, n;
@@ -357,7 +363,30 @@ __device__ __forceinline__ void persistent_body(const Geom& g, const DetGrid& d,
         else n_susp++;
       }
     }
-    if (SINK == SINK_DZ) {
+    if (SINK == SINK_PERPOS) {
+      // per-lane: the ray's own detector group only (one or two exact tests)
+      bool hit0 = false, hit1 = false;
+      int b0 = 0, b1 = 0;
+      if (bin_me) {
+        const uint64_t rel = r.id - d.map_first;
+        uint64_t grp = (uint64_t)((double)rel / (double)d.rays_per_group);
+        if (grp * d.rays_per_group > rel) grp--;
+        else if ((grp + 1) * d.rays_per_group <= rel) grp++;
+        if (d.fold == 2) {
+          const int half = d.n_phi / 2;
+          const int i = (int)(grp / (uint64_t)half), j = (int)(grp % (uint64_t)half);
+          b0 = i * d.n_phi + j;
+          b1 = b0 + half;
+          hit1 = check_intersection(d.table + 6 * (size_t)b1, d.half_w2, r.p, r.v);
+        } else {
+          b0 = (int)grp;
+        }
+        hit0 = check_intersection(d.table + 6 * (size_t)b0, d.half_w2, r.p, r.v);
+      }
+      if (hit0) atomicAdd(&hist[b0], 1u);
+      if (hit1) atomicAdd(&hist[b1], 1u);
+      n_inc += (unsigned long long)(__popcll(__ballot(hit0)) + __popcll(__ballot(hit1)));
+    } else if (SINK == SINK_DZ) {
       // per-lane: TH1D(nbins,-1,1)->Fill(dz)
       bool hit = false;
       int b = 0;
@@ -413,6 +442,8 @@ extern "C" __global__ void __launch_bounds__(kBlock)
 isx_trace_dz_kernel(const Geom g, const DetGrid d, const Work wk) { persistent_body<SINK_DZ>(g, d, wk); }
 extern "C" __global__ void __launch_bounds__(kBlock)
 isx_trace_disc_kernel(const Geom g, const DetGrid d, const Work wk) { persistent_body<SINK_DISC>(g, d, wk); }
+extern "C" __global__ void __launch_bounds__(kBlock)
+isx_trace_perpos_kernel(const Geom g, const DetGrid d, const Work wk) { persistent_body<SINK_PERPOS>(g, d, wk); }
 
 // ------------------------------------------------------------------ per-ray end states (parity tests)
 extern "C" __global__ void __launch_bounds__(256)

@@ -1,0 +1,665 @@
+// isx_macros.cpp — the reference's macro entry points over libisx (see isx_macros.hpp).
+#include "isx_macros.hpp"
+
+#include <sys/stat.h>
+#include <sys/types.h>
+
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <ctime>
+#include <fstream>
+#include <iomanip>
+#include <iostream>
+#include <sstream>
+
+namespace isxhost {
+
+// ---------------------------------------------------------------------------------------------
+// run options / device
+// ---------------------------------------------------------------------------------------------
+RunOptions& options() {
+  static RunOptions o = [] {
+    RunOptions r;
+    if (const char* s = std::getenv("ISX_SEED")) r.seed = std::strtoull(s, nullptr, 0);
+    if (const char* s = std::getenv("ISX_DEVICE")) r.device = std::atoi(s);
+    if (const char* s = std::getenv("ISX_RAYS")) r.rays_override = std::atol(s);
+    if (const char* s = std::getenv("ISX_QUIET")) r.quiet = std::atoi(s) != 0;
+    return r;
+  }();
+  return o;
+}
+
+bool ensure_device() {
+  static int state = 0;  // 0 unknown, 1 ok, -1 failed
+  if (state == 0) {
+    const int rc = isx_init(options().device);
+    if (rc != ISX_OK) {
+      std::cerr << "Error: libisx cannot bind GPU " << options().device << ": " << isx_strerror(rc) << std::endl;
+      state = -1;
+    } else {
+      state = 1;
+    }
+  }
+  return state == 1;
+}
+
+static uint64_t take_rays(uint64_t n) {
+  const uint64_t first = options().next_ray;
+  options().next_ray += n;
+  return first;
+}
+
+static long pick_n(long reference_n) { return options().rays_override > 0 ? options().rays_override : reference_n; }
+
+static double now_s() {
+  return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+
+// ---------------------------------------------------------------------------------------------
+// Detector / OpticsManager
+// ---------------------------------------------------------------------------------------------
+void Detector::setPosition(double theta, double phi, double radius) {
+  // host mirror of fluxAtObserver.C:49-68 for ONE arbitrary position (bulk grids: isx_detector_table)
+  const double theta_rad = theta * M_PI / 180.0;
+  const double phi_rad = phi * M_PI / 180.0;
+  double st, ct, sp, cp;
+  ::sincos(theta_rad, &st, &ct);
+  ::sincos(phi_rad, &sp, &cp);
+  x = radius * st * cp;
+  y = radius * st * sp;
+  z = -100 * cm - radius * ct;
+  const double dx = x - 0;
+  const double dy = y - 0;
+  const double dz = z - (-100 * cm);
+  const double mag = std::sqrt(dx * dx + dy * dy + dz * dz);
+  nx = -dy / mag;
+  ny = dx / mag;
+  nz = dz / mag;
+}
+
+OpticsManager::OpticsManager() { isx_default_config(&cfg); }
+
+// ---------------------------------------------------------------------------------------------
+// files
+// ---------------------------------------------------------------------------------------------
+static bool file_exists(const std::string& p) {
+  FILE* f = std::fopen(p.c_str(), "r");
+  if (!f) return false;
+  std::fclose(f);
+  return true;
+}
+
+std::string getUniqueFilename(const std::string& basePath) {
+  if (!file_exists(basePath)) return basePath;
+  std::string directory, filename;
+  const size_t lastSlash = basePath.find_last_of("/\\");
+  if (lastSlash != std::string::npos) {
+    directory = basePath.substr(0, lastSlash + 1);
+    filename = basePath.substr(lastSlash + 1);
+  } else {
+    filename = basePath;
+  }
+  const size_t lastDot = filename.find_last_of('.');
+  const std::string stem = lastDot != std::string::npos ? filename.substr(0, lastDot) : filename;
+  const std::string ext = lastDot != std::string::npos ? filename.substr(lastDot) : "";
+  for (int counter = 1;; ++counter) {
+    const std::string cand = directory + stem + "_" + std::to_string(counter) + ext;
+    if (!file_exists(cand)) return cand;
+  }
+}
+
+static bool make_dirs(const std::string& path) {  // mkdir -p
+  if (path.empty()) return true;
+  std::string cur;
+  for (size_t i = 0; i <= path.size(); ++i) {
+    if (i == path.size() || path[i] == '/') {
+      if (!cur.empty() && cur != "." && ::mkdir(cur.c_str(), 0777) != 0 && errno != EEXIST) return false;
+    }
+    if (i < path.size()) cur += path[i];
+  }
+  struct stat st;
+  return ::stat(path.c_str(), &st) == 0 && S_ISDIR(st.st_mode);
+}
+
+std::string currentTimeString() {
+  const time_t now = time(nullptr);
+  char buf[80];
+  strftime(buf, sizeof(buf), "%Y-%m-%d %H:%M:%S", localtime(&now));
+  return buf;
+}
+
+std::string fluxmap_header(const FluxMapMeta& m, const std::string& generated) {
+  std::ostringstream o;  // default stream formatting, as the reference before its first std::fixed
+  o << "# " << m.title << " - Generated: " << generated << std::endl;
+  o << "# " << m.n_label << ": " << m.n << std::endl;
+  o << "# Detector dimensions: " << m.det_w << "cm x " << m.det_h << "cm" << std::endl;
+  o << "# Sphere inner radius: " << m.r_in << "cm" << std::endl;
+  o << "# Sphere outer radius: " << m.r_out << "cm" << std::endl;
+  o << "# Exit port angle: " << m.thetaMax << " degrees" << std::endl;
+  o << "# Theta bins: " << m.nTheta << std::endl;
+  o << "# Phi bins: " << m.nPhi << std::endl;
+  o << "# Mirror reflectance: " << m.reflectance << std::endl;
+  o << "# Gaussian roughness: " << m.roughness << std::endl;
+  o << "# Lambertian scattering: enabled" << std::endl;
+  o << "# Source position (x,y,z): " << m.src[0] << "cm, " << m.src[1] << "cm, " << m.src[2] << "cm" << std::endl;
+  o << "# Source direction (x,y,z): " << m.dir[0] << ", " << m.dir[1] << ", " << m.dir[2] << std::endl;
+  o << "# Max reflections: " << m.maxReflections << std::endl;
+  if (!m.method_line.empty()) o << "# Method: " << m.method_line << std::endl;
+  o << "theta,phi,fraction" << std::endl;
+  return o.str();
+}
+
+std::string fluxmap_rows(const uint64_t* hits, long n, int nTheta, int nPhi, int fold) {
+  std::ostringstream o;
+  o << std::fixed << std::setprecision(6);
+  for (int i = 0; i < nTheta; i++) {
+    const double theta = (i + 0.5) * 90.0 / nTheta;
+    if (fold == 2) {  // fluxAtObserverFast.C:693-720: (theta,phi1) then (theta,phi1+180)
+      for (int j = 0; j < nPhi / 2; j++) {
+        const double phi1 = (j + 0.5) * 360.0 / nPhi;
+        double phi2 = phi1 + 180.0;
+        if (phi2 >= 360.0) phi2 -= 360.0;
+        const int j2 = j + nPhi / 2;
+        o << theta << "," << phi1 << "," << double(hits[(size_t)i * nPhi + j]) / double(n) << std::endl;
+        o << theta << "," << phi2 << "," << double(hits[(size_t)i * nPhi + j2]) / double(n) << std::endl;
+      }
+    } else {
+      for (int j = 0; j < nPhi; j++) {
+        const double phi = (j + 0.5) * 360.0 / nPhi;
+        o << theta << "," << phi << "," << double(hits[(size_t)i * nPhi + j]) / double(n) << std::endl;
+      }
+    }
+  }
+  return o.str();
+}
+
+static void say(const std::string& s) {
+  if (!options().quiet) std::cout << s << std::endl;
+}
+
+// ---------------------------------------------------------------------------------------------
+// fluxAtObserver.C
+// ---------------------------------------------------------------------------------------------
+namespace fluxAtObserver {
+
+void setupOpticsManager(OpticsManager* m) {
+  isx_config& c = m->cfg;
+  isx_default_config(&c);
+  c.max_points = 10000;          // manager->SetLimit(10000)
+  c.box_half = 200 * cm;         // TGeoBBox 200
+  c.r_in = 100.1 * cm; c.r_out = 101 * cm; c.theta_max_deg = 170.;
+  c.reflectance = 1.0;           // AMirror default, no SetReflectance
+  c.lambertian = 1;              // EnableLambertian(true)
+  c.roughness_rad = 0.5;         // SetGaussianRoughness(0.5)
+}
+
+bool isRayPassingThroughExitPort(const double lastPoint[3], double exitPortZ) { return lastPoint[2] < exitPortZ; }
+
+static int trace_one_detector(OpticsManager* m, int n, double exitPortZ, Detector& det, const double src[3],
+                              const double dir[3], int source_model) {
+  if (!ensure_device() || n <= 0) return 0;
+  isx_config c = m->cfg;
+  for (int k = 0; k < 3; ++k) { c.src[k] = src[k]; c.dir[k] = dir[k]; }
+  c.exit_port_z = exitPortZ;
+  c.source_model = source_model;
+  const double d6[6] = {det.x, det.y, det.z, det.nx, det.ny, det.nz};
+  uint64_t hits = 0;
+  isx_stats st;
+  const int rc = isx_trace_rays_detector(&c, d6, det.width, (uint64_t)n, options().seed, take_rays((uint64_t)n), &hits, &st);
+  if (rc != ISX_OK) {
+    std::cerr << "Error: isx_trace_rays_detector: " << isx_strerror(rc) << std::endl;
+    return 0;
+  }
+  det.hitCount += (int)hits;
+  return (int)hits;
+}
+
+int traceRays(OpticsManager* m, int n, double exitPortZ, Detector& det, bool) {
+  const double src[3] = {-60 * cm, 0 * cm, -80 * cm}, dir[3] = {5, 2, 0};  // :194-200
+  return trace_one_detector(m, n, exitPortZ, det, src, dir, ISX_SOURCE_PENCIL);
+}
+
+void sweepDetector() {
+  OpticsManager manager;
+  setupOpticsManager(&manager);
+  const long n = pick_n(50000);
+  const double exitPortZ = -100 * cm;
+  const int nThetaBins = 180, nPhiBins = 90;
+  Detector detector;  // 10 cm x 10 cm
+  const char* saveFolder = "results";
+  if (!make_dirs(saveFolder)) std::cerr << "Warning: Could not create directory: " << saveFolder << std::endl;
+  else say(std::string("Using directory: ") + saveFolder);
+  std::string fullPath = std::string(saveFolder) + "/fluxmap_data_" + std::to_string(n) + "rays_" +
+                         std::to_string(nThetaBins * nPhiBins) + "points.csv";
+  fullPath = getUniqueFilename(fullPath);
+  std::ofstream csvFile(fullPath);
+  if (!csvFile.is_open()) {
+    std::cerr << "Error: Could not open file " << fullPath << " for writing." << std::endl;
+    return;
+  }
+  const std::string timeBuffer = currentTimeString();
+  csvFile << "# Flux Map Data - Generated: " << timeBuffer << std::endl;
+  csvFile << "# Number of rays per position: " << n << std::endl;
+  csvFile << "# Detector dimensions: 10cm x 10cm" << std::endl;
+  csvFile << "# Sphere inner radius: 100.1cm" << std::endl;
+  csvFile << "# Sphere outer radius: 101cm" << std::endl;
+  csvFile << "# Exit port angle: " << 170. << " degrees" << std::endl;
+  csvFile << "# Theta bins: " << nThetaBins << std::endl;
+  csvFile << "# Phi bins: " << nPhiBins << std::endl;
+  csvFile << "# y direction: 2" << std::endl;
+  csvFile << "theta,phi,fraction" << std::endl;
+  if (!ensure_device()) return;
+  isx_config c = manager.cfg;
+  c.src[0] = -60; c.src[1] = 0; c.src[2] = -80;
+  c.dir[0] = 5; c.dir[1] = 2; c.dir[2] = 0;
+  c.n_theta = nThetaBins; c.n_phi = nPhiBins; c.det_diameter = detector.width; c.det_distance = 100 * cm;
+  c.exit_port_z = exitPortZ;
+  std::vector<uint64_t> hits((size_t)nThetaBins * nPhiBins);
+  isx_stats st;
+  const uint64_t total = (uint64_t)n * hits.size();
+  const int rc = isx_fluxmap_per_position(&c, (uint64_t)n, 1, 0, hits.size(), options().seed, take_rays(total), hits.data(), &st);
+  if (rc != ISX_OK) {
+    std::cerr << "Error: isx_fluxmap_per_position: " << isx_strerror(rc) << std::endl;
+    return;
+  }
+  csvFile << fluxmap_rows(hits.data(), n, nThetaBins, nPhiBins);
+  csvFile << "# Sweep completed at: " << timeBuffer << std::endl;  // (sic) the reference re-uses the start time, :384
+  csvFile.close();
+  say("\nFlux map data saved to '" + fullPath + "'");
+}
+
+}  // namespace fluxAtObserver
+
+// ---------------------------------------------------------------------------------------------
+// fluxAtObserverOptimize.C
+// ---------------------------------------------------------------------------------------------
+namespace fluxAtObserverOptimize {
+
+void setupOpticsManager(OpticsManager* m, int maxReflections, double roughness, double reflectance, double thetaMax, bool) {
+  isx_config& c = m->cfg;
+  isx_default_config(&c);
+  c.max_points = maxReflections;
+  c.box_half = 300 * cm;
+  c.r_in = INNER_RADIUS; c.r_out = OUTER_RADIUS; c.theta_max_deg = thetaMax;
+  c.reflectance = reflectance;
+  c.lambertian = 1;
+  c.roughness_rad = roughness;
+}
+
+int traceRays(OpticsManager* m, int n, double exitPortZ, Detector& det, bool, int maxPoints) {
+  const double src[3] = {-60 * cm, 0 * cm, -80 * cm}, dir[3] = {5, 0, 0};  // :251-252
+  OpticsManager tmp = *m;
+  tmp.cfg.max_points = maxPoints;
+  return fluxAtObserver::trace_one_detector(&tmp, n, exitPortZ, det, src, dir, ISX_SOURCE_PENCIL);
+}
+
+int traceRaysParallel(OpticsManager* m, int n, double exitPortZ, Detector& det, bool, double x, double y, double z,
+                      double dirX, double dirY, double dirZ) {
+  const double src[3] = {x, y, z}, dir[3] = {dirX, dirY, dirZ};
+  return fluxAtObserver::trace_one_detector(m, n, exitPortZ, det, src, dir, ISX_SOURCE_PENCIL);
+}
+
+static FluxMapMeta meta_for(const char* title, const char* nlabel, long n, double thetaMax, const double src[3],
+                            const double dir[3]) {
+  FluxMapMeta mm;
+  mm.title = title; mm.n_label = nlabel; mm.n = n;
+  mm.det_w = 40; mm.det_h = 40; mm.r_in = INNER_RADIUS / cm; mm.r_out = OUTER_RADIUS / cm; mm.thetaMax = thetaMax;
+  mm.reflectance = REFLECTANCE; mm.roughness = ROUGHNESS; mm.maxReflections = MAX_REFLECTIONS;
+  for (int k = 0; k < 3; ++k) { mm.src[k] = src[k] / cm; mm.dir[k] = dir[k]; }
+  return mm;
+}
+
+void sweepDetector(bool notify, const char* saveFolder, int /*threads: ignored, as in the reference*/, double srcX,
+                   double srcY, double srcZ, double dirX, double dirY, double dirZ, double thetaMax) {
+  OpticsManager manager;
+  setupOpticsManager(&manager, MAX_REFLECTIONS, ROUGHNESS, REFLECTANCE, thetaMax, false);
+  const long n = pick_n(50000);
+  const double exitPortZ = -100 * cm;
+  const int nThetaBins = 180, nPhiBins = 90;
+  if (!make_dirs(saveFolder)) std::cerr << "Warning: Could not create directory: " << saveFolder << std::endl;
+  else say(std::string("Using directory: ") + saveFolder);
+  std::string fullPath = std::string(saveFolder) + "/fluxmap_" + std::to_string(n) + "rays_" + std::to_string(nThetaBins) +
+                         "x" + std::to_string(nPhiBins) + "_src" + std::to_string(int(srcX / cm)) + "_" +
+                         std::to_string(int(srcY / cm)) + "_" + std::to_string(int(srcZ / cm)) + ".csv";
+  fullPath = getUniqueFilename(fullPath);
+  std::ofstream csvFile(fullPath);
+  if (!csvFile.is_open()) {
+    std::cerr << "Error: Could not open file " << fullPath << " for writing." << std::endl;
+    return;
+  }
+  Detector detector(40 * cm, 40 * cm);
+  const double src[3] = {srcX, srcY, srcZ}, dir[3] = {dirX, dirY, dirZ};
+  csvFile << fluxmap_header(meta_for("Flux Map Data", "Number of rays per position", n, thetaMax, src, dir), currentTimeString());
+  const int totalPositions = nThetaBins * nPhiBins;
+  say("\nStarting detector sweep with " + std::to_string(n) + " rays per position (" + std::to_string(totalPositions) +
+      " positions total)...");
+  if (!ensure_device()) return;
+  const double t0 = now_s();
+  isx_config c = manager.cfg;
+  for (int k = 0; k < 3; ++k) { c.src[k] = src[k]; c.dir[k] = dir[k]; }
+  c.n_theta = nThetaBins; c.n_phi = nPhiBins; c.det_diameter = detector.width; c.det_distance = 100 * cm;
+  c.exit_port_z = exitPortZ;
+  std::vector<uint64_t> hits((size_t)totalPositions);
+  isx_stats st;
+  const uint64_t total = (uint64_t)n * (uint64_t)totalPositions;
+  const int rc = isx_fluxmap_per_position(&c, (uint64_t)n, 1, 0, (uint64_t)totalPositions, options().seed, take_rays(total),
+                                          hits.data(), &st);
+  if (rc != ISX_OK) {
+    std::cerr << "Error: isx_fluxmap_per_position: " << isx_strerror(rc) << std::endl;
+    return;
+  }
+  csvFile << fluxmap_rows(hits.data(), n, nThetaBins, nPhiBins);
+  const double realTime = now_s() - t0;
+  // the stream is still in fixed/6 mode in the reference when the footer is written (:575,:668)
+  csvFile << std::fixed << std::setprecision(6);
+  csvFile << "# Sweep completed at: " << currentTimeString() << std::endl;
+  csvFile << "# Total execution time: " << realTime << " seconds" << std::endl;
+  csvFile << "# Total ray hits: " << st.bin_increments << " out of " << total << std::endl;
+  csvFile.close();
+  say("\nFlux map data saved to '" + fullPath + "'");
+  if (!options().quiet) {
+    std::cout << "Sweep completed in " << realTime << " seconds (wall clock), GPU kernels " << st.t_kernel_ms * 1e-3
+              << " s, " << total / (st.t_kernel_ms * 1e-3) / 1e6 << " Mrays/s" << std::endl;
+    if (notify) std::cout << "\n***** SWEEP COMPLETE *****\n" << std::endl << '\a' << std::endl;
+  }
+}
+
+void sweepSeries() {
+  const double srcX = -60 * cm, srcY = 0 * cm, srcZ = -75 * cm, dirXBase = 5;
+  const std::string baseFolder = "results_overnight_04_1" + std::to_string(int(srcX / cm)) + "_" +
+                                 std::to_string(int(srcY / cm)) + "_" + std::to_string(int(srcZ / cm)) + "_" +
+                                 std::to_string(int(dirXBase));
+  for (double port : {163., 166., 169., 172., 175., 178.})
+    sweepDetector(false, baseFolder.c_str(), 1, srcX, srcY, srcZ, dirXBase, 0, 0, port);
+}
+
+}  // namespace fluxAtObserverOptimize
+
+// ---------------------------------------------------------------------------------------------
+// fluxAtObserverFast.C
+// ---------------------------------------------------------------------------------------------
+namespace fluxAtObserverFast {
+using fluxAtObserverOptimize::INNER_RADIUS;
+using fluxAtObserverOptimize::MAX_REFLECTIONS;
+using fluxAtObserverOptimize::OUTER_RADIUS;
+using fluxAtObserverOptimize::REFLECTANCE;
+using fluxAtObserverOptimize::ROUGHNESS;
+
+int traceRaysParallelTwofold(OpticsManager* m, int n, double exitPortZ, Detector& d1, Detector& d2, bool, double x,
+                             double y, double z, double dirX, double dirY, double dirZ) {
+  // the SAME n rays against two detectors: identical ray indices for both calls
+  if (!ensure_device() || n <= 0) return 0;
+  const uint64_t first = take_rays((uint64_t)n);
+  isx_config c = m->cfg;
+  c.src[0] = x; c.src[1] = y; c.src[2] = z; c.dir[0] = dirX; c.dir[1] = dirY; c.dir[2] = dirZ;
+  c.exit_port_z = exitPortZ;
+  int total = 0;
+  for (Detector* d : {&d1, &d2}) {
+    const double d6[6] = {d->x, d->y, d->z, d->nx, d->ny, d->nz};
+    uint64_t h = 0;
+    isx_stats st;
+    const int rc = isx_trace_rays_detector(&c, d6, d->width, (uint64_t)n, options().seed, first, &h, &st);
+    if (rc != ISX_OK) {
+      std::cerr << "Error: isx_trace_rays_detector: " << isx_strerror(rc) << std::endl;
+      return total;
+    }
+    d->hitCount += (int)h;
+    total += (int)h;
+  }
+  return total;
+}
+
+static void sweep_common(bool traceOnce, bool notify, const char* saveFolder, double srcX, double srcY, double srcZ,
+                         double dirX, double dirY, double dirZ, double thetaMax) {
+  const double tSetup = now_s();
+  OpticsManager manager;
+  fluxAtObserverOptimize::setupOpticsManager(&manager, MAX_REFLECTIONS, ROUGHNESS, REFLECTANCE, thetaMax, false);
+  const long n = pick_n(traceOnce ? 100000 : 50000);
+  const double exitPortZ = -100 * cm;
+  const int nThetaBins = 180, nPhiBins = 90;
+  const int totalPositions = nThetaBins * nPhiBins;
+  if (!make_dirs(saveFolder)) std::cerr << "Warning: Could not create directory: " << saveFolder << std::endl;
+  std::string fullPath = std::string(saveFolder) + (traceOnce ? "/fluxmap_traceonce_" : "/fluxmap_twofold_") +
+                         std::to_string(n) + "rays_" + std::to_string(nThetaBins) + "x" + std::to_string(nPhiBins) +
+                         "_src" + std::to_string(int(srcX / cm)) + "_" + std::to_string(int(srcY / cm)) + "_" +
+                         std::to_string(int(srcZ / cm)) + ".csv";
+  fullPath = getUniqueFilename(fullPath);
+  const double src[3] = {srcX, srcY, srcZ}, dir[3] = {dirX, dirY, dirZ};
+  FluxMapMeta mm;
+  mm.title = traceOnce ? "Flux Map Data (Trace-Once Method)" : "Flux Map Data (Twofold Method)";
+  mm.n_label = traceOnce ? "Number of rays" : "Number of rays per position";
+  mm.method_line = traceOnce ? "Trace-Once (single trace, multiple detector positions)" : "Twofold (two detectors 180° apart)";
+  mm.n = n; mm.r_in = INNER_RADIUS / cm; mm.r_out = OUTER_RADIUS / cm; mm.thetaMax = thetaMax;
+  mm.reflectance = REFLECTANCE; mm.roughness = ROUGHNESS; mm.maxReflections = MAX_REFLECTIONS;
+  for (int k = 0; k < 3; ++k) { mm.src[k] = src[k] / cm; mm.dir[k] = dir[k]; }
+  std::ofstream csvFile(fullPath, std::ios::trunc);
+  if (!csvFile.is_open()) {
+    std::cerr << "Error: Could not open file " << fullPath << " for writing." << std::endl;
+    return;
+  }
+  csvFile << fluxmap_header(mm, currentTimeString());
+  if (!ensure_device()) return;
+  isx_config c = manager.cfg;
+  for (int k = 0; k < 3; ++k) { c.src[k] = src[k]; c.dir[k] = dir[k]; }
+  c.n_theta = nThetaBins; c.n_phi = nPhiBins; c.det_diameter = 40 * cm; c.det_distance = 100 * cm;
+  c.exit_port_z = exitPortZ;
+  std::vector<uint64_t> hits((size_t)totalPositions);
+  isx_stats st;
+  int rc;
+  const double t0 = now_s();
+  if (traceOnce) {
+    // one trace, every exiting line tested against all 16200 positions (fluxAtObserverFast.C:1143-1315), with
+    // the per-position hit semantics (last point + final direction); the reference's GetPoint(nPoints-2)
+    // defect (:1181,:1225) is deliberately not reproduced.
+    rc = isx_fluxmap(&c, (uint64_t)n, options().seed, take_rays((uint64_t)n), hits.data(), &st);
+  } else {
+    const uint64_t groups = (uint64_t)totalPositions / 2;
+    rc = isx_fluxmap_per_position(&c, (uint64_t)n, 2, 0, groups, options().seed, take_rays((uint64_t)n * groups), hits.data(), &st);
+  }
+  if (rc != ISX_OK) {
+    std::cerr << "Error: libisx: " << isx_strerror(rc) << std::endl;
+    return;
+  }
+  const double rayTime = st.t_kernel_ms * 1e-3;
+  const double t1 = now_s();
+  csvFile << fluxmap_rows(hits.data(), n, nThetaBins, nPhiBins, traceOnce ? 1 : 2);
+  csvFile.close();
+  const double sweepTime = now_s() - t1;
+  const double totalTime = now_s() - tSetup;
+  std::ofstream app(fullPath, std::ios::app);  // fresh stream => default number format, as in the reference (:1374-1382)
+  if (app.is_open()) {
+    app << "# Sweep completed at: " << currentTimeString() << std::endl;
+    if (traceOnce) {
+      app << "# Total execution time: " << totalTime << " seconds" << std::endl;
+      app << "# Ray tracing time: " << rayTime << " seconds" << std::endl;
+      app << "# Detector sweep time: " << sweepTime << " seconds" << std::endl;
+      app << "# Total rays exiting port: " << st.counted_below_z << " out of " << n << std::endl;
+    } else {
+      app << std::fixed << std::setprecision(6);
+      app << "# Total execution time: " << (now_s() - t0) << " seconds" << std::endl;
+      app << "# Total ray hits: " << st.bin_increments << " out of " << (uint64_t)n * (uint64_t)totalPositions << std::endl;
+    }
+  }
+  say("\nFlux map data saved to '" + fullPath + "'");
+  if (!options().quiet) {
+    std::cout << "Ray tracing completed in " << rayTime << " seconds" << std::endl;
+    if (traceOnce) std::cout << "Total rays exiting port: " << st.counted_below_z << " out of " << n << std::endl;
+    if (notify) std::cout << (traceOnce ? "\n***** TRACE-ONCE SWEEP COMPLETE *****\n" : "\n***** SWEEP COMPLETE *****\n") << std::endl << '\a' << std::endl;
+  }
+}
+
+void sweepDetectorTwofold(bool notify, const char* saveFolder, int, double srcX, double srcY, double srcZ, double dirX,
+                          double dirY, double dirZ, double thetaMax) {
+  sweep_common(false, notify, saveFolder, srcX, srcY, srcZ, dirX, dirY, dirZ, thetaMax);
+}
+
+void sweepDetectorTraceOnce(bool notify, const char* saveFolder, int, double srcX, double srcY, double srcZ, double dirX,
+                            double dirY, double dirZ, double thetaMax) {
+  sweep_common(true, notify, saveFolder, srcX, srcY, srcZ, dirX, dirY, dirZ, thetaMax);
+}
+
+void sweepSeries() {
+  const double srcX = -60 * cm, srcY = 0 * cm, srcZ = -75 * cm, dirXBase = 5, portAngle = 164.0;
+  const std::string baseFolder = "portAngleSweep_04_03_" + std::to_string(int(srcX / cm)) + "_" +
+                                 std::to_string(int(srcY / cm)) + "_" + std::to_string(int(srcZ / cm)) + "_" +
+                                 std::to_string(int(portAngle));
+  for (int i = 0; i < 5; i++) sweepDetectorTraceOnce(false, baseFolder.c_str(), 1, srcX, srcY, srcZ, dirXBase, 0, 0, portAngle);
+  if (!options().quiet) std::cout << "\n***** ALL SWEEP SERIES COMPLETE *****\n" << std::endl << '\a' << std::endl;
+}
+
+}  // namespace fluxAtObserverFast
+
+// ---------------------------------------------------------------------------------------------
+// nonLambertianFlux.C
+// ---------------------------------------------------------------------------------------------
+namespace nonLambertianFlux {
+
+void setupOpticsManager(OpticsManager* m) {
+  fluxAtObserver::setupOpticsManager(m);  // identical constants (:213-226)
+  m->cfg.brdf[0] = 0.3; m->cfg.brdf[1] = 0.4; m->cfg.brdf[2] = 0.6;  // gBRDF(0.3, 0.4, 0.6) :211
+}
+
+int traceRays(OpticsManager* m, int n, double exitPortZ, Detector& det, bool) {
+  const double src[3] = {-60 * cm, 0 * cm, -80 * cm}, dir[3] = {5, 0, 0};  // :243-244
+  return fluxAtObserver::trace_one_detector(m, n, exitPortZ, det, src, dir, ISX_SOURCE_BRDF);
+}
+
+void sweepDetector() {
+  OpticsManager manager;
+  setupOpticsManager(&manager);
+  const long n = pick_n(100000);
+  const double exitPortZ = -100 * cm;
+  const int nThetaBins = 45, nPhiBins = 20;
+  Detector detector;
+  if (!ensure_device()) return;
+  isx_config c = manager.cfg;
+  c.src[0] = -60; c.src[1] = 0; c.src[2] = -80; c.dir[0] = 5; c.dir[1] = 0; c.dir[2] = 0;
+  c.n_theta = nThetaBins; c.n_phi = nPhiBins; c.det_diameter = detector.width; c.det_distance = 100 * cm;
+  c.exit_port_z = exitPortZ; c.source_model = ISX_SOURCE_BRDF;
+  std::vector<uint64_t> hits((size_t)nThetaBins * nPhiBins);
+  isx_stats st;
+  const uint64_t total = (uint64_t)n * hits.size();
+  const int rc = isx_fluxmap_per_position(&c, (uint64_t)n, 1, 0, hits.size(), options().seed, take_rays(total), hits.data(), &st);
+  if (rc != ISX_OK) {
+    std::cerr << "Error: isx_fluxmap_per_position: " << isx_strerror(rc) << std::endl;
+    return;
+  }
+  const std::string path = getUniqueFilename("fluxmap_data.csv");  // the reference overwrites; this driver never does
+  std::ofstream csvFile(path);
+  if (!csvFile.is_open()) {
+    std::cerr << "Error: Could not open file " << path << " for writing." << std::endl;
+    return;
+  }
+  csvFile << "theta,phi,fraction\n";
+  std::string rows = fluxmap_rows(hits.data(), n, nThetaBins, nPhiBins);
+  csvFile << rows;
+  csvFile.close();
+  say("\nFlux map data saved to '" + path + "'");
+}
+
+}  // namespace nonLambertianFlux
+
+// ---------------------------------------------------------------------------------------------
+// root-level macros
+// ---------------------------------------------------------------------------------------------
+namespace rootMacros {
+
+static void root_geometry(isx_config& c, double r_out) {
+  isx_default_config(&c);
+  c.max_points = 10000; c.box_half = 200 * cm; c.r_in = 100.1 * cm; c.r_out = r_out; c.theta_max_deg = 170.;
+  c.reflectance = 1.0; c.lambertian = 1; c.roughness_rad = 0.0;
+  c.src[0] = -60 * cm; c.src[1] = 0; c.src[2] = -80 * cm; c.dir[0] = 5; c.dir[1] = 0; c.dir[2] = 0;
+}
+
+void makeIntegratingSphereNRays() {
+  if (!ensure_device()) return;
+  isx_config c;
+  root_geometry(c, 101 * cm);
+  const long n = pick_n(1000);
+  c.n_theta = 1; c.n_phi = 1;
+  std::vector<uint64_t> hist(1);
+  isx_stats st;
+  const int rc = isx_exit_dz_hist(&c, (uint64_t)n, options().seed, take_rays((uint64_t)n), 1, hist.data(), &st);
+  if (rc != ISX_OK) {
+    std::cerr << "Error: libisx: " << isx_strerror(rc) << std::endl;
+    return;
+  }
+  std::cout << "Flux of rays through the exit port: " << st.counted_below_z << std::endl;  // :93
+}
+
+void detectorDiskPlacement(double theta, double phi, double out[6]) {
+  const double r = 200 * cm;  // :151-154
+  const double x = r * std::sin(theta * M_PI / 180.0) * std::cos(phi * M_PI / 180.0);
+  const double y = r * std::sin(theta * M_PI / 180.0) * std::sin(phi * M_PI / 180.0);
+  const double z = -r * std::cos(theta * M_PI / 180.0);
+  const double dx = 0 - x, dy = 0 - y, dz = -100 * cm - z;
+  const double rotTheta = -std::atan2(std::sqrt(dx * dx + dy * dy), dz);  // radians here; degrees in the macro
+  // rot->RotateZ(rotPhi); rot->RotateY(rotTheta): TGeoRotation left-multiplies, so the tube axis (local z) becomes
+  // RY(rotTheta)*RZ(rotPhi)*ez = (sin rotTheta, 0, cos rotTheta) whatever rotPhi is (checked against detector_sweep.txt).
+  out[0] = x; out[1] = y; out[2] = z;
+  out[3] = std::sin(rotTheta); out[4] = 0.0; out[5] = std::cos(rotTheta);
+}
+
+void sweepDetector(OpticsManager* manager, double diskRadius, int nRays, double dtheta, double thetaMax) {
+  const double dphi = 180;
+  std::ofstream outFile(getUniqueFilename("detector_sweep3.txt"));
+  if (!outFile.is_open()) {
+    std::cerr << "Error: Could not open file detector_sweep3.txt for writing." << std::endl;
+    return;
+  }
+  outFile << "Theta(deg)\tPhi(deg)\tHitFraction\n";
+  if (!ensure_device()) return;
+  for (double theta = -thetaMax; theta <= thetaMax; theta += dtheta) {
+    for (double phi = 0; phi < 360; phi += dphi) {
+      double ca[6];
+      detectorDiskPlacement(theta, phi, ca);
+      uint64_t hits = 0;
+      isx_stats st;
+      // fresh rays per position, as the reference's inner loop (:67-77)
+      const int rc = isx_disc_sweep(&manager->cfg, ca, 1, diskRadius, 0.1 * cm, (uint64_t)nRays, options().seed,
+                                    take_rays((uint64_t)nRays), &hits, &st);
+      if (rc != ISX_OK) {
+        std::cerr << "Error: isx_disc_sweep: " << isx_strerror(rc) << std::endl;
+        return;
+      }
+      const double hitFraction = static_cast<double>(hits) / nRays;
+      if (!options().quiet)
+        std::cout << "Theta: " << theta << "° Phi: " << phi << "° Hit fraction: " << hitFraction << std::endl;
+      outFile << theta << "\t" << phi << "\t" << hitFraction << "\n";
+    }
+  }
+  outFile.close();
+}
+
+void integratingSphereDetectorSweep() {
+  OpticsManager manager;
+  root_geometry(manager.cfg, 105 * cm);  // TGeoSphere(100.1, 105, 0, 170) :118
+  const int nRays = (int)pick_n(100000);
+  sweepDetector(&manager, 5 * cm, nRays, 0.5, 45);
+}
+
+void distributionSphereDetectorSweep() {
+  if (!ensure_device()) return;
+  isx_config c;
+  root_geometry(c, 101 * cm);
+  const long n = pick_n(10000);
+  std::vector<uint64_t> hist(100);
+  isx_stats st;
+  const int rc = isx_exit_dz_hist(&c, (uint64_t)n, options().seed, take_rays((uint64_t)n), 100, hist.data(), &st);
+  if (rc != ISX_OK) {
+    std::cerr << "Error: libisx: " << isx_strerror(rc) << std::endl;
+    return;
+  }
+  std::cout << "Flux of rays through the exit port: " << st.counted_below_z << std::endl;
+  // hDirectionZ = TH1D(100,-1,1) (:54,:91); written in the format of the committed angular_dist.txt
+  std::ofstream f(getUniqueFilename("angular_dist.txt"));
+  f << "# bin_center content\n";
+  for (int b = 0; b < 100; ++b) f << (-1.0 + (b + 0.5) * 0.02) << " " << hist[b] << "\n";
+}
+
+}  // namespace rootMacros
+
+}  // namespace isxhost

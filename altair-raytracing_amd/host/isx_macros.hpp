@@ -1,0 +1,130 @@
+// isx_macros.hpp — host driver that keeps the reference's ROOT-macro entry signatures
+//  and routes them to libisx (include/isx.h).  No ROOT, no ROBAST.
+//
+// One namespace per reference macro file, because the files reuse names
+// (sweepDetector, traceRays, setupOpticsManager) with different constants:
+//
+//   isxhost::fluxAtObserver          flux_at_observer/fluxAtObserver.C
+//   isxhost::fluxAtObserverOptimize  flux_at_observer/fluxAtObserverOptimize.C
+//   isxhost::fluxAtObserverFast      flux_at_observer/fluxAtObserverFast.C
+//   isxhost::nonLambertianFlux       flux_at_observer/nonLambertianFlux.C
+//   isxhost::rootMacros              makeIntegratingSphereNRays.C, integratingSphereDetectorSweep.C,
+//                                    distributionSphereDetectorSweep.C
+//
+// `AOpticsManager*` becomes the opaque `OpticsManager*` (it holds an isx_config); the
+// visualisation arguments (drawRays) are accepted and ignored; `threads` is accepted and
+// ignored exactly as the reference ignores it (fluxAtObserverOptimize.C:433).
+// Errors: message on std::cerr and early return, never an exception (reference behaviour,
+// fluxAtObserverOptimize.C:485-488); existing files are never overwritten (getUniqueFilename).
+#pragma once
+#include <cstdint>
+#include <string>
+#include <vector>
+
+#include "../../include/isx.h"
+
+namespace isxhost {
+
+constexpr double cm = 1.0;  // AOpticsManager::cm()
+constexpr double nm = 1e-7; // AOpticsManager::nm() (unused by the physics: reflectance is a scalar)
+
+// Detector (fluxAtObserver.C:31-145) — data + setPosition; the hit test runs on the GPU.
+struct Detector {
+  double x = 0, y = 0, z = 0;
+  double nx = 0, ny = 0, nz = 0;
+  double width, height;
+  int hitCount = 0;
+  explicit Detector(double w = 10 * cm, double h = 10 * cm) : width(w), height(h) {}
+  void setPosition(double theta, double phi, double radius);  // fluxAtObserver.C:49-68
+};
+
+struct OpticsManager {  // stands in for AOpticsManager: geometry + surface parameters
+  isx_config cfg;
+  OpticsManager();
+};
+
+// --- run-wide settings (the reference has none: it uses the global, unseeded gRandom)
+struct RunOptions {
+  uint64_t seed = 0x5EED0001ull;   // env ISX_SEED
+  uint64_t next_ray = 0;           // advances so successive sweeps use fresh Philox streams
+  int device = 0;                  // env ISX_DEVICE
+  long rays_override = -1;         // env ISX_RAYS: replaces the macros' hard-coded n (tests)
+  bool quiet = false;              // env ISX_QUIET
+};
+RunOptions& options();
+// Binds libisx to options().device on first use; false (and a message on cerr) if no GPU.
+bool ensure_device();
+
+// --- CSV plumbing shared by the sweeps (exposed for tests)
+std::string getUniqueFilename(const std::string& basePath);  // fluxAtObserverOptimize.C:336-387
+std::string currentTimeString();                              // "%Y-%m-%d %H:%M:%S"
+struct FluxMapMeta {
+  std::string title;               // "Flux Map Data" | "Flux Map Data (Trace-Once Method)" | ...
+  std::string n_label;             // "Number of rays per position" | "Number of rays"
+  std::string method_line;         // optional "# Method: ..." line
+  long n = 0;
+  double det_w = 40, det_h = 40, r_in = 100.1, r_out = 101, thetaMax = 170;
+  int nTheta = 180, nPhi = 90;
+  double reflectance = 0.99, roughness = 0.01;
+  double src[3] = {-60, 0, -75}, dir[3] = {5, 0, 0};
+  int maxReflections = 50000;
+};
+// header exactly as fluxAtObserverOptimize.C:504-518 / fluxAtObserverFast.C:1117-1132
+std::string fluxmap_header(const FluxMapMeta& m, const std::string& generated);
+// rows "theta,phi,fraction" fixed/6, theta-major (fold 2: twofold row order j, j+nPhi/2)
+std::string fluxmap_rows(const uint64_t* hits, long n, int nTheta, int nPhi, int fold = 1);
+
+namespace fluxAtObserver {
+void setupOpticsManager(OpticsManager* manager);                                  // :147-160
+bool isRayPassingThroughExitPort(const double lastPoint[3], double exitPortZ);    // :162-166
+int traceRays(OpticsManager* manager, int n, double exitPortZ, Detector& detector, bool drawRays = false);  // :169-228
+void sweepDetector();                                                             // :231-406
+}  // namespace fluxAtObserver
+
+namespace fluxAtObserverOptimize {
+constexpr double THETA_MAX = 170.;
+constexpr int MAX_REFLECTIONS = 50000;
+constexpr double INNER_RADIUS = 100.1 * cm, OUTER_RADIUS = 101 * cm, REFLECTANCE = 0.99, ROUGHNESS = 0.01;
+void setupOpticsManager(OpticsManager* manager, int maxReflections = MAX_REFLECTIONS, double roughness = ROUGHNESS,
+                        double reflectance = REFLECTANCE, double thetaMax = THETA_MAX, bool drawRays = false);  // :192-230
+int traceRays(OpticsManager* manager, int n, double exitPortZ, Detector& detector, bool drawRays = false,
+              int maxPoints = MAX_REFLECTIONS);                                                                   // :239-278
+int traceRaysParallel(OpticsManager* manager, int n, double exitPortZ, Detector& detector, bool drawRays = false,
+                      double x = -60 * cm, double y = 0 * cm, double z = -80 * cm, double dirX = 5, double dirY = 2,
+                      double dirZ = 0);                                                                            // :281-333
+void sweepDetector(bool notify = true, const char* saveFolder = "results", int threads = -1, double srcX = -60 * cm,
+                   double srcY = 0 * cm, double srcZ = -80 * cm, double dirX = 5, double dirY = 2, double dirZ = 0,
+                   double thetaMax = THETA_MAX);                                                                   // :433-702
+void sweepSeries();                                                                                                // :892-921
+}  // namespace fluxAtObserverOptimize
+
+namespace fluxAtObserverFast {
+int traceRaysParallelTwofold(OpticsManager* manager, int n, double exitPortZ, Detector& detector1, Detector& detector2,
+                             bool drawRays = false, double x = -60 * cm, double y = 0 * cm, double z = -80 * cm,
+                             double dirX = 5, double dirY = 2, double dirZ = 0);                                   // :336-408
+void sweepDetectorTwofold(bool notify = true, const char* saveFolder = "results", int threads = -1,
+                          double srcX = -60 * cm, double srcY = 0 * cm, double srcZ = -80 * cm, double dirX = 5,
+                          double dirY = 2, double dirZ = 0, double thetaMax = 170.);                               // :518-865
+void sweepDetectorTraceOnce(bool notify = true, const char* saveFolder = "results", int threads = -1,
+                            double srcX = -60 * cm, double srcY = 0 * cm, double srcZ = -80 * cm, double dirX = 5,
+                            double dirY = 2, double dirZ = 0, double thetaMax = 170.);                             // :1068-1397
+void sweepSeries();                                                                                                // :1641-1673
+}  // namespace fluxAtObserverFast
+
+namespace nonLambertianFlux {
+void setupOpticsManager(OpticsManager* manager);                                                                   // :213-226
+int traceRays(OpticsManager* manager, int n, double exitPortZ, Detector& detector, bool drawRays = false);        // :235-304
+void sweepDetector();                                                                                              // :307-387
+}  // namespace nonLambertianFlux
+
+namespace rootMacros {
+void makeIntegratingSphereNRays();                                         // makeIntegratingSphereNRays.C:22-100
+// inner sweep of integratingSphereDetectorSweep.C:31-105 (AOpticalComponent* world is folded into the manager)
+void sweepDetector(OpticsManager* manager, double diskRadius, int nRays, double dtheta, double thetaMax);
+void integratingSphereDetectorSweep();                                     // integratingSphereDetectorSweep.C:107-131
+// disc placement of addDetectorDisk (:145-172): centre + tube axis after RotateZ(rotPhi), RotateY(rotTheta)
+void detectorDiskPlacement(double theta, double phi, double out6[6]);
+void distributionSphereDetectorSweep();                                    // distributionSphereDetectorSweep.C:26-130
+}  // namespace rootMacros
+
+}  // namespace isxhost

@@ -155,6 +155,27 @@ int isx_disc_sweep(const isx_config* cfg, const double* centers_axes /*[n_disc][
                    uint64_t* hits, isx_stats* stats);
 
 /*
+ * The reference's PER-POSITION maps: every detector position gets its own
+ * `rays_per_position` fresh rays (fluxAtObserverOptimize.C:542-579, n=50000 => 8.1e8 rays
+ * for 180x90).  Rays [first_ray + g*rays_per_position, +rays_per_position) belong to
+ * detector group g and are tested against that group only.  fold=1: group g is bin g
+ * (theta-major).  fold=2 is the "twofold" variant (fluxAtObserverFast.C:336-408,518-865):
+ * group g = (i, j<n_phi/2) feeds the two detectors (i,j) and (i,j+n_phi/2).
+ * Groups [first_group, first_group+n_groups) are traced (so ranks can split a map);
+ * hits: host buffer [n_theta*n_phi], zeroed by the callee.
+ */
+int isx_fluxmap_per_position(const isx_config* cfg, uint64_t rays_per_position, int32_t fold, uint64_t first_group,
+                             uint64_t n_groups, uint64_t seed, uint64_t first_ray, uint64_t* hits, isx_stats* stats);
+
+/*
+ * int traceRays(AOpticsManager*, int n, double exitPortZ, Detector&, bool) (fluxAtObserver.C:169,
+ * fluxAtObserverOptimize.C:239,281): n rays against ONE detector given as x,y,z,nx,ny,nz
+ * (what Detector::setPosition left in the struct) and its width.
+ */
+int isx_trace_rays_detector(const isx_config* cfg, const double* detector /*[6]*/, double width, uint64_t n_rays,
+                            uint64_t seed, uint64_t first_ray, uint64_t* hit_count, isx_stats* stats);
+
+/*
  * Exit-direction by-product (distributionSphereDetectorSweep.C:54,91): histogram of the z
  * component of the final direction of every ray counted below exit_port_z,
  * TH1D(nbins,-1,1) binning.  hist: host buffer [nbins], zeroed by the callee.

@@ -643,6 +643,88 @@ int isxo_fluxmap(const isxo_config* c, uint64_t n, uint64_t seed, uint64_t first
   return 0;
 }
 
+int isxo_fluxmap_per_position(const isxo_config* c, uint64_t rpp, int32_t fold, uint64_t first_group, uint64_t n_groups,
+                              uint64_t seed, uint64_t first, uint64_t* hits, isxo_stats* stats, int nthreads) {
+  geom g;
+  if (!c || !hits || rpp < 1 || (fold != 1 && fold != 2)) return -3;
+  int rc = prepare(c, &g);
+  if (rc) return rc;
+  if (c->n_theta < 1 || c->n_phi < 1 || (fold == 2 && (c->n_phi % 2))) return -2;
+  size_t nb = (size_t)c->n_theta * c->n_phi;
+  if (first_group + n_groups > nb / (size_t)fold) return -3;
+  double* tab = (double*)malloc(nb * 6 * sizeof(double));
+  isxo_detector_table(c, tab);
+  memset(hits, 0, nb * sizeof(uint64_t));
+  isxo_stats tot;
+  memset(&tot, 0, sizeof(tot));
+  double t0 = now_ms();
+#ifdef _OPENMP
+  if (nthreads > 0) omp_set_num_threads(nthreads);
+  else omp_set_num_threads(omp_get_num_procs());
+#endif
+#pragma omp parallel
+  {
+    isxo_stats st;
+    memset(&st, 0, sizeof(st));
+#pragma omp for schedule(dynamic, 4)
+    for (int64_t gi = 0; gi < (int64_t)n_groups; gi++) {
+      uint64_t grp = first_group + (uint64_t)gi;
+      size_t b0, b1 = 0;
+      if (fold == 2) {
+        int half = c->n_phi / 2;
+        b0 = (size_t)(grp / (uint64_t)half) * c->n_phi + (size_t)(grp % (uint64_t)half);
+        b1 = b0 + half;
+      } else b0 = (size_t)grp;
+      uint64_t h0 = 0, h1 = 0;
+      for (uint64_t k = 0; k < rpp; k++) { /* traceRaysParallel, fluxAtObserverOptimize.C:281-333 */
+        endstate es;
+        trace_ray(c, &g, seed, first + grp * rpp + k, &es);
+        int counted;
+        census(&es, c->exit_port_z, &st, &counted);
+        if (counted) {
+          double lp[3] = { es.p.x, es.p.y, es.p.z }, d[3] = { es.v.x, es.v.y, es.v.z };
+          if (isxo_check_intersection(tab + 6 * b0, c->det_diameter, lp, d)) h0++;
+          if (fold == 2 && isxo_check_intersection(tab + 6 * b1, c->det_diameter, lp, d)) h1++;
+        }
+      }
+      hits[b0] = h0;
+      if (fold == 2) hits[b1] = h1;
+      st.bin_increments += h0 + h1;
+    }
+#pragma omp critical
+    stats_add(&tot, &st);
+  }
+  tot.t_kernel_ms = now_ms() - t0;
+  if (stats) *stats = tot;
+  free(tab);
+  return 0;
+}
+
+int isxo_trace_rays_detector(const isxo_config* c, const double* det, double width, uint64_t n, uint64_t seed,
+                             uint64_t first, uint64_t* hit_count, isxo_stats* stats) {
+  geom g;
+  if (!c || !det || !hit_count) return -3;
+  int rc = prepare(c, &g);
+  if (rc) return rc;
+  isxo_stats st;
+  memset(&st, 0, sizeof(st));
+  uint64_t h = 0;
+  for (uint64_t i = 0; i < n; i++) {
+    endstate es;
+    trace_ray(c, &g, seed, first + i, &es);
+    int counted;
+    census(&es, c->exit_port_z, &st, &counted);
+    if (counted) {
+      double lp[3] = { es.p.x, es.p.y, es.p.z }, d[3] = { es.v.x, es.v.y, es.v.z };
+      if (isxo_check_intersection(det, width, lp, d)) h++;
+    }
+  }
+  st.bin_increments = h;
+  *hit_count = h;
+  if (stats) *stats = st;
+  return 0;
+}
+
 /* forward segment [0,tmax] of p+t*v enters the tube {|s|<=h, rho<=r} about centre c, unit axis a */
 static int segment_hits_tube(v3 p, v3 v, double tmax, const double ca[6], double r, double h) {
   v3 c = { ca[0], ca[1], ca[2] }, a = { ca[3], ca[4], ca[5] };

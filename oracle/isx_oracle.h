@@ -64,6 +64,14 @@ int isxo_trace_endstates(const isxo_config* cfg, uint64_t n_rays, uint64_t seed,
 int isxo_fluxmap(const isxo_config* cfg, uint64_t n_rays, uint64_t seed, uint64_t first_ray,
                  uint64_t* hits, isxo_stats* stats, int nthreads);
 
+/* Per-position maps (fluxAtObserverOptimize.C:542-579; fold=2: fluxAtObserverFast.C:336-408). */
+int isxo_fluxmap_per_position(const isxo_config* cfg, uint64_t rays_per_position, int32_t fold, uint64_t first_group,
+                              uint64_t n_groups, uint64_t seed, uint64_t first_ray, uint64_t* hits, isxo_stats* stats,
+                              int nthreads);
+/* traceRays() against one detector (fluxAtObserver.C:169-228). */
+int isxo_trace_rays_detector(const isxo_config* cfg, const double* detector, double width, uint64_t n_rays,
+                             uint64_t seed, uint64_t first_ray, uint64_t* hit_count, isxo_stats* stats);
+
 /* Physical disc sweep (integratingSphereDetectorSweep.C:134-172). */
 int isxo_disc_sweep(const isxo_config* cfg, const double* centers_axes, int32_t n_disc, double radius,
                     double half_thick, uint64_t n_rays, uint64_t seed, uint64_t first_ray, uint64_t* hits,

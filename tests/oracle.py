@@ -80,6 +80,8 @@ def lib():
         L.isxo_fluxmap.argtypes = [P(Config), u64, u64, u64, P(u64), P(Stats), C.c_int]
         L.isxo_disc_sweep.argtypes = [P(Config), P(dbl), i32, dbl, dbl, u64, u64, u64, P(u64), P(Stats), C.c_int]
         L.isxo_exit_dz_hist.argtypes = [P(Config), u64, u64, u64, i32, P(u64), P(Stats), C.c_int]
+        L.isxo_fluxmap_per_position.argtypes = [P(Config), u64, i32, u64, u64, u64, u64, P(u64), P(Stats), C.c_int]
+        L.isxo_trace_rays_detector.argtypes = [P(Config), P(dbl), dbl, u64, u64, u64, P(u64), P(Stats)]
         L.isxo_max_threads.restype = C.c_int
         _lib = L
     return _lib
@@ -158,3 +160,24 @@ def exit_dz_hist(cfg, n, seed, nbins=100, first=0, nthreads=0):
     rc = lib().isxo_exit_dz_hist(C.byref(cfg), n, seed, first, nbins, _p(hist, C.c_uint64), C.byref(st), nthreads)
     assert rc == 0, rc
     return hist, st
+
+
+def fluxmap_per_position(cfg, rays_per_position, seed, fold=1, first_group=0, n_groups=None, first=0, nthreads=0):
+    nb = cfg.n_theta * cfg.n_phi
+    if n_groups is None:
+        n_groups = nb // fold - first_group
+    hits = np.zeros(nb, dtype=np.uint64)
+    st = Stats()
+    rc = lib().isxo_fluxmap_per_position(C.byref(cfg), rays_per_position, fold, first_group, n_groups, seed, first,
+                                         _p(hits, C.c_uint64), C.byref(st), nthreads)
+    assert rc == 0, rc
+    return hits.reshape(cfg.n_theta, cfg.n_phi), st
+
+
+def trace_rays_detector(cfg, detector, width, n, seed, first=0):
+    det = np.ascontiguousarray(detector, dtype=np.float64).reshape(6)
+    h = C.c_uint64(0)
+    st = Stats()
+    rc = lib().isxo_trace_rays_detector(C.byref(cfg), _p(det, C.c_double), width, n, seed, first, C.byref(h), C.byref(st))
+    assert rc == 0, rc
+    return int(h.value), st

@@ -247,3 +247,32 @@ def test_exit_dz_hist_bit_exact(isx, orc):
     oh, ost = orc.exit_dz_hist(mk(orc), 300000, 5, 100)
     assert np.array_equal(gh, oh)
     _census_equal(gst, ost)
+
+
+def test_per_position_maps_bit_exact(isx, orc):
+    """fluxAtObserverOptimize.C per-position semantics (fresh rays per detector) and the twofold variant."""
+    def mk(mod, nt, nph):
+        c = mod.default_config(); c.n_theta, c.n_phi = nt, nph
+        return c
+    for nt, nph, rpp, fold in [(12, 10, 700, 1), (12, 10, 700, 2), (180, 90, 3, 1), (5, 4, 5000, 2)]:
+        gh, gst = isx.fluxmap_per_position(mk(isx, nt, nph), rpp, 31337, fold, first_ray=10 ** 9)
+        oh, ost = orc.fluxmap_per_position(mk(orc, nt, nph), rpp, 31337, fold, first=10 ** 9)
+        assert np.array_equal(gh, oh), (nt, nph, rpp, fold)
+        _census_equal(gst, ost)
+        assert gst.launched == nt * nph * rpp // fold
+    # group sub-ranges add up to the full map (multi-GPU split of one map)
+    c = mk(isx, 12, 10)
+    full, _ = isx.fluxmap_per_position(c, 700, 5, 1)
+    a, _ = isx.fluxmap_per_position(c, 700, 5, 1, 0, 50)
+    b, _ = isx.fluxmap_per_position(c, 700, 5, 1, 50, 70)
+    assert np.array_equal(full, a + b)
+
+
+def test_trace_rays_single_detector(isx, orc):
+    """int traceRays(manager, n, exitPortZ, detector) for an arbitrary Detector (fluxAtObserver.C:169)."""
+    tab = isx.detector_table(isx.default_config())
+    for k, w in [(0, 40.0), (4321, 10.0), (16199, 40.0)]:
+        g, gst = isx.trace_rays_detector(isx.default_config(), tab[k], w, 60000, 2024, 17)
+        o, ost = orc.trace_rays_detector(orc.default_config(), tab[k], w, 60000, 2024, 17)
+        assert g == o
+        _census_equal(gst, ost)

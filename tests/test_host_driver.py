@@ -1,0 +1,155 @@
+"""Host driver (altair-raytracing_amd/host): the reference's macro entry points and file formats.
+
+CPU part: writers + naming, against the format of the reference's committed CSVs.
+GPU part (-m gpu): the CLI runs the entry points end to end; files are parsed with the same contract
+as flux_analysis.py:11-57 and compared with the C ABI called directly."""
+import os
+import re
+import subprocess
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HOST = os.path.join(ROOT, "altair-raytracing_amd", "host")
+CLI = os.path.join(HOST, "isx_macro")
+
+
+def parse_fluxmap(path):
+    """flux_analysis.py:11-57 — '#' lines are 'key: value' metadata (split on the first ':'), then a CSV."""
+    meta, rows, header = {}, [], None
+    with open(path) as f:
+        for line in f:
+            if line.startswith("#"):
+                if ":" in line:
+                    k, v = line[1:].strip().split(":", 1)
+                    meta[k.strip()] = v.strip()
+            elif header is None:
+                header = line.strip()
+            elif line.strip():
+                rows.append([float(x) for x in line.strip().split(",")])
+    return meta, header, np.array(rows)
+
+
+@pytest.fixture(scope="module")
+def cli():
+    if not os.path.exists(CLI):
+        subprocess.check_call(["make", "-s", "-C", HOST])
+    return CLI
+
+
+def test_writer_matches_reference_format(cli, golden, tmp_path):
+    out = tmp_path / "w.csv"
+    subprocess.check_call([cli, "--selftest-writer", str(out)])
+    lines = out.read_text().splitlines()
+    g = golden["csv_format_sample"]
+    # header: byte-identical to results_overnight_03_31.../fluxmap_50000rays_180x90_src-60_0_-75.csv:1-15
+    assert lines[:15] == g["header"]
+    assert len(lines) == 15 + 16200
+    # rows: %.6f,%.6f,%.6f, theta-major then phi
+    assert [l.split(",")[:2] for l in lines[15:18]] == [l.split(",")[:2] for l in g["first_rows"]]
+    assert all(re.fullmatch(r"\d+\.\d{6},\d+\.\d{6},\d\.\d{6}", l) for l in lines[15:])
+    assert lines[-1].startswith("89.750000,358.000000,")
+    meta, header, rows = parse_fluxmap(out)
+    assert header == "theta,phi,fraction" and rows.shape == (16200, 3)
+    assert list(meta)[:3] == ["Flux Map Data - Generated", "Number of rays per position", "Detector dimensions"]
+    assert meta["Exit port angle"] == "170 degrees" and meta["Source position (x,y,z)"] == "-60cm, 0cm, -75cm"
+    # synthetic map of the self-test: hits[k] = (k*7919) % 1000, n = 50000
+    k = np.arange(16200)
+    assert np.allclose(rows[:, 2], np.round(((k * 7919) % 1000) / 50000.0, 6), atol=5e-7)
+
+
+def test_unique_filename_never_overwrites(cli, tmp_path):
+    """getUniqueFilename (fluxAtObserverOptimize.C:336-387): stem_1.ext, stem_2.ext ..."""
+    base = tmp_path / "fluxmap_50000rays_180x90_src-60_0_-75.csv"
+    def uniq():
+        return subprocess.check_output([cli, "--unique", str(base)], text=True).strip()
+    assert uniq() == str(base)
+    base.write_text("x")
+    assert uniq() == str(tmp_path / "fluxmap_50000rays_180x90_src-60_0_-75_1.csv")
+    (tmp_path / "fluxmap_50000rays_180x90_src-60_0_-75_1.csv").write_text("x")
+    assert uniq() == str(tmp_path / "fluxmap_50000rays_180x90_src-60_0_-75_2.csv")
+    noext = tmp_path / "detector_sweep"
+    noext.write_text("x")
+    assert subprocess.check_output([cli, "--unique", str(noext)], text=True).strip() == str(noext) + "_1"
+
+
+def test_cli_fails_loudly_without_gpu(cli, tmp_path):
+    import altair_raytracing_amd as isx
+    if isx.load().isx_init(0) == 0:
+        isx.load().isx_shutdown()
+        pytest.skip("GPU present")
+    r = subprocess.run([cli, "makeIntegratingSphereNRays"], capture_output=True, text=True, cwd=tmp_path)
+    assert r.returncode != 0 and "no CPU fallback" in r.stderr
+
+
+# --------------------------------------------------------------------------------------------- GPU
+def _run(cli, cwd, entry, *args, rays=None, seed=None):
+    env = dict(os.environ, ISX_QUIET="1")
+    if rays is not None:
+        env["ISX_RAYS"] = str(rays)
+    if seed is not None:
+        env["ISX_SEED"] = str(seed)
+    r = subprocess.run([cli, entry, *args], cwd=cwd, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr
+    return r.stdout
+
+
+@pytest.mark.gpu
+def test_traceonce_entry_point(cli, isx, tmp_path):
+    """sweepDetectorTraceOnce(false, folder, 1, -60,0,-75, 5,0,0, 170) (fluxAtObserverFast.C:1068)."""
+    _run(cli, tmp_path, "fluxAtObserverFast::sweepDetectorTraceOnce", "folder=out", "srcZ=-75", "dirY=0", "thetaMax=170",
+         rays=100000, seed=4242)
+    path = tmp_path / "out" / "fluxmap_traceonce_100000rays_180x90_src-60_0_-75.csv"
+    meta, header, rows = parse_fluxmap(path)
+    assert header == "theta,phi,fraction" and rows.shape == (16200, 3)
+    assert meta["Number of rays"] == "100000" and meta["Method"].startswith("Trace-Once")
+    for k in ("Sweep completed at", "Total execution time", "Ray tracing time", "Detector sweep time", "Total rays exiting port"):
+        assert k in meta
+    hits, st = isx.fluxmap(isx.default_config(), 100000, 4242, 0)
+    assert meta["Total rays exiting port"] == f"{st.counted_below_z} out of 100000"
+    want = np.array([float(f"{h / 100000.0:.6f}") for h in hits.reshape(-1)])
+    assert np.array_equal(rows[:, 2], want)
+    assert np.allclose(rows[:90, 1], (np.arange(90) + .5) * 4) and rows[0, 0] == 0.25 and rows[-1, 0] == 89.75
+    # a second run never overwrites
+    _run(cli, tmp_path, "fluxAtObserverFast::sweepDetectorTraceOnce", "folder=out", "srcZ=-75", "dirY=0", rays=1000)
+    assert (tmp_path / "out" / "fluxmap_traceonce_1000rays_180x90_src-60_0_-75.csv").exists()
+    _run(cli, tmp_path, "fluxAtObserverFast::sweepDetectorTraceOnce", "folder=out", "srcZ=-75", "dirY=0", rays=1000)
+    assert (tmp_path / "out" / "fluxmap_traceonce_1000rays_180x90_src-60_0_-75_1.csv").exists()
+
+
+@pytest.mark.gpu
+def test_per_position_and_twofold_entry_points(cli, isx, tmp_path):
+    """sweepDetector (fluxAtObserverOptimize.C:433) and sweepDetectorTwofold (fluxAtObserverFast.C:518), 200 rays/position."""
+    _run(cli, tmp_path, "fluxAtObserverOptimize::sweepDetector", "folder=pp", "srcZ=-75", "dirY=0", "thetaMax=166", rays=200, seed=7)
+    meta, header, rows = parse_fluxmap(tmp_path / "pp" / "fluxmap_200rays_180x90_src-60_0_-75.csv")
+    c = isx.default_config(); c.theta_max_deg = 166.0
+    hits, st = isx.fluxmap_per_position(c, 200, 7, 1)
+    assert np.array_equal(rows[:, 2], np.array([float(f"{h / 200.0:.6f}") for h in hits.reshape(-1)]))
+    assert meta["Exit port angle"] == "166 degrees"
+    assert meta["Total ray hits"] == f"{int(hits.sum())} out of {200 * 16200}"
+    assert re.fullmatch(r"\d+\.\d{6} seconds", meta["Total execution time"])   # sticky fixed/6 format of the reference
+    _run(cli, tmp_path, "fluxAtObserverFast::sweepDetectorTwofold", "folder=tf", "srcZ=-75", "dirY=0", rays=200, seed=7)
+    meta, header, rows = parse_fluxmap(tmp_path / "tf" / "fluxmap_twofold_200rays_180x90_src-60_0_-75.csv")
+    hits, st = isx.fluxmap_per_position(isx.default_config(), 200, 7, 2)
+    # twofold row order: (theta, phi_j), (theta, phi_j+180), ...
+    assert list(rows[:4, 1]) == [2.0, 182.0, 6.0, 186.0]
+    order = np.array([[i * 90 + j, i * 90 + j + 45] for i in range(180) for j in range(45)]).reshape(-1)
+    assert np.array_equal(rows[:, 2], np.array([float(f"{h / 200.0:.6f}") for h in hits.reshape(-1)[order]]))
+
+
+@pytest.mark.gpu
+def test_small_macros(cli, isx, tmp_path):
+    out = _run(cli, tmp_path, "makeIntegratingSphereNRays", seed=3)
+    m = re.search(r"Flux of rays through the exit port: (\d+)", out)
+    assert m and 330 < int(m.group(1)) < 540          # 1000 rays, p ~ 0.43
+    _run(cli, tmp_path, "nonLambertianFlux::sweepDetector", rays=300, seed=3)
+    meta, header, rows = parse_fluxmap(tmp_path / "fluxmap_data.csv")
+    assert header == "theta,phi,fraction" and rows.shape == (900, 3) and meta == {}
+    _run(cli, tmp_path, "integratingSphereDetectorSweep", rays=2000, seed=3)
+    txt = (tmp_path / "detector_sweep3.txt").read_text().splitlines()
+    assert txt[0] == "Theta(deg)\tPhi(deg)\tHitFraction" and len(txt) == 1 + 181 * 2
+    assert txt[1].startswith("-45\t0\t") and txt[2].startswith("-45\t180\t") and txt[3].startswith("-44.5\t0\t")
+    _run(cli, tmp_path, "distributionSphereDetectorSweep", rays=20000, seed=3)
+    ad = np.loadtxt(tmp_path / "angular_dist.txt", comments="#")
+    assert ad.shape == (100, 2) and ad[0, 0] == pytest.approx(-0.99) and ad[50:, 1].sum() == 0
