@@ -10,7 +10,7 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
-LIB_PATH = os.path.join(CSRC, "libisx.so")
+LIB_PATH = os.environ.get("ISX_LIB_PATH") or os.path.join(CSRC, "libisx.so")  # ISX_LIB_PATH: tuning variants
 
 OK = 0
 ERR_NO_DEVICE = -1

@@ -35,8 +35,9 @@ struct State {
   unsigned long long* d_stats = nullptr;  // [8]
   // options
   int bin_mode = 1;
-  int blocks_per_cu = 2;
+  int blocks_per_cu = 1;   // 1024-thread blocks: 16 waves/CU, 4 per SIMD
   int grid_blocks = 0;  // 0 = auto
+  int sched_mask = 15, sched_min = 12;
   // timing of enqueued-but-not-collected launches
   std::vector<hipEvent_t> ev_pool;
   size_t ev_used = 0;
@@ -75,6 +76,8 @@ int prepare_geom(const isx_config* c, Geom* g) {
   g->limit = c->max_points;
   g->source_model = c->source_model;
   g->pad = 0;
+  g->sched_mask = S.sched_mask;
+  g->sched_min = S.sched_min;
   for (int k = 0; k < 3; ++k) g->src[k] = c->src[k];
   const double dx = c->dir[0], dy = c->dir[1], dz = c->dir[2];
   const double mag = std::sqrt(dx * dx + dy * dy + dz * dz);
@@ -214,7 +217,7 @@ int enqueue(int sink, const isx_config* c, uint64_t n, uint64_t seed, uint64_t f
     d.rho_d = c->det_diameter / 2;
     d.R = c->det_distance;
     d.table = S.d_table; d.rowtab = S.d_rowtab; d.coltab = S.d_coltab;
-    lds = (((size_t)d.nbins * 4 + 15) & ~(size_t)15) + (size_t)(4 * d.n_theta + 2 * d.n_phi) * 8 + 64;
+    lds = (((size_t)d.nbins * 4 + 15) & ~(size_t)15) + (size_t)(4 * d.n_theta + 2 * d.n_phi) * 8 + 64 + sizeof(Geom) + sizeof(DetGrid);
   } else if (sink == SINK_PERPOS) {
     if (!pp || pp->rays_per_group < 1 || (pp->fold != 1 && pp->fold != 2)) return ISX_ERR_BAD_ARG;
     if (pp->d_table) {  // caller-supplied detector list (traceRays with one Detector)
@@ -233,12 +236,12 @@ int enqueue(int sink, const isx_config* c, uint64_t n, uint64_t seed, uint64_t f
       d.half_w2 = (c->det_diameter / 2) * (c->det_diameter / 2);
     }
     d.map_first = pp->map_first; d.rays_per_group = pp->rays_per_group; d.fold = pp->fold;
-    lds = (((size_t)d.nbins * 4 + 15) & ~(size_t)15) + 64;
+    lds = (((size_t)d.nbins * 4 + 15) & ~(size_t)15) + 64 + sizeof(Geom) + sizeof(DetGrid);
   } else {
     if (nbins_override < 1 || nbins_override > 36000) return ISX_ERR_BAD_ARG;
     d.nbins = nbins_override;
     d.discs = d_discs; d.disc_r = disc_r; d.disc_h = disc_h;
-    lds = (((size_t)d.nbins * 4 + 15) & ~(size_t)15) + 64;
+    lds = (((size_t)d.nbins * 4 + 15) & ~(size_t)15) + 64 + sizeof(Geom) + sizeof(DetGrid);
   }
   if (n == 0) return ISX_OK;
   Work wk;
@@ -382,8 +385,10 @@ int isx_device_info(char* buf, int buflen) {
 
 int isx_set_option(const char* key, int64_t value) {
   if (!key) return ISX_ERR_BAD_ARG;
-  if (!std::strcmp(key, "bin_mode")) { S.bin_mode = value != 0; return ISX_OK; }
+  if (!std::strcmp(key, "bin_mode")) { if (value < 0 || value > 2) return ISX_ERR_BAD_ARG; S.bin_mode = (int)value; return ISX_OK; }
   if (!std::strcmp(key, "blocks_per_cu")) { if (value < 1 || value > 8) return ISX_ERR_BAD_ARG; S.blocks_per_cu = (int)value; return ISX_OK; }
+  if (!std::strcmp(key, "sched_mask")) { if (value < 0 || value > 255) return ISX_ERR_BAD_ARG; S.sched_mask = (int)value; return ISX_OK; }
+  if (!std::strcmp(key, "sched_min")) { if (value < 1 || value > 65) return ISX_ERR_BAD_ARG; S.sched_min = (int)value; return ISX_OK; }
   if (!std::strcmp(key, "grid_blocks")) { if (value < 0 || value > 65535) return ISX_ERR_BAD_ARG; S.grid_blocks = (int)value; return ISX_OK; }
   return ISX_ERR_BAD_ARG;
 }

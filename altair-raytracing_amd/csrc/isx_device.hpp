@@ -29,7 +29,22 @@ struct Geom {
   double brdf_theta_scale;  // rough * M_PI / 6   (nonLambertianFlux.C:178)
   double brdf_spec;         // specular/(specular+diffuse) (:157-159)
   int lambertian, limit, source_model, pad;
+  int sched_mask, sched_min;  // generic-search batching: flush when (iter & mask) == mask or >= min lanes parked
 };
+
+// The handful of constants the hot loop needs; kept in SGPRs.  Everything else of Geom is read
+// on demand from an LDS copy (a `const volatile Geom&`), so it never occupies scalar registers
+// across the loop (SGPR spills were >10 % of the issued instructions before this split).
+struct Hot {
+  double rin2, zcut_in, ninv_rin, rho;
+  int lambertian, limit, source_model;
+};
+__device__ __forceinline__ Hot make_hot(const Geom& g) {
+  Hot h;
+  h.rin2 = g.rin2; h.zcut_in = g.zcut_in; h.ninv_rin = g.ninv_rin; h.rho = g.rho;
+  h.lambertian = g.lambertian; h.limit = g.limit; h.source_model = g.source_model;
+  return h;
+}
 
 __device__ __forceinline__ double dot3(const V3& a, const V3& b) { return fma(a.x, b.x, fma(a.y, b.y, a.z * b.z)); }
 __device__ __forceinline__ V3 axpy(double t, const V3& v, const V3& p) {
@@ -57,7 +72,8 @@ __device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t
 __device__ __forceinline__ void draw_block(uint64_t seed, uint64_t ray, uint32_t block, uint32_t stream, uint32_t w[4]) {
   philox4x32_10((uint32_t)ray, (uint32_t)(ray >> 32), block, stream, (uint32_t)seed, (uint32_t)(seed >> 32), w);
 }
-__device__ __forceinline__ double u01(uint32_t w) { return ((double)w + 0.5) * 0x1.0p-32; }
+// (w + 0.5) * 2^-32, exact; written as one fma (w*2^-32 + 2^-33 is the same exact value)
+__device__ __forceinline__ double u01(uint32_t w) { return fma((double)w, 0x1.0p-32, 0x1.0p-33); }
 
 // ---------------------------------------------------------------- elementary functions
 __device__ __forceinline__ double kern_sin(double x) {
@@ -134,7 +150,11 @@ __device__ __forceinline__ void consider(double t, const V3& q, int kind, double
 }
 
 // Generic nearest boundary (all surfaces).  Rare path: port transits, rim, outer sphere, box.
-__device__ inline int next_hit_generic(const Geom& g, const V3 p, const V3 v, const int on, V3& q_out) {
+template <class G>
+__device__ inline int next_hit_generic(const G& gg, const V3 p, const V3 v, const int on, V3& q_out) {
+  // one read of each constant (gg may be a volatile LDS copy)
+  struct { double rin2, rout2, zcut_in, zcut_out, k2, H; } g;
+  g.rin2 = gg.rin2; g.rout2 = gg.rout2; g.zcut_in = gg.zcut_in; g.zcut_out = gg.zcut_out; g.k2 = gg.k2; g.H = gg.H;
   const double b = dot3(p, v);
   const double pp = dot3(p, p);
   double best = __builtin_inf();
@@ -210,23 +230,27 @@ __device__ inline int next_hit_generic(const Geom& g, const V3 p, const V3 v, co
   return K_BOX;
 }
 
-// Hot path = Rule S1 of the spec: inside/on the inner ball heading inward, far root on the
-// mirror patch.  Anything else falls to the generic search (which re-derives the same numbers).
-__device__ __forceinline__ int next_hit(const Geom& g, const V3& p, const V3& v, const int on, V3& q_out) {
+// Rule S1 alone: returns true (and q) if the far root of the inner sphere is the hit.
+__device__ __forceinline__ bool next_hit_s1(const Hot& g, const V3& p, const V3& v, const int on, V3& q_out) {
   const double b = dot3(p, v);
   const double pp = dot3(p, p);
   const double ci = pp - g.rin2;
   const double di = fma(b, b, -ci);
   const bool s1 = (di >= 0.0) && ((on == K_INNER && b < 0.0) || (on == K_NONE && ci < 0.0));
-  if (s1) {
-    const double s = sqrt(di);
-    const double tf = s - b;
-    const V3 q = axpy(tf, v, p);
-    if (q.z >= g.zcut_in) { q_out = q; return K_INNER; }
-  }
-  return next_hit_generic(g, p, v, on, q_out);
+  if (!s1) return false;
+  const double s = sqrt(di);
+  const double tf = s - b;
+  const V3 q = axpy(tf, v, p);
+  if (q.z >= g.zcut_in) { q_out = q; return true; }
+  return false;
 }
 
+// Rule S1 first (hot path); anything else falls to the generic search (which re-derives the same numbers).
+template <class G>
+__device__ __forceinline__ int next_hit(const Hot& h, const G& g, const V3& p, const V3& v, const int on, V3& q_out) {
+  if (next_hit_s1(h, p, v, on, q_out)) return K_INNER;
+  return next_hit_generic(g, p, v, on, q_out);
+}
 // ---------------------------------------------------------------- surface interaction
 __device__ __forceinline__ void onb(const V3& n, V3& t1, V3& t2) {
   const double sg = copysign(1.0, n.z);
@@ -240,12 +264,14 @@ __device__ __forceinline__ void onb(const V3& n, V3& t1, V3& t2) {
   t2.z = -n.y;
 }
 
-__device__ __forceinline__ V3 surface_normal(const Geom& g, int kind, const V3& q) {
+template <class G>
+__device__ __forceinline__ V3 surface_normal(const Hot& h, const G& g, int kind, const V3& q) {
   V3 n;
   if (kind == K_INNER) {
-    n.x = q.x * g.ninv_rin; n.y = q.y * g.ninv_rin; n.z = q.z * g.ninv_rin;
+    n.x = q.x * h.ninv_rin; n.y = q.y * h.ninv_rin; n.z = q.z * h.ninv_rin;
   } else if (kind == K_OUTER) {
-    n.x = q.x * g.inv_rout; n.y = q.y * g.inv_rout; n.z = q.z * g.inv_rout;
+    const double ir = g.inv_rout;
+    n.x = q.x * ir; n.y = q.y * ir; n.z = q.z * ir;
   } else {
     const double gz = g.k2 * q.z;
     const double nn = sqrt(fma(q.x, q.x, fma(q.y, q.y, gz * gz)));
@@ -255,14 +281,15 @@ __device__ __forceinline__ V3 surface_normal(const Geom& g, int kind, const V3& 
 }
 
 // returns false if absorbed; otherwise v is the re-emitted direction
-__device__ __forceinline__ bool interact(const Geom& g, int kind, const V3& q, V3& v, uint64_t seed, uint64_t ray,
-                                         uint32_t j, uint32_t stream) {
+template <class G>
+__device__ __forceinline__ bool interact(const Hot& h, const G& g, int kind, const V3& q, V3& v, uint64_t seed,
+                                         uint64_t ray, uint32_t j, uint32_t stream) {
   uint32_t wl[4];
   draw_block(seed, ray, 2u * j, stream, wl);
-  if (!(u01(wl[2]) < g.rho)) return false;
-  const V3 n = surface_normal(g, kind, q);
+  if (!(u01(wl[2]) < h.rho)) return false;
+  const V3 n = surface_normal(h, g, kind, q);
   V3 w;
-  if (g.lambertian) {
+  if (h.lambertian) {
     // cosine-law re-emission about the geometric normal; roughness does not act on a
     // Lambertian border
     V3 A, Bv;
@@ -278,7 +305,8 @@ __device__ __forceinline__ bool interact(const Geom& g, int kind, const V3& q, V
     w.z = fma(x, A.z, fma(y, Bv.z, z * n.z));
   } else {
     V3 M = n;
-    if (g.sigma != 0.0) {
+    const double sigma = g.sigma;
+    if (sigma != 0.0) {
       V3 A, Bv;
       onb(n, A, Bv);
       uint32_t wr[4];
@@ -287,7 +315,7 @@ __device__ __forceinline__ bool interact(const Geom& g, int kind, const V3& q, V
       const double R = sqrt(-2.0 * log_pos(u1));
       double s2, c2;
       sincos2pi(u2, s2, c2);
-      const double delta = g.sigma * (R * c2);
+      const double delta = sigma * (R * c2);
       double sd, cd, sp, cp;
       sincos_cw(delta, sd, cd);
       sincos2pi(u3, sp, cp);
@@ -336,7 +364,8 @@ __device__ __forceinline__ V3 tv_setmag1(const V3& a) {
   return r;
 }
 
-__device__ inline V3 brdf_sample(const Geom& g, const V3 normal, const V3 incident, uint64_t seed, uint64_t ray) {
+template <class G>
+__device__ inline V3 brdf_sample(const G& g, const V3 normal, const V3 incident, uint64_t seed, uint64_t ray) {
   uint32_t w[4];
   draw_block(seed, ray, 0u, 1u, w);
   if (u01(w[0]) < g.brdf_spec) {

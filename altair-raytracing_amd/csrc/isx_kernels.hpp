@@ -45,7 +45,18 @@ struct Work {
   unsigned long long* stats;  // [8]: launched, exited, counted, absorbed, suspended, increments, wall_hits
 };
 
-constexpr int kBlock = 512;
+#ifndef ISX_BLOCK
+#define ISX_BLOCK 1024
+#endif
+#ifndef ISX_WAVES_PER_EU
+#define ISX_WAVES_PER_EU 0   // 0: let the compiler choose
+#endif
+constexpr int kBlock = ISX_BLOCK;
+#if ISX_WAVES_PER_EU > 0
+#define ISX_KERNEL_ATTR __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(ISX_WAVES_PER_EU, ISX_WAVES_PER_EU)))
+#else
+#define ISX_KERNEL_ATTR __launch_bounds__(kBlock)
+#endif
 constexpr int kWavesPerBlock = kBlock / 64;
 
 __device__ __forceinline__ double readlane_f64(double x, int lane) {
@@ -70,91 +81,94 @@ __device__ __forceinline__ float atan2_cull(float y, float x) {
   return r;
 }
 
-// Fast sign test of r2 - (w/2)^2 without the division:  r2*dot^2 = dd*dot^2 - 2*num*dot*dv + num^2.
-// Returns +1 hit, 0 miss, -1 "too close to call" (caller runs the exact reference-order test).
-__device__ __forceinline__ int classify(const DetGrid& d, const double* __restrict__ rowt, const double* __restrict__ colt,
-                                        int i, int j, const V3& P, const V3& V) {
-  const double S = rowt[4 * i + 0], Cc = rowt[4 * i + 1], z = rowt[4 * i + 2], A = rowt[4 * i + 3];
-  const double cph = colt[2 * j + 0], sph = colt[2 * j + 1];
-  const double nx = -(S * sph), ny = S * cph, nz = -Cc;
-  const double dx = P.x - A * cph, dy = P.y - A * sph, dz = P.z - z;
-  const double dot = fma(V.x, nx, fma(V.y, ny, V.z * nz));
-  const double num = fma(dx, nx, fma(dy, ny, dz * nz));
-  const double dv = fma(dx, V.x, fma(dy, V.y, dz * V.z));
-  const double dd = fma(dx, dx, fma(dy, dy, dz * dz));
-  const double dot2 = dot * dot;
-  const double t1 = dd * dot2;
-  const double t2 = (2.0 * num) * (dot * dv);
-  const double t3 = num * num;
-  const double rhs = d.half_w2 * dot2;
-  const double diff = (t1 - t2) + (t3 - rhs);
-  const double band = 1e-9 * (fabs(t1) + fabs(t2) + t3 + rhs);
-  if (fabs(dot) < 1e-4 || fabs(diff) <= band) return -1;
-  return diff < 0.0 ? 1 : 0;
-}
-
 // ------------------------------------------------------------------ binning of one exit line by a whole wave
 // P,V are wave-uniform.  Returns the number of bins incremented (wave-uniform).
-__device__ __forceinline__ uint32_t bin_brute(const DetGrid& d, uint32_t* __restrict__ hist, const V3& P, const V3& V,
+template <class DG>
+__device__ __forceinline__ uint32_t bin_brute(const DG& dd, uint32_t* __restrict__ hist, const V3& P, const V3& V,
                                               int lane) {
+  const int nbins = dd.nbins;
+  const double* table = dd.table;
+  const double half_w2 = dd.half_w2;
   uint32_t inc = 0;
-  for (int b0 = 0; b0 < d.nbins; b0 += 64) {
+  for (int b0 = 0; b0 < nbins; b0 += 64) {
     const int b = b0 + lane;
     bool hit = false;
-    if (b < d.nbins) hit = check_intersection(d.table + 6 * (size_t)b, d.half_w2, P, V);
+    if (b < nbins) hit = check_intersection(table + 6 * (size_t)b, half_w2, P, V);
     if (hit) atomicAdd(&hist[b], 1u);
     inc += (uint32_t)__popcll(__ballot(hit));
   }
   return inc;
 }
 
-__device__ inline uint32_t bin_culled(const DetGrid& d, uint32_t* __restrict__ hist,
-                                            const double* __restrict__ rowt, const double* __restrict__ colt,
-                                            const V3 P, const V3 V, int lane) {
-  // ---- line vs the sphere of detector centres S(O,R), O=(0,0,portz): all wave-uniform
-  V3 w; w.x = P.x; w.y = P.y; w.z = P.z - d.portz;
-  const double wv = dot3(w, V);
-  V3 h; h.x = fma(-wv, V.x, w.x); h.y = fma(-wv, V.y, w.y); h.z = fma(-wv, V.z, w.z);
-  const double dO2 = dot3(h, h);
-  const double R2 = d.R * d.R;
-  const double dO = sqrt(dO2);
-  const double a1 = dO + d.rho_d;
-  if (!(a1 < 0.999 * d.R)) return bin_brute(d, hist, P, V, lane);
-  const double sF = sqrt(R2 - dO2);
-  const double smin = sqrt(R2 - a1 * a1);
-  const double a0 = fmax(0.0, dO - d.rho_d);
-  const double smax = sqrt(R2 - a0 * a0);
-  const double ext = fmax(sF - smin, smax - sF);
+// Culled binning, "lane = detector row": every lane owns one theta-row of the cap around a piercing
+// point, derives the row's phi-window (cull, f32) and the row's affine coefficients of the hit
+// polynomial (f64), then walks its window column by column.  For fixed ray (P,V) and row i
+//   dot = V.n, num = (P-c).n, dv = (P-c).V, dd = |P-c|^2
+// are all of the form k0 + k1*cos(phi_j) + k2*sin(phi_j)  (c = (A c, A s, z), n = (-S s, S c, -C)),
+// so one candidate costs 8 fma + the sign test of  dd*dot^2 - 2*num*dot*dv + num^2 - (w/2)^2*dot^2.
+template <class DG>
+__device__ inline uint32_t bin_culled(const DG& dd, uint32_t* __restrict__ hist,
+                                      const double* __restrict__ rowt, const double* __restrict__ colt,
+                                      const V3 P, const V3 V, int lane) {
+  // one read of each constant (dd is a volatile LDS copy: nothing of it lives in SGPRs across the trace loop)
+  struct { int n_theta, n_phi; double half_w2, rho_d, R, portz; const double* table; } d;
+  d.n_theta = dd.n_theta; d.n_phi = dd.n_phi; d.half_w2 = dd.half_w2; d.rho_d = dd.rho_d; d.R = dd.R;
+  d.portz = dd.portz; d.table = dd.table;
+  // ---- line vs the sphere of detector centres S(O,R), O=(0,0,portz): wave-uniform, f32 is enough (cull only)
+  const double wz = P.z - d.portz;
+  const double wv = fma(P.x, V.x, fma(P.y, V.y, wz * V.z));
+  const double hx = fma(-wv, V.x, P.x), hy = fma(-wv, V.y, P.y), hz = fma(-wv, V.z, wz);
+  const float dO2 = (float)fma(hx, hx, fma(hy, hy, hz * hz));
+  const float Rf = (float)d.R, rho = (float)d.rho_d;
+  const float R2 = Rf * Rf;
+  const float dO = sqrtf(dO2);
+  const float a1 = dO + rho;
+  if (!(a1 < 0.999f * Rf)) return bin_brute(dd, hist, P, V, lane);
+  const float sF = sqrtf(R2 - dO2);
+  const float smin = sqrtf(R2 - a1 * a1);
+  const float a0 = fmaxf(0.f, dO - rho);
+  const float smax = sqrtf(R2 - a0 * a0);
+  const float ext = fmaxf(sF - smin, smax - sF);
   // every detector centre within rho_d of the line lies within chord ch of a piercing point
-  const double ch2 = fma(ext, ext, d.rho_d * d.rho_d) * (1.0 + 1e-6) + 1e-6;
-  if (!(4.0 * (R2 - dO2) > 4.04 * ch2)) return bin_brute(d, hist, P, V, lane);
-  const double ch = sqrt(ch2);
+  const float ch2 = fmaf(ext, ext, rho * rho) * 1.0001f + 1e-3f;
+  if (!(4.0f * (R2 - dO2) > 4.04f * ch2)) return bin_brute(dd, hist, P, V, lane);
+  const float ch = sqrtf(ch2);
   const float dphi = 6.28318530718f / (float)d.n_phi;
   const float inv_dphi = 1.0f / dphi;
+  const float dth = 1.57079632679f / (float)d.n_theta;   // row spacing in theta
+  const float omega = (ch / Rf) * 1.01f + 2e-3f;          // cap angular radius 2*asin(ch/2R), conservatively
   uint32_t inc = 0;
 #pragma unroll 1
   for (int side = 0; side < 2; ++side) {
-    const double s = side == 0 ? (sF - wv) : (-sF - wv);
-    const V3 F = axpy(s, V, P);
-    if (F.z - ch > d.portz) continue;  // cap entirely above every detector row
-    const double AF2 = fma(F.x, F.x, F.y * F.y);
-    const double AF = sqrt(AF2);
-    float phiF = atan2_cull((float)F.y, (float)F.x);
+    const double s = side == 0 ? ((double)sF - wv) : (-(double)sF - wv);
+    const float Fx = (float)fma(s, V.x, P.x), Fy = (float)fma(s, V.y, P.y), Fz = (float)fma(s, V.z, P.z);
+    if (Fz - ch > (float)d.portz) continue;  // cap entirely above every detector row
+    const float AF2 = fmaf(Fx, Fx, Fy * Fy);
+    const float AF = sqrtf(AF2);
+    float phiF = atan2_cull(Fy, Fx);
     if (phiF < 0.f) phiF += 6.28318530718f;
     const float jf = phiF * inv_dphi - 0.5f;
+    // rows that can intersect the cap: |theta_i - theta_F| <= omega, theta measured from -z about O
+    const float thF = atan2_cull(AF, (float)d.portz - Fz);
+    int ilo = (int)floorf((thF - omega) / dth - 0.5f), ihi = (int)ceilf((thF + omega) / dth - 0.5f);
+    ilo = max(ilo, 0);
+    ihi = min(ihi, d.n_theta - 1);
 #pragma unroll 1
-    for (int i0 = 0; i0 < d.n_theta; i0 += 64) {
+    for (int i0 = ilo; i0 <= ihi; i0 += 64) {
       const int i = i0 + lane;
       int jlo = 0, cnt = 0;
-      if (i < d.n_theta) {
-        const double zi = rowt[4 * i + 2], Ai = rowt[4 * i + 3];
-        const double dzi = zi - F.z;
-        const double num = fma(Ai, Ai, fma(dzi, dzi, AF2)) - ch2;
-        const double den = 2.0 * Ai * AF;
-        if (num <= -den) { jlo = 0; cnt = d.n_phi; }
-        else if (num > den) { cnt = 0; }
+      double a0c = 0, a1c = 0, a2c = 0, b0c = 0, b1c = 0, b2c = 0, e0c = 0, e1c = 0, e2c = 0, f0c = 0, f1c = 0, f2c = 0;
+      if (i <= ihi) {
+        const double Sd = rowt[4 * i + 0], Cd = rowt[4 * i + 1], zd = rowt[4 * i + 2], Ad = rowt[4 * i + 3];
+        const float zi = (float)zd, Ai = (float)Ad;
+        const float dzi = zi - Fz;
+        const float num = fmaf(Ai, Ai, fmaf(dzi, dzi, AF2)) - ch2;
+        const float den = 2.0f * Ai * AF;
+        const float slack = 2e-5f * (fmaf(Ai, Ai, AF2) + ch2);  // f32 rounding of num
+        if (num - slack <= -den) { jlo = 0; cnt = d.n_phi; }
+        else if (num - slack > den) { cnt = 0; }
         else {
-          float K = (float)(num / den) - 1e-5f;
+          float K = (num - slack) / den - 1e-5f;
           K = fminf(1.f, fmaxf(-1.f, K));
           const float dl = atan2_cull(sqrtf(fmaxf(0.f, 1.f - K * K)), K) + 1e-3f;
           const float hw = dl * inv_dphi;
@@ -163,37 +177,46 @@ __device__ inline uint32_t bin_culled(const DetGrid& d, uint32_t* __restrict__ h
           if (cnt < 0) cnt = 0;
           if (cnt >= d.n_phi) { jlo = 0; cnt = d.n_phi; }
         }
+        if (cnt > 0) {
+          const double pz = P.z - zd;
+          a0c = -(Cd * V.z); a1c = Sd * V.y; a2c = -(Sd * V.x);
+          b0c = -(Cd * pz);  b1c = Sd * P.y; b2c = -(Sd * P.x);
+          e0c = fma(P.x, V.x, fma(P.y, V.y, pz * V.z)); e1c = -(Ad * V.x); e2c = -(Ad * V.y);
+          f0c = fma(P.x, P.x, fma(P.y, P.y, fma(Ad, Ad, pz * pz))); f1c = -2.0 * (Ad * P.x); f2c = -2.0 * (Ad * P.y);
+          if (jlo < 0) jlo += d.n_phi;   // keep the running column in [0, n_phi)
+        }
       }
-      const unsigned long long m = __ballot(cnt > 0);
-      if (m == 0ull) continue;
-      const int first = __builtin_ctzll(m), last = 63 - __builtin_clzll(m);
       int gmax = cnt;
 #pragma unroll
       for (int o = 32; o > 0; o >>= 1) gmax = max(gmax, __shfl_xor(gmax, o));
-      const int gsh = gmax <= 8 ? 3 : (gmax <= 16 ? 4 : (gmax <= 32 ? 5 : 6));
-      const int G = 1 << gsh, rpi = 64 >> gsh;
-      for (int c0 = 0; c0 < gmax; c0 += 64) {
-        for (int r0 = first; r0 <= last; r0 += rpi) {
-          const int rl = r0 + (lane >> gsh);
-          const int k = (lane & (G - 1)) + c0;
-          const int jlo_r = __shfl(jlo, rl & 63), cnt_r = __shfl(cnt, rl & 63);
-          const bool act = (rl <= last) && (k < cnt_r);
-          bool hit = false;
-          int bin = 0;
-          if (act) {
-            const int ii = i0 + rl;
-            int j = jlo_r + k;
-            if (j < 0) j += d.n_phi;
-            if (j >= d.n_phi) j -= d.n_phi;
-            if (j >= d.n_phi) j -= d.n_phi;
-            bin = ii * d.n_phi + j;
-            const int c = classify(d, rowt, colt, ii, j, P, V);
-            hit = c > 0;
-            if (c < 0) hit = check_intersection(d.table + 6 * (size_t)bin, d.half_w2, P, V);
-          }
-          if (hit) atomicAdd(&hist[bin], 1u);
-          inc += (uint32_t)__popcll(__ballot(hit));
+      int j = jlo;
+      const int rowbase = i * d.n_phi;
+      for (int k = 0; k < gmax; ++k) {
+        const bool act = k < cnt;
+        bool hit = false;
+        int bin = 0;
+        if (act) {
+          if (j >= d.n_phi) j -= d.n_phi;
+          bin = rowbase + j;
+          const double cph = colt[2 * j + 0], sph = colt[2 * j + 1];
+          const double dot = fma(a1c, cph, fma(a2c, sph, a0c));
+          const double num = fma(b1c, cph, fma(b2c, sph, b0c));
+          const double dv = fma(e1c, cph, fma(e2c, sph, e0c));
+          const double dd = fma(f1c, cph, fma(f2c, sph, f0c));
+          const double dot2 = dot * dot;
+          const double t1 = dd * dot2;
+          const double t2 = (2.0 * num) * (dot * dv);
+          const double t3 = num * num;
+          const double rhs = d.half_w2 * dot2;
+          const double diff = (t1 - t2) + (t3 - rhs);
+          const double band = 1e-9 * (fabs(t1) + fabs(t2) + t3 + rhs);
+          hit = diff < 0.0;
+          if (fabs(dot) < 1e-4 || fabs(diff) <= band)  // too close to call: exact reference-order test
+            hit = check_intersection(d.table + 6 * (size_t)bin, d.half_w2, P, V);
+          j++;
         }
+        if (hit) atomicAdd(&hist[bin], 1u);
+        inc += (uint32_t)__popcll(__ballot(hit));
       }
     }
   }
@@ -210,32 +233,40 @@ struct Ray {
   int phase;        // 0 primary, 2 scattered (source_model 1)
 };
 
-__device__ __forceinline__ void ray_start(const Geom& g, Ray& r, uint64_t id) {
+template <class G>
+__device__ __forceinline__ void ray_start(const G& g, Ray& r, uint64_t id) {
   r.id = id; r.j = 0; r.npts = 1; r.on = K_NONE; r.phase = 0;
   r.p.x = g.src[0]; r.p.y = g.src[1]; r.p.z = g.src[2];
   r.v.x = g.dir0[0]; r.v.y = g.dir0[1]; r.v.z = g.dir0[2];
 }
 
-// One step: next boundary + interaction.  Returns 0 while running, else the end status of
-// the CURRENT trace.
-template <bool KEEP_PREV = false>
-__device__ __forceinline__ int ray_step(const Geom& g, Ray& r, uint64_t seed) {
-  V3 q;
-  const int kind = next_hit(g, r.p, r.v, r.on, q);
+// Second half of a step, once the boundary (kind, q) is known: advance, interact.
+// Returns 0 while running, else the end status of the CURRENT trace.
+template <bool KEEP_PREV, class G>
+__device__ __forceinline__ int ray_arrive(const Hot& h, const G& g, Ray& r, uint64_t seed, int kind, const V3& q) {
   if (KEEP_PREV) r.prev = r.p;
   r.p = q;
   r.npts++;
   if (kind == K_BOX) { r.on = K_BOX; return ST_EXITED; }
   r.on = kind;
-  const bool alive = interact(g, kind, q, r.v, seed, r.id, r.j, (uint32_t)r.phase);
+  const bool alive = interact(h, g, kind, q, r.v, seed, r.id, r.j, (uint32_t)r.phase);
   r.j++;
   if (!alive) return ST_ABSORBED;
-  if (r.npts > g.limit) return ST_SUSPENDED;
+  if (r.npts > h.limit) return ST_SUSPENDED;
   return 0;
 }
 
+// One full step: next boundary + interaction.
+template <bool KEEP_PREV, class G>
+__device__ __forceinline__ int ray_step(const Hot& h, const G& g, Ray& r, uint64_t seed) {
+  V3 q;
+  const int kind = next_hit(h, g, r.p, r.v, r.on, q);
+  return ray_arrive<KEEP_PREV>(h, g, r, seed, kind, q);
+}
+
 // nonLambertianFlux.C:253-268: restart from the primary's last point along a BRDF-sampled direction
-__device__ __forceinline__ void ray_rescatter(const Geom& g, Ray& r, uint64_t seed) {
+template <class G>
+__device__ __forceinline__ void ray_rescatter(const G& g, Ray& r, uint64_t seed) {
   V3 d0; d0.x = g.dir0[0]; d0.y = g.dir0[1]; d0.z = g.dir0[2];
   const V3 normal = tv_unit(r.p);
   const V3 nd = brdf_sample(g, normal, d0, seed, r.id);
@@ -275,8 +306,11 @@ __device__ __forceinline__ bool segment_hits_tube(const V3& p, const V3& v, doub
   return t0 <= t1;
 }
 
-__device__ __forceinline__ uint32_t bin_discs(const DetGrid& d, uint32_t* __restrict__ hist, const V3& P0, const V3& P1,
+template <class DG>
+__device__ __forceinline__ uint32_t bin_discs(const DG& dd, uint32_t* __restrict__ hist, const V3& P0, const V3& P1,
                                               const V3& V, int lane) {
+  struct { int nbins; const double* discs; double disc_r, disc_h; } d;
+  d.nbins = dd.nbins; d.discs = dd.discs; d.disc_r = dd.disc_r; d.disc_h = dd.disc_h;
   V3 dl; dl.x = P1.x - P0.x; dl.y = P1.y - P0.y; dl.z = P1.z - P0.z;
   const double tmax = dot3(dl, V);
   uint32_t inc = 0;
@@ -295,35 +329,55 @@ __device__ __forceinline__ uint32_t bin_discs(const DetGrid& d, uint32_t* __rest
 //   SINK_DZ  : histogram of the exit direction's z component (distributionSphereDetectorSweep.C:54,91)
 //   SINK_DISC: physical disc sweep (integratingSphereDetectorSweep.C)
 template <int SINK>
-__device__ __forceinline__ void persistent_body(const Geom& g, const DetGrid& d, const Work& wk) {
+__device__ __forceinline__ void persistent_body(const Geom& g_arg, const DetGrid& d_arg, const Work& wk) {
   extern __shared__ __align__(16) unsigned char smem[];
   uint32_t* hist = reinterpret_cast<uint32_t*>(smem);
-  const size_t off_row = ((size_t)d.nbins * 4 + 15) & ~(size_t)15;
+  const int nbins = d_arg.nbins;
+  const size_t off_row = ((size_t)nbins * 4 + 15) & ~(size_t)15;
   double* rowt = reinterpret_cast<double*>(smem + off_row);
-  double* colt = rowt + (SINK == SINK_FLUX ? 4 * d.n_theta : 0);
-  unsigned long long* sstat = reinterpret_cast<unsigned long long*>(colt + (SINK == SINK_FLUX ? 2 * d.n_phi : 0));
+  double* colt = rowt + (SINK == SINK_FLUX ? 4 * d_arg.n_theta : 0);
+  unsigned long long* sstat = reinterpret_cast<unsigned long long*>(colt + (SINK == SINK_FLUX ? 2 * d_arg.n_phi : 0));
+  // LDS copies of the parameter blocks: rare paths read them on demand (volatile), the hot loop
+  // keeps only `Hot` + a few scalars in SGPRs.
+  Geom* g_lds = reinterpret_cast<Geom*>(sstat + 8);
+  DetGrid* d_lds = reinterpret_cast<DetGrid*>(g_lds + 1);
 
   const int tid = threadIdx.x;
-  for (int b = tid; b < d.nbins; b += kBlock) hist[b] = 0u;
+  for (int b = tid; b < nbins; b += kBlock) hist[b] = 0u;
   if (SINK == SINK_FLUX) {
-    for (int b = tid; b < 4 * d.n_theta; b += kBlock) rowt[b] = d.rowtab[b];
-    for (int b = tid; b < 2 * d.n_phi; b += kBlock) colt[b] = d.coltab[b];
+    for (int b = tid; b < 4 * d_arg.n_theta; b += kBlock) rowt[b] = d_arg.rowtab[b];
+    for (int b = tid; b < 2 * d_arg.n_phi; b += kBlock) colt[b] = d_arg.coltab[b];
   }
   if (tid < 8) sstat[tid] = 0ull;
+  if (tid == 64) *g_lds = g_arg;
+  if (tid == 128) *d_lds = d_arg;
   __syncthreads();
+  typedef __attribute__((address_space(3))) Geom LdsGeom;        // explicit LDS address space: ds_read, not flat_load
+  typedef __attribute__((address_space(3))) DetGrid LdsDetGrid;
+  const volatile LdsGeom& g = *(const volatile LdsGeom*)g_lds;
+  const volatile LdsDetGrid& d = *(const volatile LdsDetGrid*)d_lds;
+  const Hot h = make_hot(g_arg);
+  const double portz = d_arg.portz;
+  const int bin_mode = d_arg.bin_mode;
+  const int sched_mask = g_arg.sched_mask, sched_min = g_arg.sched_min;
+  const uint64_t seed = wk.seed;
 
   const int lane = tid & 63;
-  const uint64_t wave = (uint64_t)blockIdx.x * kWavesPerBlock + (uint64_t)(tid >> 6);
-  const uint64_t nwaves = (uint64_t)gridDim.x * kWavesPerBlock;
-  // contiguous ray range of this wave: [next,end)
-  const uint64_t q = wk.n / nwaves, rem = wk.n % nwaves;
-  uint64_t next = wk.first + wave * q + (wave < rem ? wave : rem);
-  const uint64_t end = next + q + (wave < rem ? 1 : 0);
+  uint64_t next, end;
+  {
+    const uint64_t wave = (uint64_t)blockIdx.x * kWavesPerBlock + (uint64_t)(tid >> 6);
+    const uint64_t nwaves = (uint64_t)gridDim.x * kWavesPerBlock;
+    // contiguous ray range of this wave: [next,end)
+    const uint64_t q = wk.n / nwaves, rem = wk.n % nwaves;
+    next = wk.first + wave * q + (wave < rem ? wave : rem);
+    end = next + q + (wave < rem ? 1 : 0);
+  }
 
   Ray r;
   ray_start(g, r, 0);
   r.prev = r.p;
-  bool alive = false;
+  bool alive = false, parked = false;
+  uint32_t iter = 0;
   uint32_t n_launched = 0, n_exited = 0, n_counted = 0, n_abs = 0, n_susp = 0;
   unsigned long long n_wall = 0, n_inc = 0;
 
@@ -342,25 +396,49 @@ __device__ __forceinline__ void persistent_body(const Geom& g, const DetGrid& d,
       }
       if (__ballot(alive) == 0ull) break;
     }
-    // ---- one boundary + interaction per live lane
+    // ---- one boundary + interaction per live lane.  The hot boundary search (rule S1) runs every
+    // iteration; the generic search (port transits, rim, box: ~0.75 % of lane-steps but ~40 % of
+    // wave-iterations if run eagerly) is BATCHED: a lane that needs it parks until several lanes
+    // need it, every 4th iteration, or nothing else is left to do.  Scheduling only - a ray's
+    // history never depends on it.
     bool bin_me = false;
-    if (alive) {
-      int st = ray_step<SINK == SINK_DISC>(g, r, wk.seed);
-      if (st != 0 && g.source_model == 1 && r.phase == 0) {
-        n_wall += r.j;
-        ray_rescatter(g, r, wk.seed);
-        st = 0;
+    {
+      V3 q;
+      int kind = K_NONE;
+      bool arrived = false;
+      if (alive && !parked) {
+        if (next_hit_s1(h, r.p, r.v, r.on, q)) { kind = K_INNER; arrived = true; }
+        else parked = true;
       }
-      if (st != 0) {
-        alive = false;
-        n_wall += r.j;
-        if (st == ST_EXITED) {
-          n_exited++;
-          const bool below = r.p.z < d.portz;  // isRayPassingThroughExitPort, fluxAtObserver.C:162-166
-          if (below) n_counted++;
-          bin_me = (SINK == SINK_DISC) ? true : below;
-        } else if (st == ST_ABSORBED) n_abs++;
-        else n_susp++;
+      const unsigned long long pm = __ballot(parked);
+      if (pm) {
+        const bool flush = (__popcll(pm) >= sched_min) || ((iter & (uint32_t)sched_mask) == (uint32_t)sched_mask) ||
+                           (__ballot(alive && !parked) == 0ull);
+        if (flush && parked) {
+          kind = next_hit_generic(g, r.p, r.v, r.on, q);
+          arrived = true;
+          parked = false;
+        }
+      }
+      iter++;
+      if (arrived) {
+        int st = ray_arrive<SINK == SINK_DISC>(h, g, r, seed, kind, q);
+        if (st != 0 && h.source_model == 1 && r.phase == 0) {
+          n_wall += r.j;
+          ray_rescatter(g, r, seed);
+          st = 0;
+        }
+        if (st != 0) {
+          alive = false;
+          n_wall += r.j;
+          if (st == ST_EXITED) {
+            n_exited++;
+            const bool below = r.p.z < portz;  // isRayPassingThroughExitPort, fluxAtObserver.C:162-166
+            if (below) n_counted++;
+            bin_me = (SINK == SINK_DISC) ? true : below;
+          } else if (st == ST_ABSORBED) n_abs++;
+          else n_susp++;
+        }
       }
     }
     if (SINK == SINK_PERPOS) {
@@ -368,20 +446,23 @@ __device__ __forceinline__ void persistent_body(const Geom& g, const DetGrid& d,
       bool hit0 = false, hit1 = false;
       int b0 = 0, b1 = 0;
       if (bin_me) {
-        const uint64_t rel = r.id - d.map_first;
-        uint64_t grp = (uint64_t)((double)rel / (double)d.rays_per_group);
-        if (grp * d.rays_per_group > rel) grp--;
-        else if ((grp + 1) * d.rays_per_group <= rel) grp++;
+        const uint64_t map_first = d.map_first, rpg = d.rays_per_group;
+        const double* table = d.table;
+        const double half_w2 = d.half_w2;
+        const uint64_t rel = r.id - map_first;
+        uint64_t grp = (uint64_t)((double)rel / (double)rpg);
+        if (grp * rpg > rel) grp--;
+        else if ((grp + 1) * rpg <= rel) grp++;
         if (d.fold == 2) {
-          const int half = d.n_phi / 2;
+          const int nphi = d.n_phi, half = nphi / 2;
           const int i = (int)(grp / (uint64_t)half), j = (int)(grp % (uint64_t)half);
-          b0 = i * d.n_phi + j;
+          b0 = i * nphi + j;
           b1 = b0 + half;
-          hit1 = check_intersection(d.table + 6 * (size_t)b1, d.half_w2, r.p, r.v);
+          hit1 = check_intersection(table + 6 * (size_t)b1, half_w2, r.p, r.v);
         } else {
           b0 = (int)grp;
         }
-        hit0 = check_intersection(d.table + 6 * (size_t)b0, d.half_w2, r.p, r.v);
+        hit0 = check_intersection(table + 6 * (size_t)b0, half_w2, r.p, r.v);
       }
       if (hit0) atomicAdd(&hist[b0], 1u);
       if (hit1) atomicAdd(&hist[b1], 1u);
@@ -391,9 +472,9 @@ __device__ __forceinline__ void persistent_body(const Geom& g, const DetGrid& d,
       bool hit = false;
       int b = 0;
       if (bin_me) {
-        const double f = (r.v.z + 1.0) * 0.5 * (double)d.nbins;
+        const double f = (r.v.z + 1.0) * 0.5 * (double)nbins;
         b = (int)floor(f);
-        hit = b >= 0 && b < d.nbins;
+        hit = b >= 0 && b < nbins;
       }
       if (hit) atomicAdd(&hist[b], 1u);
       n_inc += (unsigned long long)__popcll(__ballot(hit));
@@ -411,7 +492,9 @@ __device__ __forceinline__ void persistent_body(const Geom& g, const DetGrid& d,
           P0.x = readlane_f64(r.prev.x, src); P0.y = readlane_f64(r.prev.y, src); P0.z = readlane_f64(r.prev.z, src);
           n_inc += bin_discs(d, hist, P0, P, V, lane);
         } else {
-          n_inc += d.bin_mode == 0 ? bin_brute(d, hist, P, V, lane) : bin_culled(d, hist, rowt, colt, P, V, lane);
+          if (bin_mode == 0) n_inc += bin_brute(d, hist, P, V, lane);
+          else if (bin_mode == 1) n_inc += bin_culled(d, hist, rowt, colt, P, V, lane);
+          // bin_mode 2: diagnostic only (trace without binning; results are NOT a flux map)
         }
       }
     }
@@ -426,7 +509,7 @@ __device__ __forceinline__ void persistent_body(const Geom& g, const DetGrid& d,
   atomicAdd(&sstat[6], n_wall);
   if (lane == 0) atomicAdd(&sstat[5], n_inc);
   __syncthreads();
-  for (int b = tid; b < d.nbins; b += kBlock) {
+  for (int b = tid; b < nbins; b += kBlock) {
     const uint32_t c = hist[b];
     if (c) atomicAdd(&wk.hist[b], (unsigned long long)c);
   }
@@ -436,13 +519,13 @@ __device__ __forceinline__ void persistent_body(const Geom& g, const DetGrid& d,
   }
 }
 
-extern "C" __global__ void __launch_bounds__(kBlock)
+extern "C" __global__ void ISX_KERNEL_ATTR
 isx_trace_bin_kernel(const Geom g, const DetGrid d, const Work wk) { persistent_body<SINK_FLUX>(g, d, wk); }
-extern "C" __global__ void __launch_bounds__(kBlock)
+extern "C" __global__ void ISX_KERNEL_ATTR
 isx_trace_dz_kernel(const Geom g, const DetGrid d, const Work wk) { persistent_body<SINK_DZ>(g, d, wk); }
-extern "C" __global__ void __launch_bounds__(kBlock)
+extern "C" __global__ void ISX_KERNEL_ATTR
 isx_trace_disc_kernel(const Geom g, const DetGrid d, const Work wk) { persistent_body<SINK_DISC>(g, d, wk); }
-extern "C" __global__ void __launch_bounds__(kBlock)
+extern "C" __global__ void ISX_KERNEL_ATTR
 isx_trace_perpos_kernel(const Geom g, const DetGrid d, const Work wk) { persistent_body<SINK_PERPOS>(g, d, wk); }
 
 // ------------------------------------------------------------------ per-ray end states (parity tests)
@@ -451,12 +534,13 @@ isx_endstates_kernel(const Geom g, uint64_t seed, uint64_t first, uint64_t n, in
                      int32_t* __restrict__ npts, double* __restrict__ lp, double* __restrict__ dir) {
   const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
+  const Hot h = make_hot(g);
   Ray r;
   ray_start(g, r, first + i);
   int st;
   for (;;) {
-    st = ray_step(g, r, seed);
-    if (st != 0 && g.source_model == 1 && r.phase == 0) { ray_rescatter(g, r, seed); st = 0; }
+    st = ray_step<false>(h, g, r, seed);
+    if (st != 0 && h.source_model == 1 && r.phase == 0) { ray_rescatter(g, r, seed); st = 0; }
     if (st != 0) break;
   }
   status[i] = st;
