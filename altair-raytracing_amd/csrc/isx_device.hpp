@@ -76,17 +76,28 @@ __device__ __forceinline__ void draw_block(uint64_t seed, uint64_t ray, uint32_t
 __device__ __forceinline__ double u01(uint32_t w) { return fma((double)w, 0x1.0p-32, 0x1.0p-33); }
 
 // ---------------------------------------------------------------- elementary functions
+// A 64-bit literal cannot be an inline VALU operand.  Left alone, hipcc hoists the polynomial
+// coefficients into VGPRs outside the trace loop, runs out of registers and reloads them from
+// SCRATCH inside the loop (10 dependent scratch loads per bounce).  sconst() pins a literal to an
+// SGPR pair at its point of use (2 s_mov per constant, SALU is otherwise idle); the value is
+// unchanged, so the arithmetic is exactly the specified one.
+__device__ __forceinline__ double sconst(double x) {
+  asm volatile("" : "+s"(x));
+  return x;
+}
 __device__ __forceinline__ double kern_sin(double x) {
-  const double S1 = -1.66666666666666324348e-01, S2 = 8.33333333332248946124e-03, S3 = -1.98412698298579493134e-04,
-               S4 = 2.75573137070700676789e-06, S5 = -2.50507602534068634195e-08, S6 = 1.58969099521155010221e-10;
+  const double S1 = sconst(-1.66666666666666324348e-01), S2 = sconst(8.33333333332248946124e-03),
+               S3 = sconst(-1.98412698298579493134e-04), S4 = sconst(2.75573137070700676789e-06),
+               S5 = sconst(-2.50507602534068634195e-08), S6 = sconst(1.58969099521155010221e-10);
   const double z = x * x;
   const double r = fma(z, fma(z, fma(z, fma(z, S6, S5), S4), S3), S2);
   const double v = z * x;
   return fma(v, fma(z, r, S1), x);
 }
 __device__ __forceinline__ double kern_cos(double x) {
-  const double C1 = 4.16666666666666019037e-02, C2 = -1.38888888888741095749e-03, C3 = 2.48015872894767294178e-05,
-               C4 = -2.75573143513906633035e-07, C5 = 2.08757232129817482790e-09, C6 = -1.13596475577881948265e-11;
+  const double C1 = sconst(4.16666666666666019037e-02), C2 = sconst(-1.38888888888741095749e-03),
+               C3 = sconst(2.48015872894767294178e-05), C4 = sconst(-2.75573143513906633035e-07),
+               C5 = sconst(2.08757232129817482790e-09), C6 = sconst(-1.13596475577881948265e-11);
   const double z = x * x;
   const double r = z * fma(z, fma(z, fma(z, fma(z, fma(z, C6, C5), C4), C3), C2), C1);
   const double hz = 0.5 * z;
@@ -104,7 +115,7 @@ __device__ __forceinline__ void quadrant(int k, double s, double c, double& so, 
   co = negc ? -b : b;
 }
 __device__ __forceinline__ void sincos2pi(double u, double& s, double& c) {
-  const double PIO2 = 1.57079632679489655800e+00;
+  const double PIO2 = sconst(1.57079632679489655800e+00);
   const double t = 4.0 * u;
   const double kd = floor(t + 0.5);
   const double r = t - kd;
