@@ -67,11 +67,16 @@ __device__ __forceinline__ double readlane_f64(double x, int lane) {
 }
 
 // ------------------------------------------------------------------ cull helpers (never decide a result)
+// raw hardware f32 reciprocal / sqrt (about 1 ulp; the IEEE-exact expansions cost ~10 instructions
+// each and buy nothing for a conservative pre-selection)
+__device__ __forceinline__ float rcp_cull(float x) { return __builtin_amdgcn_rcpf(x); }
+__device__ __forceinline__ float sqrt_cull(float x) { return __builtin_amdgcn_sqrtf(x); }
+
 // atan2 in f32, |error| < 2e-5 rad (checked in tests/test_cull_math.py against numpy)
 __device__ __forceinline__ float atan2_cull(float y, float x) {
   const float ax = fabsf(x), ay = fabsf(y);
   const float mx = fmaxf(ax, ay), mn = fminf(ax, ay);
-  const float a = mx > 0.f ? mn / mx : 0.f;
+  const float a = mx > 0.f ? mn * rcp_cull(mx) : 0.f;
   const float s = a * a;
   float r = fmaf(s, fmaf(s, fmaf(s, fmaf(s, fmaf(s, -0.01172120f, 0.05265332f), -0.11643287f), 0.19354346f), -0.33262347f),
                  0.99997726f) * a;
@@ -121,22 +126,21 @@ __device__ inline uint32_t bin_culled(const DG& dd, uint32_t* __restrict__ hist,
   const float dO2 = (float)fma(hx, hx, fma(hy, hy, hz * hz));
   const float Rf = (float)d.R, rho = (float)d.rho_d;
   const float R2 = Rf * Rf;
-  const float dO = sqrtf(dO2);
+  const float dO = sqrt_cull(dO2);
   const float a1 = dO + rho;
   if (!(a1 < 0.999f * Rf)) return bin_brute(dd, hist, P, V, lane);
-  const float sF = sqrtf(R2 - dO2);
-  const float smin = sqrtf(R2 - a1 * a1);
+  const float sF = sqrt_cull(R2 - dO2);
+  const float smin = sqrt_cull(R2 - a1 * a1);
   const float a0 = fmaxf(0.f, dO - rho);
-  const float smax = sqrtf(R2 - a0 * a0);
+  const float smax = sqrt_cull(R2 - a0 * a0);
   const float ext = fmaxf(sF - smin, smax - sF);
   // every detector centre within rho_d of the line lies within chord ch of a piercing point
   const float ch2 = fmaf(ext, ext, rho * rho) * 1.0001f + 1e-3f;
   if (!(4.0f * (R2 - dO2) > 4.04f * ch2)) return bin_brute(dd, hist, P, V, lane);
-  const float ch = sqrtf(ch2);
-  const float dphi = 6.28318530718f / (float)d.n_phi;
-  const float inv_dphi = 1.0f / dphi;
-  const float dth = 1.57079632679f / (float)d.n_theta;   // row spacing in theta
-  const float omega = (ch / Rf) * 1.01f + 2e-3f;          // cap angular radius 2*asin(ch/2R), conservatively
+  const float ch = sqrt_cull(ch2);
+  const float inv_dphi = (float)d.n_phi * 0.15915494309f;  // 1/dphi
+  const float inv_dth = (float)d.n_theta * 0.63661977237f;   // 1 / row spacing in theta
+  const float omega = ch * rcp_cull(Rf) * 1.01f + 2e-3f;          // cap angular radius 2*asin(ch/2R), conservatively
   uint32_t inc = 0;
 #pragma unroll 1
   for (int side = 0; side < 2; ++side) {
@@ -144,13 +148,13 @@ __device__ inline uint32_t bin_culled(const DG& dd, uint32_t* __restrict__ hist,
     const float Fx = (float)fma(s, V.x, P.x), Fy = (float)fma(s, V.y, P.y), Fz = (float)fma(s, V.z, P.z);
     if (Fz - ch > (float)d.portz) continue;  // cap entirely above every detector row
     const float AF2 = fmaf(Fx, Fx, Fy * Fy);
-    const float AF = sqrtf(AF2);
+    const float AF = sqrt_cull(AF2);
     float phiF = atan2_cull(Fy, Fx);
     if (phiF < 0.f) phiF += 6.28318530718f;
     const float jf = phiF * inv_dphi - 0.5f;
     // rows that can intersect the cap: |theta_i - theta_F| <= omega, theta measured from -z about O
     const float thF = atan2_cull(AF, (float)d.portz - Fz);
-    int ilo = (int)floorf((thF - omega) / dth - 0.5f), ihi = (int)ceilf((thF + omega) / dth - 0.5f);
+    int ilo = (int)floorf((thF - omega) * inv_dth - 0.5f - 1e-3f), ihi = (int)ceilf((thF + omega) * inv_dth - 0.5f + 1e-3f);
     ilo = max(ilo, 0);
     ihi = min(ihi, d.n_theta - 1);
 #pragma unroll 1
@@ -168,9 +172,9 @@ __device__ inline uint32_t bin_culled(const DG& dd, uint32_t* __restrict__ hist,
         if (num - slack <= -den) { jlo = 0; cnt = d.n_phi; }
         else if (num - slack > den) { cnt = 0; }
         else {
-          float K = (num - slack) / den - 1e-5f;
+          float K = (num - slack) * rcp_cull(den) - 2e-5f;
           K = fminf(1.f, fmaxf(-1.f, K));
-          const float dl = atan2_cull(sqrtf(fmaxf(0.f, 1.f - K * K)), K) + 1e-3f;
+          const float dl = atan2_cull(sqrt_cull(fmaxf(0.f, 1.f - K * K)), K) + 1e-3f;
           const float hw = dl * inv_dphi;
           const int lo = (int)ceilf(jf - hw), hi = (int)floorf(jf + hw);
           jlo = lo; cnt = hi - lo + 1;
@@ -209,7 +213,8 @@ __device__ inline uint32_t bin_culled(const DG& dd, uint32_t* __restrict__ hist,
           const double t3 = num * num;
           const double rhs = d.half_w2 * dot2;
           const double diff = (t1 - t2) + (t3 - rhs);
-          const double band = 1e-9 * (fabs(t1) + fabs(t2) + t3 + rhs);
+          // |t2| = 2|num||dot*dv| <= 2 sqrt(t3) sqrt(t1) <= t1 + t3, so this bounds the scale of all four terms
+          const double band = 2e-9 * (t1 + t3 + rhs);
           hit = diff < 0.0;
           if (fabs(dot) < 1e-4 || fabs(diff) <= band)  // too close to call: exact reference-order test
             hit = check_intersection(d.table + 6 * (size_t)bin, d.half_w2, P, V);
