@@ -18,8 +18,8 @@ os.makedirs(os.path.join(ROOT, "profiles"), exist_ok=True)
 
 
 def one(pattern):
-    g = glob.glob(os.path.join(OUT, pattern))
-    return g[0] if g else None
+    g = sorted(glob.glob(os.path.join(OUT, pattern)), key=os.path.getmtime)
+    return g[-1] if g else None   # newest: gpurun merges successive runs into the same directories
 
 
 lines = [f"# rocprofv3 summary `{tag}` — {KERNEL}", "", note, ""]
@@ -47,11 +47,11 @@ pmc = {}
 for d in sorted(glob.glob(os.path.join(OUT, "prof_pmc_*"))):
     if not os.path.isdir(d):
         continue
-    f = glob.glob(os.path.join(d, "*", "*_counter_collection.csv"))
+    f = sorted(glob.glob(os.path.join(d, "*", "*_counter_collection.csv")), key=os.path.getmtime)
     if not f:
         continue
     by = collections.defaultdict(dict)
-    for r in csv.DictReader(open(f[0])):
+    for r in csv.DictReader(open(f[-1])):
         if KERNEL in r["Kernel_Name"]:
             by[r["Dispatch_Id"]][r["Counter_Name"]] = float(r["Counter_Value"])
     # keep full-size dispatches: those whose first counter is within 2x of the max
