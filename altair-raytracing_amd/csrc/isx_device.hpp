@@ -339,6 +339,10 @@ __device__ __forceinline__ bool interact(const Hot& h, const G& g, int kind, con
   }
   const double dn = dot3(w, n);
   if (dn <= 0.0) w = axpy(-2.0 * dn, n, w);
+  // one Newton step towards unit length (keeps the |v| error at rounding level instead of letting it
+  // random-walk multiplicatively through hit point -> normal -> new direction)
+  const double k = fma(-0.5, dot3(w, w), 1.5);
+  w.x *= k; w.y *= k; w.z *= k;
   v = w;
   return true;
 }

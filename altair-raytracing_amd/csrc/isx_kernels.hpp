@@ -133,6 +133,7 @@ __device__ inline uint32_t bin_culled(const DG& dd, uint32_t* __restrict__ hist,
   d.n_theta = dd.n_theta; d.n_phi = dd.n_phi; d.half_w2 = dd.half_w2; d.rho_d = dd.rho_d; d.R = dd.R;
   d.portz = dd.portz; d.table = dd.table;
   // ---- line vs the sphere of detector centres S(O,R), O=(0,0,portz): wave-uniform, f32 is enough (cull only)
+  const double vv = dot3(V, V);
   const double wz = P.z - d.portz;
   const double wv = fma(P.x, V.x, fma(P.y, V.y, wz * V.z));
   const double hx = fma(-wv, V.x, P.x), hy = fma(-wv, V.y, P.y), hz = fma(-wv, V.z, wz);
@@ -221,7 +222,7 @@ __device__ inline uint32_t bin_culled(const DG& dd, uint32_t* __restrict__ hist,
           const double dot2 = dot * dot;
           const double t1 = dd * dot2;
           const double t2 = (2.0 * num) * (dot * dv);
-          const double t3 = num * num;
+          const double t3 = (num * num) * vv;     // |d + tV|^2 carries |V|^2 (= 1 to rounding; kept for robustness)
           const double rhs = d.half_w2 * dot2;
           const double diff = (t1 - t2) + (t3 - rhs);
           // |t2| = 2|num||dot*dv| <= 2 sqrt(t3) sqrt(t1) <= t1 + t3, so this bounds the scale of all four terms
@@ -246,14 +247,14 @@ struct Ray {
   V3 p, v;
   V3 prev;          // start of the current segment (only kept for SINK_DISC)
   uint64_t id;
-  uint32_t j;       // mirror interactions of the current trace
-  int npts, on;
+  uint32_t j;       // mirror interactions of the current trace; track points = j + 1 (+1 once it left the box)
+  int on;
   int phase;        // 0 primary, 2 scattered (source_model 1)
 };
 
 template <class G>
 __device__ __forceinline__ void ray_start(const G& g, Ray& r, uint64_t id) {
-  r.id = id; r.j = 0; r.npts = 1; r.on = K_NONE; r.phase = 0;
+  r.id = id; r.j = 0; r.on = K_NONE; r.phase = 0;
   r.p.x = g.src[0]; r.p.y = g.src[1]; r.p.z = g.src[2];
   r.v.x = g.dir0[0]; r.v.y = g.dir0[1]; r.v.z = g.dir0[2];
 }
@@ -264,13 +265,12 @@ template <bool KEEP_PREV, class G>
 __device__ __forceinline__ int ray_arrive(const Hot& h, const G& g, Ray& r, uint64_t seed, int kind, const V3& q) {
   if (KEEP_PREV) r.prev = r.p;
   r.p = q;
-  r.npts++;
   if (kind == K_BOX) { r.on = K_BOX; return ST_EXITED; }
   r.on = kind;
   const bool alive = interact(h, g, kind, q, r.v, seed, r.id, r.j, (uint32_t)r.phase);
   r.j++;
   if (!alive) return ST_ABSORBED;
-  if (r.npts > h.limit) return ST_SUSPENDED;
+  if ((int)r.j + 1 > h.limit) return ST_SUSPENDED;  // npoints = j + 1 after this interaction
   return 0;
 }
 
@@ -291,7 +291,7 @@ __device__ __forceinline__ void ray_rescatter(const G& g, Ray& r, uint64_t seed)
   const double mag = sqrt(nd.x * nd.x + nd.y * nd.y + nd.z * nd.z);
   r.v.x = nd.x / mag; r.v.y = nd.y / mag; r.v.z = nd.z / mag;
   r.on = (r.on == K_BOX) ? K_NONE : r.on;
-  r.npts = 1; r.j = 0; r.phase = 2;
+  r.j = 0; r.phase = 2;
 }
 
 // ------------------------------------------------------------------ physical disc test (SINK_DISC)
@@ -389,15 +389,19 @@ __device__ __forceinline__ void persistent_body(const Geom& g_arg, const DetGrid
     const uint64_t q = wk.n / nwaves, rem = wk.n % nwaves;
     next = wk.first + wave * q + (wave < rem ? wave : rem);
     end = next + q + (wave < rem ? 1 : 0);
+    // wave-uniform by construction: keep them in SGPRs
+    next = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(next >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)next);
+    end = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(end >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)end);
   }
+  const uint64_t range_first = next, range_end = end;
 
   Ray r;
   ray_start(g, r, 0);
   r.prev = r.p;
   bool alive = false, parked = false;
   uint32_t iter = 0;
-  uint32_t n_launched = 0, n_exited = 0, n_counted = 0, n_abs = 0, n_susp = 0;
-  unsigned long long n_wall = 0, n_inc = 0;
+  uint32_t n_exited = 0, n_counted = 0, n_susp = 0, n_ended = 0, n_wall = 0;   // per lane
+  unsigned long long n_inc = 0;                                                  // per wave
 
   for (;;) {
     // ---- refill dead lanes from this wave's range
@@ -408,7 +412,7 @@ __device__ __forceinline__ void persistent_body(const Geom& g_arg, const DetGrid
             __builtin_amdgcn_mbcnt_hi((uint32_t)(dead >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)dead, 0u));
         if (!alive) {
           const uint64_t id = next + rank;
-          if (id < end) { ray_start(g, r, id); alive = true; n_launched++; }
+          if (id < end) { ray_start(g, r, id); alive = true; }
         }
         next += (uint64_t)__popcll(dead);
       }
@@ -448,14 +452,15 @@ __device__ __forceinline__ void persistent_body(const Geom& g_arg, const DetGrid
         }
         if (st != 0) {
           alive = false;
+          n_ended++;
           n_wall += r.j;
+          if (n_wall > 0x7fffffffu) { atomicAdd(&sstat[6], (unsigned long long)n_wall); n_wall = 0; }
           if (st == ST_EXITED) {
             n_exited++;
             const bool below = r.p.z < portz;  // isRayPassingThroughExitPort, fluxAtObserver.C:162-166
             if (below) n_counted++;
             bin_me = (SINK == SINK_DISC) ? true : below;
-          } else if (st == ST_ABSORBED) n_abs++;
-          else n_susp++;
+          } else if (st == ST_SUSPENDED) n_susp++;
         }
       }
     }
@@ -519,13 +524,15 @@ __device__ __forceinline__ void persistent_body(const Geom& g_arg, const DetGrid
   }
 
   // ---- census + histogram flush
-  atomicAdd(&sstat[0], (unsigned long long)n_launched);
   atomicAdd(&sstat[1], (unsigned long long)n_exited);
   atomicAdd(&sstat[2], (unsigned long long)n_counted);
-  atomicAdd(&sstat[3], (unsigned long long)n_abs);
+  atomicAdd(&sstat[3], (unsigned long long)(n_ended - n_exited - n_susp));  // absorbed
   atomicAdd(&sstat[4], (unsigned long long)n_susp);
-  atomicAdd(&sstat[6], n_wall);
-  if (lane == 0) atomicAdd(&sstat[5], n_inc);
+  atomicAdd(&sstat[6], (unsigned long long)n_wall);
+  if (lane == 0) {
+    atomicAdd(&sstat[0], (unsigned long long)(range_end - range_first));       // launched = this wave's range
+    atomicAdd(&sstat[5], n_inc);
+  }
   __syncthreads();
   for (int b = tid; b < nbins; b += kBlock) {
     const uint32_t c = hist[b];
@@ -562,7 +569,7 @@ isx_endstates_kernel(const Geom g, uint64_t seed, uint64_t first, uint64_t n, in
     if (st != 0) break;
   }
   status[i] = st;
-  npts[i] = r.npts;
+  npts[i] = (int)r.j + 1 + (st == ST_EXITED ? 1 : 0);
   lp[3 * i] = r.p.x; lp[3 * i + 1] = r.p.y; lp[3 * i + 2] = r.p.z;
   dir[3 * i] = r.v.x; dir[3 * i + 1] = r.v.y; dir[3 * i + 2] = r.v.z;
 }
