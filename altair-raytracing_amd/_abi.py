@@ -30,7 +30,8 @@ EXPORTS = [
     "isx_default_config", "isx_init", "isx_shutdown", "isx_strerror", "isx_last_hip_error", "isx_abi_version",
     "isx_device_info", "isx_fluxmap", "isx_fluxmap_device", "isx_sync", "isx_take_stats", "isx_stream",
     "isx_set_option", "isx_mathprobe", "isx_trace_endstates", "isx_disc_sweep", "isx_detector_table",
-    "isx_exit_dz_hist", "isx_fluxmap_per_position", "isx_trace_rays_detector",
+    "isx_exit_dz_hist", "isx_fluxmap_per_position", "isx_trace_rays_detector", "isx_exit_directions",
+    "isx_fluxmap_series",
 ]
 
 
@@ -106,6 +107,8 @@ def load():
     L.isx_exit_dz_hist.argtypes = [P(Config), u64, u64, u64, i32, P(u64), P(Stats)]
     L.isx_fluxmap_per_position.argtypes = [P(Config), u64, i32, u64, u64, u64, u64, P(u64), P(Stats)]
     L.isx_trace_rays_detector.argtypes = [P(Config), P(dbl), dbl, u64, u64, u64, P(u64), P(Stats)]
+    L.isx_exit_directions.argtypes = [P(Config), u64, u64, u64, u64, P(u64), P(dbl), P(u64), P(Stats)]
+    L.isx_fluxmap_series.argtypes = [P(Config), i32, u64, u64, u64, P(u64), P(Stats)]
     _lib = L
     return L
 
@@ -217,6 +220,31 @@ def trace_rays_detector(cfg, detector, width, n_rays, seed, first_ray=0):
     _chk(load().isx_trace_rays_detector(C.byref(cfg), _p(det, C.c_double), float(width), int(n_rays), int(seed),
                                         int(first_ray), C.byref(h), C.byref(st)), "isx_trace_rays_detector")
     return int(h.value), st
+
+
+def exit_directions(cfg, n_rays, seed, first_ray=0, capacity=None):
+    """-> (ray_ids[k], directions[k,3], total_count, Stats); k = min(total_count, capacity)."""
+    cap = int(capacity or n_rays)
+    ids = np.zeros(cap, dtype=np.uint64)
+    d = np.zeros((cap, 3), dtype=np.float64)
+    cnt = C.c_uint64(0)
+    st = Stats()
+    _chk(load().isx_exit_directions(C.byref(cfg), int(n_rays), int(seed), int(first_ray), cap, _p(ids, C.c_uint64),
+                                    _p(d, C.c_double), C.byref(cnt), C.byref(st)), "isx_exit_directions")
+    k = min(int(cnt.value), cap)
+    return ids[:k], d[:k], int(cnt.value), st
+
+
+def fluxmap_series(cfgs, n_rays, seed, first_ray=0):
+    """cfgs: list of Config sharing one detector grid -> (hits[n_cfg, n_theta, n_phi], [Stats])."""
+    n = len(cfgs)
+    arr = (Config * n)(*cfgs)
+    nb = cfgs[0].n_theta * cfgs[0].n_phi
+    hits = np.zeros(n * nb, dtype=np.uint64)
+    st = (Stats * n)()
+    _chk(load().isx_fluxmap_series(arr, n, int(n_rays), int(seed), int(first_ray), _p(hits, C.c_uint64), st),
+         "isx_fluxmap_series")
+    return hits.reshape(n, cfgs[0].n_theta, cfgs[0].n_phi), list(st)
 
 
 def detector_table(cfg):

@@ -11,6 +11,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <algorithm>
 #include <vector>
 
 using namespace isx;
@@ -196,9 +197,11 @@ int pick_grid(uint64_t n) {
 
 // enqueue one persistent kernel accumulating into d_hist (device) and S.d_stats
 struct PerPos { uint64_t map_first = 0, rays_per_group = 0; int fold = 1; const double* d_table = nullptr; double width = 0; };
+struct LogSink { double* rec = nullptr; unsigned long long* count = nullptr; uint64_t cap = 0; };
 
 int enqueue(int sink, const isx_config* c, uint64_t n, uint64_t seed, uint64_t first, unsigned long long* d_hist,
-            int nbins_override, const double* d_discs, double disc_r, double disc_h, const PerPos* pp = nullptr) {
+            int nbins_override, const double* d_discs, double disc_r, double disc_h, const PerPos* pp = nullptr,
+            const LogSink* lg = nullptr, unsigned long long* d_stats = nullptr) {
   Geom g;
   int rc = prepare_geom(c, &g);
   if (rc) return rc;
@@ -237,6 +240,11 @@ int enqueue(int sink, const isx_config* c, uint64_t n, uint64_t seed, uint64_t f
     }
     d.map_first = pp->map_first; d.rays_per_group = pp->rays_per_group; d.fold = pp->fold;
     lds = (((size_t)d.nbins * 4 + 15) & ~(size_t)15) + 64 + sizeof(Geom) + sizeof(DetGrid);
+  } else if (sink == SINK_LOG) {
+    if (!lg || !lg->rec || !lg->count) return ISX_ERR_BAD_ARG;
+    d.nbins = 1;
+    d.log_rec = lg->rec; d.log_count = lg->count; d.log_cap = lg->cap;
+    lds = 16 + 64 + sizeof(Geom) + sizeof(DetGrid);
   } else {
     if (nbins_override < 1 || nbins_override > 36000) return ISX_ERR_BAD_ARG;
     d.nbins = nbins_override;
@@ -245,20 +253,22 @@ int enqueue(int sink, const isx_config* c, uint64_t n, uint64_t seed, uint64_t f
   }
   if (n == 0) return ISX_OK;
   Work wk;
-  wk.seed = seed; wk.first = first; wk.n = n; wk.hist = d_hist; wk.stats = S.d_stats;
+  wk.seed = seed; wk.first = first; wk.n = n; wk.hist = d_hist; wk.stats = d_stats ? d_stats : S.d_stats;
   const int grid = pick_grid(n);
   hipEvent_t e0, e1;
   rc = get_event(&e0); if (rc) return rc;
   rc = get_event(&e1); if (rc) return rc;
   const void* fn = sink == SINK_FLUX ? (const void*)isx_trace_bin_kernel
                    : sink == SINK_DZ ? (const void*)isx_trace_dz_kernel
-                   : sink == SINK_DISC ? (const void*)isx_trace_disc_kernel : (const void*)isx_trace_perpos_kernel;
+                   : sink == SINK_DISC ? (const void*)isx_trace_disc_kernel
+                   : sink == SINK_PERPOS ? (const void*)isx_trace_perpos_kernel : (const void*)isx_trace_log_kernel;
   HIPCHK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   HIPCHK(hipEventRecord(e0, S.stream));
   if (sink == SINK_FLUX) hipLaunchKernelGGL(isx_trace_bin_kernel, dim3(grid), dim3(kBlock), lds, S.stream, g, d, wk);
   else if (sink == SINK_DZ) hipLaunchKernelGGL(isx_trace_dz_kernel, dim3(grid), dim3(kBlock), lds, S.stream, g, d, wk);
   else if (sink == SINK_DISC) hipLaunchKernelGGL(isx_trace_disc_kernel, dim3(grid), dim3(kBlock), lds, S.stream, g, d, wk);
-  else hipLaunchKernelGGL(isx_trace_perpos_kernel, dim3(grid), dim3(kBlock), lds, S.stream, g, d, wk);
+  else if (sink == SINK_PERPOS) hipLaunchKernelGGL(isx_trace_perpos_kernel, dim3(grid), dim3(kBlock), lds, S.stream, g, d, wk);
+  else hipLaunchKernelGGL(isx_trace_log_kernel, dim3(grid), dim3(kBlock), lds, S.stream, g, d, wk);
   HIPCHK(hipGetLastError());
   HIPCHK(hipEventRecord(e1, S.stream));
   S.launched_pending += n;
@@ -565,6 +575,95 @@ int isx_trace_rays_detector(const isx_config* cfg, const double* detector, doubl
   const int rc2 = collect_stats(stats);
   (void)hipFree(d_det);
   *hit_count = h;
+  return rc ? rc : rc2;
+}
+
+int isx_exit_directions(const isx_config* cfg, uint64_t n_rays, uint64_t seed, uint64_t first_ray, uint64_t capacity,
+                        uint64_t* ray_ids, double* directions, uint64_t* count, isx_stats* stats) {
+  if (!S.init) return ISX_ERR_NOT_INIT;
+  if (!cfg || !ray_ids || !directions || !count || capacity < 1) return ISX_ERR_BAD_ARG;
+  int rc = ensure_hist(1);
+  if (rc) return rc;
+  rc = collect_stats(nullptr);
+  if (rc) return rc;
+  double* d_rec = nullptr;
+  unsigned long long* d_cnt = nullptr;
+  HIPCHK(hipMalloc(&d_rec, capacity * 32));
+  hipError_t e = hipMalloc(&d_cnt, 8);
+  if (e == hipSuccess) e = hipMemsetAsync(d_cnt, 0, 8, S.stream);
+  if (e == hipSuccess) e = hipMemsetAsync(S.d_hist, 0, 8, S.stream);
+  if (e != hipSuccess) { (void)hipFree(d_rec); if (d_cnt) (void)hipFree(d_cnt); S.last_hip = (int)e; return ISX_ERR_HIP; }
+  LogSink lg;
+  lg.rec = d_rec; lg.count = d_cnt; lg.cap = capacity;
+  rc = enqueue(SINK_LOG, cfg, n_rays, seed, first_ray, S.d_hist, 0, nullptr, 0, 0, nullptr, &lg);
+  unsigned long long total = 0;
+  std::vector<double> rec;
+  if (rc == ISX_OK) {
+    e = hipStreamSynchronize(S.stream);
+    if (e == hipSuccess) e = hipMemcpy(&total, d_cnt, 8, hipMemcpyDeviceToHost);
+    const uint64_t kept = total < capacity ? total : capacity;
+    rec.resize(kept * 4);
+    if (e == hipSuccess && kept) e = hipMemcpy(rec.data(), d_rec, kept * 32, hipMemcpyDeviceToHost);
+    if (e != hipSuccess) { S.last_hip = (int)e; rc = ISX_ERR_HIP; }
+    else {
+      // slots are handed out in completion order: sort by ray index so the log is reproducible
+      std::vector<uint32_t> order(kept);
+      for (uint64_t k = 0; k < kept; ++k) order[k] = (uint32_t)k;
+      auto id_of = [&](uint32_t k) { uint64_t v; std::memcpy(&v, &rec[4 * (size_t)k], 8); return v; };
+      std::sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return id_of(a) < id_of(b); });
+      for (uint64_t k = 0; k < kept; ++k) {
+        const uint32_t o = order[k];
+        ray_ids[k] = id_of(o);
+        directions[3 * k] = rec[4 * (size_t)o + 1]; directions[3 * k + 1] = rec[4 * (size_t)o + 2]; directions[3 * k + 2] = rec[4 * (size_t)o + 3];
+      }
+    }
+  }
+  *count = total;
+  const int rc2 = collect_stats(stats);
+  (void)hipFree(d_rec); (void)hipFree(d_cnt);
+  return rc ? rc : rc2;
+}
+
+int isx_fluxmap_series(const isx_config* cfgs, int32_t n_cfg, uint64_t n_rays, uint64_t seed, uint64_t first_ray,
+                       uint64_t* hits, isx_stats* stats) {
+  if (!S.init) return ISX_ERR_NOT_INIT;
+  if (!cfgs || !hits || n_cfg < 1 || n_cfg > 4096) return ISX_ERR_BAD_ARG;
+  int rc = check_grid(&cfgs[0]);
+  if (rc) return rc;
+  for (int k = 1; k < n_cfg; ++k)
+    if (!same_grid(cfgs[0], cfgs[k]) || cfgs[k].det_diameter != cfgs[0].det_diameter) return ISX_ERR_BAD_CONFIG;
+  const size_t nb = (size_t)cfgs[0].n_theta * cfgs[0].n_phi;
+  rc = ensure_hist(nb * (size_t)n_cfg);
+  if (rc) return rc;
+  rc = collect_stats(nullptr);
+  if (rc) return rc;
+  unsigned long long* d_st = nullptr;
+  HIPCHK(hipMalloc(&d_st, (size_t)n_cfg * 8 * sizeof(unsigned long long)));
+  hipError_t e = hipMemsetAsync(d_st, 0, (size_t)n_cfg * 64, S.stream);
+  if (e == hipSuccess) e = hipMemsetAsync(S.d_hist, 0, nb * (size_t)n_cfg * sizeof(unsigned long long), S.stream);
+  if (e != hipSuccess) { (void)hipFree(d_st); S.last_hip = (int)e; return ISX_ERR_HIP; }
+  // every configuration is enqueued back to back (no host round trip in between); configuration k
+  // uses the ray indices [first_ray + k*n_rays, +n_rays) so the maps are statistically independent
+  for (int k = 0; k < n_cfg && rc == ISX_OK; ++k)
+    rc = enqueue(SINK_FLUX, &cfgs[k], n_rays, seed, first_ray + (uint64_t)k * n_rays, S.d_hist + (size_t)k * nb, 0, nullptr,
+                 0, 0, nullptr, nullptr, d_st + (size_t)k * 8);
+  std::vector<unsigned long long> hst((size_t)n_cfg * 8);
+  if (rc == ISX_OK) {
+    e = hipMemcpyAsync(hits, S.d_hist, nb * (size_t)n_cfg * sizeof(unsigned long long), hipMemcpyDeviceToHost, S.stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(hst.data(), d_st, hst.size() * 8, hipMemcpyDeviceToHost, S.stream);
+    if (e != hipSuccess) { S.last_hip = (int)e; rc = ISX_ERR_HIP; }
+  }
+  isx_stats tot;
+  const int rc2 = collect_stats(&tot);   // syncs; tot.t_kernel_ms = all launches
+  (void)hipFree(d_st);
+  if (rc == ISX_OK && rc2 == ISX_OK && stats) {
+    for (int k = 0; k < n_cfg; ++k) {
+      const unsigned long long* h = &hst[(size_t)k * 8];
+      stats[k].launched = h[0]; stats[k].exited = h[1]; stats[k].counted_below_z = h[2]; stats[k].absorbed = h[3];
+      stats[k].suspended = h[4]; stats[k].bin_increments = h[5]; stats[k].wall_hits = h[6];
+      stats[k].t_kernel_ms = tot.t_kernel_ms;  // total of the series (launches are not timed separately)
+    }
+  }
   return rc ? rc : rc2;
 }
 

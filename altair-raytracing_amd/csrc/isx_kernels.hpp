@@ -35,9 +35,15 @@ struct DetGrid {
   // fluxAtObserverFast.C:336-408): group g -> bins (i,j) and (i,j+n_phi/2), i=g/(n_phi/2).
   uint64_t map_first, rays_per_group;
   int fold, pad1;
+  // SINK_LOG: un-binned exit log (3dRayLog.txt): records {ray id, dx, dy, dz} = 32 B per counted ray,
+  // the one sink with real HBM output.  log_count is the device-side cursor; records beyond log_cap are dropped
+  // (the cursor still counts them, so the caller can tell).
+  double* log_rec;               // [log_cap][4]  (id bit-cast into the first double)
+  unsigned long long* log_count;
+  uint64_t log_cap;
 };
 
-enum : int { SINK_FLUX = 0, SINK_DZ = 1, SINK_DISC = 2, SINK_PERPOS = 3 };
+enum : int { SINK_FLUX = 0, SINK_DZ = 1, SINK_DISC = 2, SINK_PERPOS = 3, SINK_LOG = 4 };
 
 struct Work {
   uint64_t seed, first, n;
@@ -464,7 +470,27 @@ __device__ __forceinline__ void persistent_body(const Geom& g_arg, const DetGrid
         }
       }
     }
-    if (SINK == SINK_PERPOS) {
+    if (SINK == SINK_LOG) {
+      // wave-aggregated append: one atomic on the cursor per wave-step, 32-byte records
+      const unsigned long long m = __ballot(bin_me);
+      if (m) {
+        const int leader = __builtin_ctzll(m);
+        unsigned long long base = 0;
+        if (lane == leader) base = atomicAdd(d_arg.log_count, (unsigned long long)__popcll(m));
+        base = ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)(base >> 32), leader) << 32) |
+               (uint32_t)__builtin_amdgcn_readlane((int)base, leader);
+        if (bin_me) {
+          const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+          const unsigned long long slot = base + rank;
+          if (slot < d_arg.log_cap) {
+            double4 rec;
+            rec.x = __longlong_as_double((long long)r.id); rec.y = r.v.x; rec.z = r.v.y; rec.w = r.v.z;
+            reinterpret_cast<double4*>(d_arg.log_rec)[slot] = rec;
+          }
+        }
+        n_inc += (unsigned long long)__popcll(m);
+      }
+    } else if (SINK == SINK_PERPOS) {
       // per-lane: the ray's own detector group only (one or two exact tests)
       bool hit0 = false, hit1 = false;
       int b0 = 0, b1 = 0;
@@ -552,6 +578,8 @@ extern "C" __global__ void ISX_KERNEL_ATTR
 isx_trace_disc_kernel(const Geom g, const DetGrid d, const Work wk) { persistent_body<SINK_DISC>(g, d, wk); }
 extern "C" __global__ void ISX_KERNEL_ATTR
 isx_trace_perpos_kernel(const Geom g, const DetGrid d, const Work wk) { persistent_body<SINK_PERPOS>(g, d, wk); }
+extern "C" __global__ void ISX_KERNEL_ATTR
+isx_trace_log_kernel(const Geom g, const DetGrid d, const Work wk) { persistent_body<SINK_LOG>(g, d, wk); }
 
 // ------------------------------------------------------------------ per-ray end states (parity tests)
 extern "C" __global__ void __launch_bounds__(256)

@@ -13,6 +13,7 @@
 #include <fstream>
 #include <iomanip>
 #include <iostream>
+#include <algorithm>
 #include <sstream>
 
 namespace isxhost {
@@ -412,8 +413,10 @@ int traceRaysParallelTwofold(OpticsManager* m, int n, double exitPortZ, Detector
   return total;
 }
 
+// pre != nullptr: the trace-once map was already computed (batched series); only the file is written
+struct Precomputed { const uint64_t* hits; isx_stats st; };
 static void sweep_common(bool traceOnce, bool notify, const char* saveFolder, double srcX, double srcY, double srcZ,
-                         double dirX, double dirY, double dirZ, double thetaMax) {
+                         double dirX, double dirY, double dirZ, double thetaMax, const Precomputed* pre = nullptr) {
   const double tSetup = now_s();
   OpticsManager manager;
   fluxAtObserverOptimize::setupOpticsManager(&manager, MAX_REFLECTIONS, ROUGHNESS, REFLECTANCE, thetaMax, false);
@@ -450,7 +453,11 @@ static void sweep_common(bool traceOnce, bool notify, const char* saveFolder, do
   isx_stats st;
   int rc;
   const double t0 = now_s();
-  if (traceOnce) {
+  if (pre) {
+    std::copy(pre->hits, pre->hits + hits.size(), hits.begin());
+    st = pre->st;
+    rc = ISX_OK;
+  } else if (traceOnce) {
     // one trace, every exiting line tested against all 16200 positions (fluxAtObserverFast.C:1143-1315), with
     // the per-position hit semantics (last point + final direction); the reference's GetPoint(nPoints-2)
     // defect (:1181,:1225) is deliberately not reproduced.
@@ -506,7 +513,29 @@ void sweepSeries() {
   const std::string baseFolder = "portAngleSweep_04_03_" + std::to_string(int(srcX / cm)) + "_" +
                                  std::to_string(int(srcY / cm)) + "_" + std::to_string(int(srcZ / cm)) + "_" +
                                  std::to_string(int(portAngle));
-  for (int i = 0; i < 5; i++) sweepDetectorTraceOnce(false, baseFolder.c_str(), 1, srcX, srcY, srcZ, dirXBase, 0, 0, portAngle);
+  // the five repeats are traced back to back on the device with one synchronisation (isx_fluxmap_series),
+  // each on its own ray-index range, then written as five files exactly as five calls would
+  const int reps = 5;
+  const long n = pick_n(100000);
+  OpticsManager manager;
+  fluxAtObserverOptimize::setupOpticsManager(&manager, MAX_REFLECTIONS, ROUGHNESS, REFLECTANCE, portAngle, false);
+  isx_config c = manager.cfg;
+  c.src[0] = srcX; c.src[1] = srcY; c.src[2] = srcZ; c.dir[0] = dirXBase; c.dir[1] = 0; c.dir[2] = 0;
+  c.n_theta = 180; c.n_phi = 90; c.det_diameter = 40 * cm; c.det_distance = 100 * cm; c.exit_port_z = -100 * cm;
+  if (!ensure_device()) return;
+  std::vector<isx_config> cfgs(reps, c);
+  std::vector<uint64_t> hits((size_t)reps * 16200);
+  std::vector<isx_stats> st(reps);
+  const int rc = isx_fluxmap_series(cfgs.data(), reps, (uint64_t)n, options().seed, take_rays((uint64_t)n * reps), hits.data(), st.data());
+  if (rc != ISX_OK) {
+    std::cerr << "Error: isx_fluxmap_series: " << isx_strerror(rc) << std::endl;
+    return;
+  }
+  for (int i = 0; i < reps; i++) {
+    Precomputed pre{hits.data() + (size_t)i * 16200, st[i]};
+    pre.st.t_kernel_ms /= reps;
+    sweep_common(true, false, baseFolder.c_str(), srcX, srcY, srcZ, dirXBase, 0, 0, portAngle, &pre);
+  }
   if (!options().quiet) std::cout << "\n***** ALL SWEEP SERIES COMPLETE *****\n" << std::endl << '\a' << std::endl;
 }
 
@@ -658,6 +687,19 @@ void distributionSphereDetectorSweep() {
   std::ofstream f(getUniqueFilename("angular_dist.txt"));
   f << "# bin_center content\n";
   for (int b = 0; b < 100; ++b) f << (-1.0 + (b + 0.5) * 0.02) << " " << hist[b] << "\n";
+  // the un-binned log of the same rays, in the format of the committed 3dRayLog.txt
+  std::vector<uint64_t> ids((size_t)n);
+  std::vector<double> dirs((size_t)n * 3);
+  uint64_t count = 0;
+  const uint64_t first = options().next_ray - (uint64_t)n;  // the very rays the histogram was made from
+  const int rc2 = isx_exit_directions(&c, (uint64_t)n, options().seed, first, (uint64_t)n, ids.data(), dirs.data(), &count, &st);
+  if (rc2 != ISX_OK) {
+    std::cerr << "Error: isx_exit_directions: " << isx_strerror(rc2) << std::endl;
+    return;
+  }
+  std::ofstream lg(getUniqueFilename("3dRayLog.txt"));
+  lg << "# dx dy dz\n";
+  for (uint64_t k = 0; k < count; ++k) lg << dirs[3 * k] << " " << dirs[3 * k + 1] << " " << dirs[3 * k + 2] << "\n";
 }
 
 }  // namespace rootMacros

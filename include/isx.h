@@ -183,6 +183,24 @@ int isx_trace_rays_detector(const isx_config* cfg, const double* detector /*[6]*
 int isx_exit_dz_hist(const isx_config* cfg, uint64_t n_rays, uint64_t seed, uint64_t first_ray, int32_t nbins,
                      uint64_t* hist, isx_stats* stats);
 
+/*
+ * Un-binned exit log (the committed 3dRayLog.txt, "# dx dy dz"): ray index and final unit
+ * direction of every ray counted below exit_port_z, sorted by ray index.  capacity = room in
+ * ray_ids[capacity] / directions[capacity][3]; *count = number of such rays (may exceed capacity:
+ * the surplus is dropped).  This is the one sink with real HBM output (32 B per exiting ray).
+ */
+int isx_exit_directions(const isx_config* cfg, uint64_t n_rays, uint64_t seed, uint64_t first_ray, uint64_t capacity,
+                        uint64_t* ray_ids, double* directions, uint64_t* count, isx_stats* stats);
+
+/*
+ * Series driver (sweepSeries, fluxAtObserverOptimize.C:892-921 / fluxAtObserverFast.C:1641-1673):
+ * n_cfg configurations sharing one detector grid, traced back to back on the device with ONE
+ * host synchronisation; hits[n_cfg][n_theta*n_phi], stats[n_cfg] (t_kernel_ms = whole series).
+ * Configuration k uses ray indices [first_ray + k*n_rays, +n_rays).
+ */
+int isx_fluxmap_series(const isx_config* cfgs, int32_t n_cfg, uint64_t n_rays, uint64_t seed, uint64_t first_ray,
+                       uint64_t* hits, isx_stats* stats);
+
 /* Host-side detector table exactly as Detector::setPosition builds it
  * (fluxAtObserver.C:49-68): out[(i*n_phi+j)*6] = x,y,z,nx,ny,nz.  No GPU needed. */
 int isx_detector_table(const isx_config* cfg, double* out);

@@ -864,3 +864,22 @@ int isxo_exit_dz_hist(const isxo_config* c, uint64_t n, uint64_t seed, uint64_t 
   if (stats) *stats = tot;
   return 0;
 }
+
+int isxo_exit_directions(const isxo_config* c, uint64_t n, uint64_t seed, uint64_t first, uint64_t cap, uint64_t* ids,
+                         double* dirs, uint64_t* count) {
+  geom g;
+  if (!c || !ids || !dirs || !count) return -3;
+  int rc = prepare(c, &g);
+  if (rc) return rc;
+  uint64_t k = 0;
+  for (uint64_t i = 0; i < n; i++) {
+    endstate es;
+    trace_ray(c, &g, seed, first + i, &es);
+    if (es.status == ISXO_EXITED && es.p.z < c->exit_port_z) { /* distributionSphereDetectorSweep.C:76-88 */
+      if (k < cap) { ids[k] = first + i; dirs[3 * k] = es.v.x; dirs[3 * k + 1] = es.v.y; dirs[3 * k + 2] = es.v.z; }
+      k++;
+    }
+  }
+  *count = k;
+  return 0;
+}

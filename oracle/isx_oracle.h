@@ -82,6 +82,10 @@ int isxo_disc_sweep(const isxo_config* cfg, const double* centers_axes, int32_t 
 int isxo_exit_dz_hist(const isxo_config* cfg, uint64_t n_rays, uint64_t seed, uint64_t first_ray,
                       int32_t nbins, uint64_t* hist, isxo_stats* stats, int nthreads);
 
+/* Un-binned exit log (3dRayLog.txt): ray index + final direction of every ray counted below z, in ray order. */
+int isxo_exit_directions(const isxo_config* cfg, uint64_t n_rays, uint64_t seed, uint64_t first_ray, uint64_t capacity,
+                         uint64_t* ray_ids, double* directions, uint64_t* count);
+
 int isxo_max_threads(void);
 
 #ifdef __cplusplus

@@ -82,6 +82,7 @@ def lib():
         L.isxo_exit_dz_hist.argtypes = [P(Config), u64, u64, u64, i32, P(u64), P(Stats), C.c_int]
         L.isxo_fluxmap_per_position.argtypes = [P(Config), u64, i32, u64, u64, u64, u64, P(u64), P(Stats), C.c_int]
         L.isxo_trace_rays_detector.argtypes = [P(Config), P(dbl), dbl, u64, u64, u64, P(u64), P(Stats)]
+        L.isxo_exit_directions.argtypes = [P(Config), u64, u64, u64, u64, P(u64), P(dbl), P(u64)]
         L.isxo_max_threads.restype = C.c_int
         _lib = L
     return _lib
@@ -181,3 +182,14 @@ def trace_rays_detector(cfg, detector, width, n, seed, first=0):
     rc = lib().isxo_trace_rays_detector(C.byref(cfg), _p(det, C.c_double), width, n, seed, first, C.byref(h), C.byref(st))
     assert rc == 0, rc
     return int(h.value), st
+
+
+def exit_directions(cfg, n, seed, first=0, capacity=None):
+    cap = capacity or n
+    ids = np.zeros(cap, dtype=np.uint64)
+    d = np.zeros((cap, 3), dtype=np.float64)
+    cnt = C.c_uint64(0)
+    rc = lib().isxo_exit_directions(C.byref(cfg), n, seed, first, cap, _p(ids, C.c_uint64), _p(d, C.c_double), C.byref(cnt))
+    assert rc == 0, rc
+    k = min(int(cnt.value), cap)
+    return ids[:k], d[:k], int(cnt.value)

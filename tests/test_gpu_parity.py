@@ -292,3 +292,38 @@ def test_culled_binning_equals_brute_force_at_scale(isx):
     culled, sc = isx.fluxmap(c, n, 987654321)
     assert np.array_equal(brute, culled)
     assert sb.bin_increments == sc.bin_increments == int(culled.sum())
+
+
+def test_exit_direction_log_bit_exact(isx, orc):
+    """Un-binned exit log (3dRayLog.txt): ids and directions equal the oracle's, in ray order; overflow is reported."""
+    def mk(mod):
+        c = mod.default_config()
+        c.reflectance = 1.0; c.roughness_rad = 0.0; c.max_points = 10000; c.box_half = 200.0; c.src[2] = -80
+        return c
+    n = 100000
+    gi, gd, gc, gst = isx.exit_directions(mk(isx), n, 11, 3)
+    oi, od, oc = orc.exit_directions(mk(orc), n, 11, 3)
+    assert gc == oc == gst.counted_below_z and len(gi) == oc
+    assert np.array_equal(gi, oi) and np.array_equal(_bits(gd), _bits(od))
+    assert np.all(np.diff(gi.astype(np.int64)) > 0)
+    assert np.abs((gd ** 2).sum(1) - 1).max() < 1e-14
+    gi2, gd2, gc2, _ = isx.exit_directions(mk(isx), n, 11, 3, capacity=1000)
+    assert gc2 == oc and len(gi2) == 1000 and np.isin(gi2, oi).all()
+
+
+def test_series_equals_individual_maps(isx, orc):
+    """sweepSeries (port angles 163..178) as one batched call == one isx_fluxmap per configuration."""
+    cfgs = []
+    for port in (163.0, 166.0, 169.0, 172.0, 175.0, 178.0):
+        c = isx.default_config(); c.theta_max_deg = port
+        cfgs.append(c)
+    n = 60000
+    hits, stats = isx.fluxmap_series(cfgs, n, 4711, 100)
+    for k, c in enumerate(cfgs):
+        h, st = isx.fluxmap(c, n, 4711, 100 + k * n)
+        assert np.array_equal(hits[k], h), k
+        assert stats[k].counted_below_z == st.counted_below_z and stats[k].launched == n
+    o = orc.default_config(); o.theta_max_deg = 169.0
+    oh, _ = orc.fluxmap(o, n, 4711, 100 + 2 * n)
+    assert np.array_equal(hits[2], oh)
+    assert np.all(np.diff([int(h.sum()) for h in hits]) < 0)     # smaller port, fewer hits

@@ -153,3 +153,27 @@ def test_small_macros(cli, isx, tmp_path):
     _run(cli, tmp_path, "distributionSphereDetectorSweep", rays=20000, seed=3)
     ad = np.loadtxt(tmp_path / "angular_dist.txt", comments="#")
     assert ad.shape == (100, 2) and ad[0, 0] == pytest.approx(-0.99) and ad[50:, 1].sum() == 0
+    log = (tmp_path / "3dRayLog.txt").read_text().splitlines()
+    assert log[0] == "# dx dy dz" and len(log) - 1 == int(ad[:, 1].sum())
+    dirs = np.loadtxt(tmp_path / "3dRayLog.txt", comments="#")
+    assert np.abs((dirs ** 2).sum(1) - 1).max() < 1e-4 and (dirs[:, 2] < 0).all()
+    h, _ = np.histogram(dirs[:, 2], bins=100, range=(-1, 1))
+    assert np.abs(h - ad[:, 1]).sum() <= 4          # 6 significant digits in the text log
+
+
+@pytest.mark.gpu
+def test_series_entry_point(cli, isx, tmp_path):
+    """sweepSeries() of fluxAtObserverFast.C:1641: five trace-once maps at port 164 in portAngleSweep_04_03_-60_0_-75_164/."""
+    _run(cli, tmp_path, "fluxAtObserverFast::sweepSeries", rays=20000, seed=99)
+    folder = tmp_path / "portAngleSweep_04_03_-60_0_-75_164"
+    names = sorted(os.listdir(folder))
+    assert names == ["fluxmap_traceonce_20000rays_180x90_src-60_0_-75.csv"] + [
+        f"fluxmap_traceonce_20000rays_180x90_src-60_0_-75_{k}.csv" for k in range(1, 5)]
+    c = isx.default_config(); c.theta_max_deg = 164.0
+    for k, name in enumerate(["fluxmap_traceonce_20000rays_180x90_src-60_0_-75.csv"] + [
+            f"fluxmap_traceonce_20000rays_180x90_src-60_0_-75_{k}.csv" for k in range(1, 5)]):
+        meta, header, rows = parse_fluxmap(folder / name)
+        hits, st = isx.fluxmap(c, 20000, 99, k * 20000)
+        assert meta["Exit port angle"] == "164 degrees"
+        assert meta["Total rays exiting port"] == f"{st.counted_below_z} out of 20000"
+        assert np.array_equal(rows[:, 2], np.array([float(f"{h / 20000.0:.6f}") for h in hits.reshape(-1)]))
