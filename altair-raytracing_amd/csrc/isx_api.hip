@@ -76,7 +76,9 @@ int prepare_geom(const isx_config* c, Geom* g) {
   g->lambertian = c->lambertian;
   g->limit = c->max_points;
   g->source_model = c->source_model;
-  g->pad = 0;
+  if (c->surface_model != ISX_SURFACE_ROBAST && c->surface_model != ISX_SURFACE_LOBE) return ISX_ERR_BAD_CONFIG;
+  if (c->hit_line_mode != ISX_HITLINE_LAST_SEGMENT && c->hit_line_mode != ISX_HITLINE_ORIGIN_COMPAT) return ISX_ERR_BAD_CONFIG;
+  g->surface_model = c->surface_model;
   g->sched_mask = S.sched_mask;
   g->sched_min = S.sched_min;
   for (int k = 0; k < 3; ++k) g->src[k] = c->src[k];
@@ -209,6 +211,7 @@ int enqueue(int sink, const isx_config* c, uint64_t n, uint64_t seed, uint64_t f
   DetGrid d;
   std::memset(&d, 0, sizeof(d));
   d.portz = c->exit_port_z;
+  d.hit_line_mode = c->hit_line_mode;
   size_t lds = 0;
   if (sink == SINK_FLUX) {
     rc = check_grid(c);

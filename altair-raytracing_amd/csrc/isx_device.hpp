@@ -28,7 +28,7 @@ struct Geom {
   double src[3], dir0[3];
   double brdf_theta_scale;  // rough * M_PI / 6   (nonLambertianFlux.C:178)
   double brdf_spec;         // specular/(specular+diffuse) (:157-159)
-  int lambertian, limit, source_model, pad;
+  int lambertian, limit, source_model, surface_model;
   int sched_mask, sched_min;  // generic-search batching: flush when (iter & mask) == mask or >= min lanes parked
 };
 
@@ -37,12 +37,12 @@ struct Geom {
 // across the loop (SGPR spills were >10 % of the issued instructions before this split).
 struct Hot {
   double rin2, zcut_in, ninv_rin, rho;
-  int lambertian, limit, source_model;
+  int lambertian, limit, source_model, surface_model;
 };
 __device__ __forceinline__ Hot make_hot(const Geom& g) {
   Hot h;
   h.rin2 = g.rin2; h.zcut_in = g.zcut_in; h.ninv_rin = g.ninv_rin; h.rho = g.rho;
-  h.lambertian = g.lambertian; h.limit = g.limit; h.source_model = g.source_model;
+  h.lambertian = g.lambertian; h.limit = g.limit; h.source_model = g.source_model; h.surface_model = g.surface_model;
   return h;
 }
 
@@ -262,6 +262,67 @@ __device__ __forceinline__ int next_hit(const Hot& h, const G& g, const V3& p, c
   if (next_hit_s1(h, p, v, on, q_out)) return K_INNER;
   return next_hit_generic(g, p, v, on, q_out);
 }
+// ---------------------------------------------------------------- TVector3 arithmetic in ROOT's own op order (no fma)
+__device__ __forceinline__ V3 tv_orthogonal(const V3& a) {
+  const double xx = a.x < 0.0 ? -a.x : a.x, yy = a.y < 0.0 ? -a.y : a.y, zz = a.z < 0.0 ? -a.z : a.z;
+  V3 r;
+  if (xx < yy) {
+    if (xx < zz) { r.x = 0; r.y = a.z; r.z = -a.y; } else { r.x = a.y; r.y = -a.x; r.z = 0; }
+  } else {
+    if (yy < zz) { r.x = -a.z; r.y = 0; r.z = a.x; } else { r.x = a.y; r.y = -a.x; r.z = 0; }
+  }
+  return r;
+}
+__device__ __forceinline__ V3 tv_cross(const V3& a, const V3& p) {
+  V3 r;
+  r.x = a.y * p.z - p.y * a.z; r.y = a.z * p.x - p.z * a.x; r.z = a.x * p.y - p.x * a.y;
+  return r;
+}
+__device__ __forceinline__ V3 tv_unit(const V3& a) {
+  const double tot2 = a.x * a.x + a.y * a.y + a.z * a.z;
+  const double tot = (tot2 > 0) ? 1.0 / sqrt(tot2) : 1.0;
+  V3 r;
+  r.x = a.x * tot; r.y = a.y * tot; r.z = a.z * tot;
+  return r;
+}
+__device__ __forceinline__ V3 tv_setmag1(const V3& a) {
+  double f = sqrt(a.x * a.x + a.y * a.y + a.z * a.z);
+  if (f == 0) return a;
+  f = 1.0 / f;
+  V3 r;
+  r.x = a.x * f; r.y = a.y * f; r.z = a.z * f;
+  return r;
+}
+
+
+// "nonLambertianFlux copy.C":31-70 (NonLambertianSurface): cos^2 lobe within 60 deg of the normal by rejection.
+// Try k of interaction j draws from Philox block 2j + (stream>>1) of stream 16+k.
+__device__ inline V3 lobe_sample(const V3 normal, uint64_t seed, uint64_t ray, uint32_t j, uint32_t stream) {
+  const double maxAngle = 60.0 * 3.14159265358979323846 / 180.0;
+  const V3 w = tv_unit(normal);
+  V3 yxw; yxw.x = w.z; yxw.y = 0.0; yxw.z = -w.x;  // TVector3(0,1,0).Cross(w)
+  const V3 u = tv_unit(yxw);
+  const V3 vv = tv_cross(w, u);
+  V3 sc = w;
+  for (uint32_t k = 0; k < 64; k++) {
+    uint32_t r[4];
+    draw_block(seed, ray, 2u * j + (stream >> 1), 16u + k, r);
+    const double theta = maxAngle * u01(r[0]);
+    double st, ct, sp, cp;
+    sincos_cw(theta, st, ct);
+    sincos2pi(u01(r[1]), sp, cp);
+    const double x = st * cp, y = st * sp, z = ct;
+    V3 t;
+    t.x = x * u.x + y * vv.x + z * w.x; t.y = x * u.y + y * vv.y + z * w.y; t.z = x * u.z + y * vv.z + z * w.z;
+    sc = tv_unit(t);
+    const double c = sc.x * normal.x + sc.y * normal.y + sc.z * normal.z;
+    const double p = c * c;
+    if (u01(r[2]) <= p) break;
+  }
+  if (sc.x * normal.x + sc.y * normal.y + sc.z * normal.z < 0) { sc.x = -sc.x; sc.y = -sc.y; sc.z = -sc.z; }
+  return sc;
+}
+
 // ---------------------------------------------------------------- surface interaction
 __device__ __forceinline__ void onb(const V3& n, V3& t1, V3& t2) {
   const double sg = copysign(1.0, n.z);
@@ -300,7 +361,9 @@ __device__ __forceinline__ bool interact(const Hot& h, const G& g, int kind, con
   if (!(u01(wl[2]) < h.rho)) return false;
   const V3 n = surface_normal(h, g, kind, q);
   V3 w;
-  if (h.lambertian) {
+  if (h.surface_model == 1) {
+    w = lobe_sample(n, seed, ray, j, stream);
+  } else if (h.lambertian) {
     // cosine-law re-emission about the geometric normal; roughness does not act on a
     // Lambertian border
     V3 A, Bv;
@@ -347,38 +410,7 @@ __device__ __forceinline__ bool interact(const Hot& h, const G& g, int kind, con
   return true;
 }
 
-// ---------------------------------------------------------------- BRDF re-scatter (TVector3 op order, no fma)
-__device__ __forceinline__ V3 tv_orthogonal(const V3& a) {
-  const double xx = a.x < 0.0 ? -a.x : a.x, yy = a.y < 0.0 ? -a.y : a.y, zz = a.z < 0.0 ? -a.z : a.z;
-  V3 r;
-  if (xx < yy) {
-    if (xx < zz) { r.x = 0; r.y = a.z; r.z = -a.y; } else { r.x = a.y; r.y = -a.x; r.z = 0; }
-  } else {
-    if (yy < zz) { r.x = -a.z; r.y = 0; r.z = a.x; } else { r.x = a.y; r.y = -a.x; r.z = 0; }
-  }
-  return r;
-}
-__device__ __forceinline__ V3 tv_cross(const V3& a, const V3& p) {
-  V3 r;
-  r.x = a.y * p.z - p.y * a.z; r.y = a.z * p.x - p.z * a.x; r.z = a.x * p.y - p.x * a.y;
-  return r;
-}
-__device__ __forceinline__ V3 tv_unit(const V3& a) {
-  const double tot2 = a.x * a.x + a.y * a.y + a.z * a.z;
-  const double tot = (tot2 > 0) ? 1.0 / sqrt(tot2) : 1.0;
-  V3 r;
-  r.x = a.x * tot; r.y = a.y * tot; r.z = a.z * tot;
-  return r;
-}
-__device__ __forceinline__ V3 tv_setmag1(const V3& a) {
-  double f = sqrt(a.x * a.x + a.y * a.y + a.z * a.z);
-  if (f == 0) return a;
-  f = 1.0 / f;
-  V3 r;
-  r.x = a.x * f; r.y = a.y * f; r.z = a.z * f;
-  return r;
-}
-
+// ---------------------------------------------------------------- BRDF re-scatter (nonLambertianFlux.C:147-208)
 template <class G>
 __device__ inline V3 brdf_sample(const G& g, const V3 normal, const V3 incident, uint64_t seed, uint64_t ray) {
   uint32_t w[4];

@@ -19,6 +19,7 @@ namespace isx {
 
 struct DetGrid {
   int n_theta, n_phi, nbins, bin_mode;  // bin_mode 0: brute exact, 1: culled + classified
+  int hit_line_mode, pad0;              // ISX_HITLINE_*: which line the detector test sees
   double half_w2;                       // (width/2)*(width/2)   fluxAtObserver.C:106
   double rho_d;                         // width/2
   double R;                             // detector distance from (0,0,portz)
@@ -248,6 +249,17 @@ __device__ inline uint32_t bin_culled(const DG& dd, uint32_t* __restrict__ hist,
   return inc;
 }
 
+// ISX_HITLINE_ORIGIN_COMPAT (fluxAtObserverFast.C:1181-1201,1285): start (0,0,0), direction last/|last|,
+// normalised twice (once by hand, once by the ARay constructor); plain ops as in the reference.
+__device__ __forceinline__ void hit_line_compat(V3& P, V3& V) {
+  const double dx = P.x - 0.0, dy = P.y - 0.0, dz = P.z - 0.0;
+  const double mag = sqrt(dx * dx + dy * dy + dz * dz);
+  const double ex = dx / mag, ey = dy / mag, ez = dz / mag;
+  const double m2 = sqrt(ex * ex + ey * ey + ez * ez);
+  P.x = 0.0; P.y = 0.0; P.z = 0.0;
+  V.x = ex / m2; V.y = ey / m2; V.z = ez / m2;
+}
+
 // ------------------------------------------------------------------ per-lane ray state
 struct Ray {
   V3 p, v;
@@ -383,6 +395,7 @@ __device__ __forceinline__ void persistent_body(const Geom& g_arg, const DetGrid
   const Hot h = make_hot(g_arg);
   const double portz = d_arg.portz;
   const int bin_mode = d_arg.bin_mode;
+  const int hit_line_mode = d_arg.hit_line_mode;
   const int sched_mask = g_arg.sched_mask, sched_min = g_arg.sched_min;
   const uint64_t seed = wk.seed;
 
@@ -498,6 +511,8 @@ __device__ __forceinline__ void persistent_body(const Geom& g_arg, const DetGrid
         const uint64_t map_first = d.map_first, rpg = d.rays_per_group;
         const double* table = d.table;
         const double half_w2 = d.half_w2;
+        V3 lp = r.p, lv = r.v;
+        if (hit_line_mode == 1) hit_line_compat(lp, lv);
         const uint64_t rel = r.id - map_first;
         uint64_t grp = (uint64_t)((double)rel / (double)rpg);
         if (grp * rpg > rel) grp--;
@@ -507,11 +522,11 @@ __device__ __forceinline__ void persistent_body(const Geom& g_arg, const DetGrid
           const int i = (int)(grp / (uint64_t)half), j = (int)(grp % (uint64_t)half);
           b0 = i * nphi + j;
           b1 = b0 + half;
-          hit1 = check_intersection(table + 6 * (size_t)b1, half_w2, r.p, r.v);
+          hit1 = check_intersection(table + 6 * (size_t)b1, half_w2, lp, lv);
         } else {
           b0 = (int)grp;
         }
-        hit0 = check_intersection(table + 6 * (size_t)b0, half_w2, r.p, r.v);
+        hit0 = check_intersection(table + 6 * (size_t)b0, half_w2, lp, lv);
       }
       if (hit0) atomicAdd(&hist[b0], 1u);
       if (hit1) atomicAdd(&hist[b1], 1u);
@@ -541,6 +556,7 @@ __device__ __forceinline__ void persistent_body(const Geom& g_arg, const DetGrid
           P0.x = readlane_f64(r.prev.x, src); P0.y = readlane_f64(r.prev.y, src); P0.z = readlane_f64(r.prev.z, src);
           n_inc += bin_discs(d, hist, P0, P, V, lane);
         } else {
+          if (hit_line_mode == 1) hit_line_compat(P, V);
           if (bin_mode == 0) n_inc += bin_brute(d, hist, P, V, lane);
           else if (bin_mode == 1) n_inc += bin_culled(d, hist, rowt, colt, P, V, lane);
           // bin_mode 2: diagnostic only (trace without binning; results are NOT a flux map)

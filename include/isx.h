@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define ISX_ABI_VERSION 1
+#define ISX_ABI_VERSION 2
 
 typedef enum isx_status {
   ISX_OK = 0,
@@ -48,6 +48,16 @@ typedef enum isx_status {
 /* source_model */
 #define ISX_SOURCE_PENCIL 0 /* fluxAtObserver*.C: identical rays from src along dir            */
 #define ISX_SOURCE_BRDF 1   /* nonLambertianFlux.C:235-304: primary trace, BRDF re-scatter, 2nd trace */
+
+/* surface_model */
+#define ISX_SURFACE_ROBAST 0 /* ABorderSurfaceCondition: Lambertian if `lambertian`, else rough specular   */
+#define ISX_SURFACE_LOBE 1   /* "nonLambertianFlux copy.C":31-70,188-221 NonLambertianSurface: cos^2 lobe
+                                within 60 deg of the normal by rejection sampling (the de-facto CustomMirror) */
+/* hit_line_mode: which line Detector::checkIntersection sees */
+#define ISX_HITLINE_LAST_SEGMENT 0 /* last point + final direction (fluxAtObserverOptimize.C:309; canonical)   */
+#define ISX_HITLINE_ORIGIN_COMPAT 1 /* what fluxAtObserverFast.C:1181-1201,1285-1288 effectively used because
+                                       GetPoint(nPoints-2, buf) never fills buf: start (0,0,0), direction
+                                       lastPoint/|lastPoint| - reproduces the old fluxmap_traceonce_* files */
 
 /*
  * Geometry + surface + source + detector grid.  Field meaning follows the
@@ -73,8 +83,10 @@ typedef struct isx_config {
   double det_distance;   /* Detector::setPosition radius (100)                        */
   double exit_port_z;    /* exitPortZ (-100); also the point the detectors face       */
   int32_t source_model;  /* ISX_SOURCE_*                                              */
-  int32_t reserved0;
+  int32_t surface_model; /* ISX_SURFACE_*                                             */
   double brdf[3];        /* BRDF(roughness, specular, diffuse) nonLambertianFlux.C:211 */
+  int32_t hit_line_mode; /* ISX_HITLINE_*                                             */
+  int32_t reserved1;
 } isx_config;
 
 /* Ray census of one call (all ranks' census add up). */

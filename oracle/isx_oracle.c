@@ -164,7 +164,7 @@ enum { K_NONE = 0, K_INNER = 1, K_OUTER = 2, K_CONE = 3, K_BOX = 4 };
 
 typedef struct {
   double rin2, rout2, zcut_in, zcut_out, k2, ninv_rin, inv_rout, H, rho, sigma;
-  int lambertian, limit;
+  int lambertian, limit, surface_model;
   v3 src, dir0;
 } geom;
 
@@ -188,6 +188,9 @@ static int prepare(const isxo_config* c, geom* g) {
   g->sigma = c->roughness_rad;
   g->lambertian = c->lambertian;
   g->limit = c->max_points;
+  g->surface_model = c->surface_model;
+  if (c->surface_model != 0 && c->surface_model != 1) return -2;
+  if (c->hit_line_mode != 0 && c->hit_line_mode != 1) return -2;
   g->src.x = c->src[0]; g->src.y = c->src[1]; g->src.z = c->src[2];
   /* ARay constructor normalises the direction (fluxAtObserverOptimize.C:290 passes (5,0,0)) */
   double dx = c->dir[0], dy = c->dir[1], dz = c->dir[2];
@@ -308,6 +311,37 @@ static inline v3 surface_normal(const geom* g, int kind, v3 q) {
   return n;
 }
 
+/* "nonLambertianFlux copy.C":31-70: cos^2 lobe within 60 deg of the normal, rejection sampled
+ * (TVector3 arithmetic in its own order).  Try k of interaction j draws from Philox block
+ * 2j + (stream>>1) of stream 16+k. */
+static inline v3 tv_unit(v3 a);
+static inline v3 tv_cross(v3 a, v3 p);
+static inline double tv_dot(v3 a, v3 b);
+static v3 lobe_sample(v3 normal, uint64_t seed, uint64_t ray, uint32_t j, uint32_t stream) {
+  const double maxAngle = 60.0 * M_PI / 180.0;
+  v3 w = tv_unit(normal);
+  v3 yxw = { w.z, 0.0, -w.x };  /* TVector3(0,1,0).Cross(w) */
+  v3 u = tv_unit(yxw);
+  v3 vv = tv_cross(w, u);
+  v3 sc = w;
+  for (uint32_t k = 0; k < 64; k++) {
+    uint32_t r[4];
+    draw_block(seed, ray, 2u * j + (stream >> 1), 16u + k, r);
+    double theta = maxAngle * isxo_u01(r[0]);
+    double st, ct, sp, cp;
+    isxo_sincos(theta, &st, &ct);
+    isxo_sincos2pi(isxo_u01(r[1]), &sp, &cp);
+    double x = st * cp, y = st * sp, z = ct;
+    v3 t = { x * u.x + y * vv.x + z * w.x, x * u.y + y * vv.y + z * w.y, x * u.z + y * vv.z + z * w.z };
+    sc = tv_unit(t);
+    double c = tv_dot(sc, normal);
+    double p = c * c;   /* pow(|cosTheta|, 2.0) */
+    if (isxo_u01(r[2]) <= p) break;
+  }
+  if (tv_dot(sc, normal) < 0) { sc.x = -sc.x; sc.y = -sc.y; sc.z = -sc.z; }
+  return sc;
+}
+
 /* returns 0 if absorbed, 1 otherwise (v updated) */
 static int interact(const geom* g, int kind, v3 q, v3* v, uint64_t seed, uint64_t ray, uint32_t j, uint32_t stream) {
   uint32_t wl[4];
@@ -315,7 +349,9 @@ static int interact(const geom* g, int kind, v3 q, v3* v, uint64_t seed, uint64_
   if (!(isxo_u01(wl[2]) < g->rho)) return 0;
   v3 n = surface_normal(g, kind, q);
   v3 w;
-  if (g->lambertian) {
+  if (g->surface_model == 1) {
+    w = lobe_sample(n, seed, ray, j, stream);
+  } else if (g->lambertian) {
     /* EnableLambertian(true): cosine-law re-emission about the GEOMETRIC normal.  The Gaussian
      * roughness does not act on a Lambertian border: the reference's own sigma=0.5 map
      * (flux_at_observer/fluxmap_data.csv) is reproduced with the roughness ignored and is
@@ -561,6 +597,23 @@ static double now_ms(void) {
   return ts.tv_sec * 1e3 + ts.tv_nsec * 1e-6;
 }
 
+/* the line handed to Detector::checkIntersection */
+static inline void hit_line(const isxo_config* c, const endstate* es, double lp[3], double d[3]) {
+  if (c->hit_line_mode == 1) {
+    /* fluxAtObserverFast.C:1181-1201: secondLastPoint stays (0,0,0); dir = (last-0)/|last-0|; then the
+     * ARay constructor (:1285) normalises the direction once more */
+    double dx = es->p.x - 0.0, dy = es->p.y - 0.0, dz = es->p.z - 0.0;
+    double mag = sqrt(dx * dx + dy * dy + dz * dz);
+    double ex = dx / mag, ey = dy / mag, ez = dz / mag;
+    double m2 = sqrt(ex * ex + ey * ey + ez * ez);
+    lp[0] = 0.0; lp[1] = 0.0; lp[2] = 0.0;
+    d[0] = ex / m2; d[1] = ey / m2; d[2] = ez / m2;
+  } else {
+    lp[0] = es->p.x; lp[1] = es->p.y; lp[2] = es->p.z;
+    d[0] = es->v.x; d[1] = es->v.y; d[2] = es->v.z;
+  }
+}
+
 static inline void census(const endstate* es, double portz, isxo_stats* st, int* counted) {
   st->launched++;
   st->wall_hits += es->wall_hits;
@@ -629,7 +682,8 @@ int isxo_fluxmap(const isxo_config* c, uint64_t n, uint64_t seed, uint64_t first
       int counted;
       census(&es, c->exit_port_z, &st, &counted);
       if (counted) {
-        double lp[3] = { es.p.x, es.p.y, es.p.z }, d[3] = { es.v.x, es.v.y, es.v.z };
+        double lp[3], d[3];
+        hit_line(c, &es, lp, d);
         /* trace-once loop fluxAtObserverFast.C:1269-1294 with the per-position semantics
          * of fluxAtObserverOptimize.C:309 (last point + final direction) */
         for (size_t k = 0; k < nb; k++)
@@ -688,7 +742,8 @@ int isxo_fluxmap_per_position(const isxo_config* c, uint64_t rpp, int32_t fold, 
         int counted;
         census(&es, c->exit_port_z, &st, &counted);
         if (counted) {
-          double lp[3] = { es.p.x, es.p.y, es.p.z }, d[3] = { es.v.x, es.v.y, es.v.z };
+          double lp[3], d[3];
+          hit_line(c, &es, lp, d);
           if (isxo_check_intersection(tab + 6 * b0, c->det_diameter, lp, d)) h0++;
           if (fold == 2 && isxo_check_intersection(tab + 6 * b1, c->det_diameter, lp, d)) h1++;
         }
@@ -721,7 +776,8 @@ int isxo_trace_rays_detector(const isxo_config* c, const double* det, double wid
     int counted;
     census(&es, c->exit_port_z, &st, &counted);
     if (counted) {
-      double lp[3] = { es.p.x, es.p.y, es.p.z }, d[3] = { es.v.x, es.v.y, es.v.z };
+      double lp[3], d[3];
+      hit_line(c, &es, lp, d);
       if (isxo_check_intersection(det, width, lp, d)) h++;
     }
   }

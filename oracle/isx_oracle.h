@@ -30,8 +30,9 @@ typedef struct isxo_config {
   double src[3], dir[3];
   int32_t n_theta, n_phi;
   double det_diameter, det_distance, exit_port_z;
-  int32_t source_model, reserved0;
+  int32_t source_model, surface_model;
   double brdf[3];
+  int32_t hit_line_mode, reserved1;
 } isxo_config;
 
 typedef struct isxo_stats {

@@ -74,6 +74,22 @@ fx = {"_generated_by": "tests/golden/make_golden.py", "_source": "bdagnillo/alta
 fx["exit_counts"] = (exit_counts("trace_once_test_04_2-60_0_-75_5") + exit_counts("portAngleSweep_04_03_-60_0_-75_164")
                      + exit_counts("portAngleSweep_04_02_-60_0_-75_160"))
 
+# trace-once maps (affected by the reference's GetPoint(nPoints-2) defect): kept to pin the
+# optional hit_line_mode=1 compatibility switch
+to = []
+for folder in ("trace_once_test_04_2-60_0_-75_5", "portAngleSweep_04_03_-60_0_-75_164"):
+    profs, sums, port = [], [], None
+    for p in sorted(glob.glob(os.path.join(FAO, folder, "*.csv"))):
+        meta, rows = parse_csv(p)
+        if rows.shape[0] != 16200:
+            continue
+        fr = rows[:, 2].reshape(180, 90)
+        profs.append(fr.mean(axis=1)); sums.append(float(fr.sum())); port = float(meta["Exit port angle"].split()[0])
+    to.append({"folder": folder, "port_deg": port, "n_files": len(profs), "rays": 100000,
+               "sum_fraction_mean": float(np.mean(sums)), "sum_fraction_std": float(np.std(sums, ddof=1)),
+               "theta_profile_mean": [float(x) for x in np.mean(profs, axis=0)]})
+fx["traceonce_maps"] = to
+
 maps = []
 for folder in ("results_overnight_03_31-60_0_-75_5", "results_overnight_04_1-60_0_-75_5"):
     for p in sorted(glob.glob(os.path.join(FAO, folder, "*.csv"))):

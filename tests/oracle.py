@@ -24,8 +24,9 @@ class Config(C.Structure):
         ("src", C.c_double * 3), ("dir", C.c_double * 3),
         ("n_theta", C.c_int32), ("n_phi", C.c_int32),
         ("det_diameter", C.c_double), ("det_distance", C.c_double), ("exit_port_z", C.c_double),
-        ("source_model", C.c_int32), ("reserved0", C.c_int32),
+        ("source_model", C.c_int32), ("surface_model", C.c_int32),
         ("brdf", C.c_double * 3),
+        ("hit_line_mode", C.c_int32), ("reserved1", C.c_int32),
     ]
 
     def copy(self):
