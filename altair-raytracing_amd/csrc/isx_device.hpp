@@ -353,7 +353,9 @@ __device__ __forceinline__ V3 surface_normal(const Hot& h, const G& g, int kind,
 }
 
 // returns false if absorbed; otherwise v is the re-emitted direction
-template <class G>
+// LEAN = the configuration of the headline path (ROBAST Lambertian border, pencil source): the other surface
+// models are compiled out so their registers and code do not burden the hot kernel.
+template <bool LEAN, class G>
 __device__ __forceinline__ bool interact(const Hot& h, const G& g, int kind, const V3& q, V3& v, uint64_t seed,
                                          uint64_t ray, uint32_t j, uint32_t stream) {
   uint32_t wl[4];
@@ -361,9 +363,9 @@ __device__ __forceinline__ bool interact(const Hot& h, const G& g, int kind, con
   if (!(u01(wl[2]) < h.rho)) return false;
   const V3 n = surface_normal(h, g, kind, q);
   V3 w;
-  if (h.surface_model == 1) {
+  if (!LEAN && h.surface_model == 1) {
     w = lobe_sample(n, seed, ray, j, stream);
-  } else if (h.lambertian) {
+  } else if (LEAN || h.lambertian) {
     // cosine-law re-emission about the geometric normal; roughness does not act on a
     // Lambertian border
     V3 A, Bv;

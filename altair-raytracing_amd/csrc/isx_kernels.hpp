@@ -279,13 +279,13 @@ __device__ __forceinline__ void ray_start(const G& g, Ray& r, uint64_t id) {
 
 // Second half of a step, once the boundary (kind, q) is known: advance, interact.
 // Returns 0 while running, else the end status of the CURRENT trace.
-template <bool KEEP_PREV, class G>
+template <bool KEEP_PREV, bool LEAN, class G>
 __device__ __forceinline__ int ray_arrive(const Hot& h, const G& g, Ray& r, uint64_t seed, int kind, const V3& q) {
   if (KEEP_PREV) r.prev = r.p;
   r.p = q;
   if (kind == K_BOX) { r.on = K_BOX; return ST_EXITED; }
   r.on = kind;
-  const bool alive = interact(h, g, kind, q, r.v, seed, r.id, r.j, (uint32_t)r.phase);
+  const bool alive = interact<LEAN>(h, g, kind, q, r.v, seed, r.id, r.j, (uint32_t)r.phase);
   r.j++;
   if (!alive) return ST_ABSORBED;
   if ((int)r.j + 1 > h.limit) return ST_SUSPENDED;  // npoints = j + 1 after this interaction
@@ -297,7 +297,7 @@ template <bool KEEP_PREV, class G>
 __device__ __forceinline__ int ray_step(const Hot& h, const G& g, Ray& r, uint64_t seed) {
   V3 q;
   const int kind = next_hit(h, g, r.p, r.v, r.on, q);
-  return ray_arrive<KEEP_PREV>(h, g, r, seed, kind, q);
+  return ray_arrive<KEEP_PREV, false>(h, g, r, seed, kind, q);
 }
 
 // nonLambertianFlux.C:253-268: restart from the primary's last point along a BRDF-sampled direction
@@ -364,7 +364,7 @@ __device__ __forceinline__ uint32_t bin_discs(const DG& dd, uint32_t* __restrict
 //   SINK_FLUX: 180x90 detector flux map (the headline path)
 //   SINK_DZ  : histogram of the exit direction's z component (distributionSphereDetectorSweep.C:54,91)
 //   SINK_DISC: physical disc sweep (integratingSphereDetectorSweep.C)
-template <int SINK>
+template <int SINK, bool LEAN = false>
 __device__ __forceinline__ void persistent_body(const Geom& g_arg, const DetGrid& d_arg, const Work& wk) {
   extern __shared__ __align__(16) unsigned char smem[];
   uint32_t* hist = reinterpret_cast<uint32_t*>(smem);
@@ -463,8 +463,8 @@ __device__ __forceinline__ void persistent_body(const Geom& g_arg, const DetGrid
       }
       iter++;
       if (arrived) {
-        int st = ray_arrive<SINK == SINK_DISC>(h, g, r, seed, kind, q);
-        if (st != 0 && h.source_model == 1 && r.phase == 0) {
+        int st = ray_arrive<SINK == SINK_DISC, LEAN>(h, g, r, seed, kind, q);
+        if (!LEAN && st != 0 && h.source_model == 1 && r.phase == 0) {
           n_wall += r.j;
           ray_rescatter(g, r, seed);
           st = 0;
@@ -556,7 +556,7 @@ __device__ __forceinline__ void persistent_body(const Geom& g_arg, const DetGrid
           P0.x = readlane_f64(r.prev.x, src); P0.y = readlane_f64(r.prev.y, src); P0.z = readlane_f64(r.prev.z, src);
           n_inc += bin_discs(d, hist, P0, P, V, lane);
         } else {
-          if (hit_line_mode == 1) hit_line_compat(P, V);
+          if (!LEAN && hit_line_mode == 1) hit_line_compat(P, V);
           if (bin_mode == 0) n_inc += bin_brute(d, hist, P, V, lane);
           else if (bin_mode == 1) n_inc += bin_culled(d, hist, rowt, colt, P, V, lane);
           // bin_mode 2: diagnostic only (trace without binning; results are NOT a flux map)
@@ -587,7 +587,10 @@ __device__ __forceinline__ void persistent_body(const Geom& g_arg, const DetGrid
 }
 
 extern "C" __global__ void ISX_KERNEL_ATTR
-isx_trace_bin_kernel(const Geom g, const DetGrid d, const Work wk) { persistent_body<SINK_FLUX>(g, d, wk); }
+isx_trace_bin_kernel(const Geom g, const DetGrid d, const Work wk) { persistent_body<SINK_FLUX, true>(g, d, wk); }
+// every surface / source / hit-line model (BRDF re-scatter, cos^2 lobe, rough specular, origin-compat line)
+extern "C" __global__ void ISX_KERNEL_ATTR
+isx_trace_bin_full_kernel(const Geom g, const DetGrid d, const Work wk) { persistent_body<SINK_FLUX, false>(g, d, wk); }
 extern "C" __global__ void ISX_KERNEL_ATTR
 isx_trace_dz_kernel(const Geom g, const DetGrid d, const Work wk) { persistent_body<SINK_DZ>(g, d, wk); }
 extern "C" __global__ void ISX_KERNEL_ATTR
