@@ -39,12 +39,17 @@ int main(int argc, char** argv) {
                  "  fluxAtObserver::sweepDetector | fluxAtObserverOptimize::sweepDetector | fluxAtObserverOptimize::sweepSeries |\n"
                  "  fluxAtObserverFast::sweepDetectorTwofold | fluxAtObserverFast::sweepDetectorTraceOnce | fluxAtObserverFast::sweepSeries |\n"
                  "  nonLambertianFlux::sweepDetector | makeIntegratingSphereNRays | integratingSphereDetectorSweep |\n"
-                 "  distributionSphereDetectorSweep | --selftest-writer <file> | --unique <path>\n";
+                 "  distributionSphereDetectorSweep | --selftest-writer <file> | --unique <path> | --analyze <csv>...\n";
     return 2;
   }
   const std::string entry = argv[1];
   if (entry == "--selftest-writer" && argc > 2) return selftest_writer(argv[2]);
   if (entry == "--unique" && argc > 2) { std::cout << getUniqueFilename(argv[2]) << std::endl; return 0; }
+  if (entry == "--analyze" && argc > 2) {  // python flux_analysis.py <csv> (numeric part; no GPU)
+    int bad = 0;
+    for (int i = 2; i < argc; ++i) { ThetaAnalysis ta; if (!analyzeFluxMap(argv[i], ta)) bad++; }
+    return bad ? 1 : 0;
+  }
   std::map<std::string, std::string> kv;
   for (int i = 2; i < argc; ++i) {
     const char* eq = std::strchr(argv[i], '=');

@@ -177,6 +177,138 @@ std::string fluxmap_rows(const uint64_t* hits, long n, int nTheta, int nPhi, int
   return o.str();
 }
 
+// ---------------------------------------------------------------------------------------------
+// flux_analysis.py (numeric part)
+// ---------------------------------------------------------------------------------------------
+namespace {
+// Levenberg-Marquardt for y = a*cos(b*x*pi/180) + c  (scipy.optimize.curve_fit's default for an unbounded problem)
+bool fit_cosine(const std::vector<double>& x, const std::vector<double>& y, double p[3]) {
+  const size_t n = x.size();
+  if (n < 3) return false;
+  auto model = [&](const double q[3], size_t k) { return q[0] * std::cos(q[1] * x[k] * M_PI / 180.0) + q[2]; };
+  auto sse = [&](const double q[3]) { double s = 0; for (size_t k = 0; k < n; ++k) { const double r = y[k] - model(q, k); s += r * r; } return s; };
+  double lambda = 1e-3, cur = sse(p);
+  for (int it = 0; it < 200; ++it) {
+    double JtJ[3][3] = {{0}}, Jtr[3] = {0};
+    for (size_t k = 0; k < n; ++k) {
+      const double arg = p[1] * x[k] * M_PI / 180.0;
+      const double J[3] = {std::cos(arg), -p[0] * std::sin(arg) * x[k] * M_PI / 180.0, 1.0};
+      const double r = y[k] - model(p, k);
+      for (int i = 0; i < 3; ++i) { Jtr[i] += J[i] * r; for (int j = 0; j < 3; ++j) JtJ[i][j] += J[i] * J[j]; }
+    }
+    bool improved = false;
+    for (int tries = 0; tries < 30 && !improved; ++tries) {
+      double A[3][4];
+      for (int i = 0; i < 3; ++i) { for (int j = 0; j < 3; ++j) A[i][j] = JtJ[i][j] + (i == j ? lambda * JtJ[i][i] : 0.0); A[i][3] = Jtr[i]; }
+      bool singular = false;
+      for (int c = 0; c < 3 && !singular; ++c) {  // Gauss-Jordan with partial pivoting
+        int piv = c;
+        for (int r = c + 1; r < 3; ++r) if (std::fabs(A[r][c]) > std::fabs(A[piv][c])) piv = r;
+        if (std::fabs(A[piv][c]) < 1e-300) { singular = true; break; }
+        if (piv != c) for (int j = 0; j < 4; ++j) std::swap(A[piv][j], A[c][j]);
+        for (int r = 0; r < 3; ++r) if (r != c) { const double f = A[r][c] / A[c][c]; for (int j = c; j < 4; ++j) A[r][j] -= f * A[c][j]; }
+      }
+      if (singular) { lambda *= 10; continue; }
+      double q[3];
+      for (int i = 0; i < 3; ++i) q[i] = p[i] + A[i][3] / A[i][i];
+      const double s = sse(q);
+      if (s < cur) {
+        const double rel = (cur - s) / (cur > 0 ? cur : 1.0);
+        for (int i = 0; i < 3; ++i) p[i] = q[i];
+        cur = s; lambda = std::max(lambda * 0.3, 1e-12); improved = true;
+        if (rel < 1e-14) return true;
+      } else lambda *= 10;
+    }
+    if (!improved) return true;  // converged: no step decreases the residual
+  }
+  return true;
+}
+}  // namespace
+
+bool analyzeFluxMap(const std::string& csvPath, ThetaAnalysis& out, bool writeReport) {
+  std::ifstream in(csvPath);
+  if (!in.is_open()) {
+    std::cerr << "File not found: " << csvPath << std::endl;
+    return false;
+  }
+  // process_file(): '#' lines are "key: value" metadata, the first other line is the header, then theta,phi,fraction
+  std::vector<double> th, fr;
+  std::string line;
+  bool header = false;
+  while (std::getline(in, line)) {
+    if (line.empty()) continue;
+    if (line[0] == '#') {
+      const size_t colon = line.find(':');
+      if (colon != std::string::npos) {
+        std::string key = line.substr(1, colon - 1), val = line.substr(colon + 1);
+        auto trim = [](std::string& t) { const size_t a = t.find_first_not_of(" \t\r"), b = t.find_last_not_of(" \t\r"); t = a == std::string::npos ? "" : t.substr(a, b - a + 1); };
+        trim(key); trim(val);
+        if (key == "Exit port angle") out.metadata_port_angle = val;
+      }
+      continue;
+    }
+    if (!header) { header = true; continue; }
+    double t, p, f;
+    if (std::sscanf(line.c_str(), "%lf,%lf,%lf", &t, &p, &f) == 3) { th.push_back(t); fr.push_back(f); }
+  }
+  if (th.empty()) {
+    std::cerr << "Error reading CSV data from " << csvPath << std::endl;
+    return false;
+  }
+  // groupby('theta'): mean, std (ddof=1, NaN -> 0.001), count
+  std::vector<size_t> order(th.size());
+  for (size_t k = 0; k < order.size(); ++k) order[k] = k;
+  std::stable_sort(order.begin(), order.end(), [&](size_t a, size_t b) { return th[a] < th[b]; });
+  out.theta.clear(); out.mean.clear(); out.stderr_.clear();
+  for (size_t k = 0; k < order.size();) {
+    size_t e = k;
+    double s = 0;
+    while (e < order.size() && th[order[e]] == th[order[k]]) s += fr[order[e++]];
+    const double cnt = double(e - k), m = s / cnt;
+    double ss = 0;
+    for (size_t q = k; q < e; ++q) ss += (fr[order[q]] - m) * (fr[order[q]] - m);
+    const double sd = cnt > 1 ? std::sqrt(ss / (cnt - 1)) : 0.001;
+    out.theta.push_back(th[order[k]]); out.mean.push_back(m); out.stderr_.push_back(sd / std::sqrt(cnt));
+    k = e;
+  }
+  const double mx = *std::max_element(out.mean.begin(), out.mean.end()), mn = *std::min_element(out.mean.begin(), out.mean.end());
+  double avg = 0;
+  for (double v : out.mean) avg += v;
+  avg /= double(out.mean.size());
+  double p[3] = {(mx - mn) / 2, 1.0, avg};  // p0 of flux_analysis.py:203
+  out.fit_ok = fit_cosine(out.theta, out.mean, p);
+  if (!out.fit_ok) { p[0] = avg / 2; p[1] = 1.0; p[2] = avg / 2; }
+  out.a = p[0]; out.b = p[1]; out.c = p[2];
+  double ss_res = 0, ss_tot = 0;
+  for (size_t k = 0; k < out.theta.size(); ++k) {
+    const double r = out.mean[k] - (p[0] * std::cos(p[1] * out.theta[k] * M_PI / 180.0) + p[2]);
+    ss_res += r * r; ss_tot += (out.mean[k] - avg) * (out.mean[k] - avg);
+  }
+  out.r_squared = ss_tot > 0 ? 1 - ss_res / ss_tot : 0;
+  const size_t slash = csvPath.find_last_of("/\\");
+  const std::string filename = slash == std::string::npos ? csvPath : csvPath.substr(slash + 1);
+  char buf[256];
+  std::cout << "File: " << filename << std::endl;
+  std::snprintf(buf, sizeof(buf), "  Fit parameters: a=%.5f, b=%.5f, c=%.5f", out.a, out.b, out.c);
+  std::cout << buf << std::endl;
+  std::snprintf(buf, sizeof(buf), "  R-squared value: %.5f", out.r_squared);
+  std::cout << buf << std::endl;
+  if (writeReport) {
+    const size_t dot = csvPath.find_last_of('.');
+    const std::string rep = getUniqueFilename((dot == std::string::npos ? csvPath : csvPath.substr(0, dot)) + "_theta_analysis.txt");
+    std::ofstream o(rep);
+    o << "# theta analysis of " << filename << " (flux_analysis.py equivalent)" << std::endl;
+    if (!out.metadata_port_angle.empty()) o << "# Exit port angle: " << out.metadata_port_angle << std::endl;
+    o << std::setprecision(10);
+    o << "# fit: fraction = a*cos(b*theta) + c  a=" << out.a << " b=" << out.b << " c=" << out.c << " R2=" << out.r_squared << std::endl;
+    o << "theta,mean_fraction,stderr,fit" << std::endl;
+    for (size_t k = 0; k < out.theta.size(); ++k)
+      o << out.theta[k] << "," << out.mean[k] << "," << out.stderr_[k] << ","
+        << (out.a * std::cos(out.b * out.theta[k] * M_PI / 180.0) + out.c) << std::endl;
+  }
+  return true;
+}
+
 static void say(const std::string& s) {
   if (!options().quiet) std::cout << s << std::endl;
 }

@@ -74,6 +74,17 @@ std::string fluxmap_header(const FluxMapMeta& m, const std::string& generated);
 // rows "theta,phi,fraction" fixed/6, theta-major (fold 2: twofold row order j, j+nPhi/2)
 std::string fluxmap_rows(const uint64_t* hits, long n, int nTheta, int nPhi, int fold = 1);
 
+// --- offline analysis of a flux-map CSV, the numeric part of flux_at_observer/flux_analysis.py
+// (process_file :11-57, per-theta mean + standard error :182-199, fit a*cos(b*theta)+c :60-62,200-209,
+// R^2 :229-233).  Writes "<stem>_theta_analysis.txt" next to the CSV and prints the script's lines.
+struct ThetaAnalysis {
+  std::vector<double> theta, mean, stderr_;   // one entry per theta row
+  double a = 0, b = 0, c = 0, r_squared = 0;
+  bool fit_ok = false;
+  std::string metadata_port_angle;            // "Exit port angle" header value, if present
+};
+bool analyzeFluxMap(const std::string& csvPath, ThetaAnalysis& out, bool writeReport = true);
+
 namespace fluxAtObserver {
 void setupOpticsManager(OpticsManager* manager);                                  // :147-160
 bool isRayPassingThroughExitPort(const double lastPoint[3], double exitPortZ);    // :162-166

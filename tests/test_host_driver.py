@@ -74,6 +74,40 @@ def test_unique_filename_never_overwrites(cli, tmp_path):
     assert subprocess.check_output([cli, "--unique", str(noext)], text=True).strip() == str(noext) + "_1"
 
 
+def test_theta_analysis_matches_scipy(cli, golden, tmp_path):
+    """isx_macro --analyze == the numeric part of flux_analysis.py (per-theta mean, a*cos(b*theta)+c fit, R^2)."""
+    from scipy.optimize import curve_fit
+    m = [m for m in golden["per_position_maps"] if m["port_deg"] == 170.0][0]
+    prof = np.array(m["theta_profile"])
+    rng = np.random.default_rng(4)
+    path = tmp_path / "map.csv"
+    with open(path, "w") as f:
+        f.write("# Flux Map Data - Generated: 2025-04-01 01:42:14\n# Exit port angle: 170 degrees\ntheta,phi,fraction\n")
+        rows = []
+        for i in range(180):
+            for j in range(90):
+                v = max(0.0, prof[i] * (1 + 0.05 * rng.standard_normal()))
+                rows.append(((i + .5) * .5, (j + .5) * 4, float(f"{v:.6f}")))
+                f.write(f"{rows[-1][0]:.6f},{rows[-1][1]:.6f},{v:.6f}\n")
+        f.write("# Sweep completed at: 2025-04-01 05:10:58\n")
+    out = subprocess.check_output([cli, "--analyze", str(path)], text=True)
+    a, b, c = [float(x) for x in re.search(r"a=([-\d.]+), b=([-\d.]+), c=([-\d.]+)", out).groups()]
+    r2 = float(re.search(r"R-squared value: ([-\d.]+)", out).group(1))
+    arr = np.array(rows)
+    theta = np.unique(arr[:, 0])
+    means = np.array([arr[arr[:, 0] == t, 2].mean() for t in theta])
+
+    def cosine_func(x, a, b, c):
+        return a * np.cos(np.deg2rad(b * x)) + c
+    p0 = [(means.max() - means.min()) / 2, 1.0, means.mean()]
+    popt, _ = curve_fit(cosine_func, theta, means, p0=p0)
+    assert [a, b, c] == pytest.approx(list(popt), abs=2e-5)
+    res = means - cosine_func(theta, *popt)
+    assert r2 == pytest.approx(1 - (res ** 2).sum() / ((means - means.mean()) ** 2).sum(), abs=2e-5)
+    rep = np.loadtxt(tmp_path / "map_theta_analysis.txt", delimiter=",", comments="#", skiprows=4)
+    assert rep.shape == (180, 4) and np.allclose(rep[:, 1], means, atol=1e-9)
+
+
 def test_cli_fails_loudly_without_gpu(cli, tmp_path):
     import altair_raytracing_amd as isx
     if isx.load().isx_init(0) == 0:
