@@ -177,7 +177,10 @@ __device__ inline int next_hit_generic(const G& gg, const V3 p, const V3 v, cons
     if (di >= 0.0) {
       const double s = sqrt(di);
       const double tn = -b - s, tf = s - b;
-      if ((on == K_INNER && b < 0.0) || (on == K_NONE && ci < 0.0)) {
+      if (on == K_INNER && b < 0.0) {          // rule S1' (see next_hit_s1)
+        const V3 q = axpy(-2.0 * b, v, p);
+        if (q.z >= g.zcut_in) { q_out = q; return K_INNER; }
+      } else if (on == K_NONE && ci < 0.0) {
         const V3 q = axpy(tf, v, p);
         if (q.z >= g.zcut_in) { q_out = q; return K_INNER; }
       }
@@ -241,14 +244,24 @@ __device__ inline int next_hit_generic(const G& gg, const V3 p, const V3 v, cons
   return K_BOX;
 }
 
-// Rule S1 alone: returns true (and q) if the far root of the inner sphere is the hit.
+// Rules S1/S1' alone: returns true (and q) if the far root of the inner sphere is the hit.
+// S1' (the bounce-to-bounce case): on the inner sphere heading inwards the far root is -2b - the root of
+// t^2 + 2bt = 0 since p is on the sphere and |v| = 1 to rounding - so the hot path needs no square root
+// (an IEEE f64 sqrt costs ~91 cycles per wave here).  If the generic search has to take over it re-derives
+// the same -2b first, so both routes always agree.
 __device__ __forceinline__ bool next_hit_s1(const Hot& g, const V3& p, const V3& v, const int on, V3& q_out) {
   const double b = dot3(p, v);
+  if (on == K_INNER) {
+    if (!(b < 0.0)) return false;
+    const V3 q = axpy(-2.0 * b, v, p);
+    if (q.z >= g.zcut_in) { q_out = q; return true; }
+    return false;
+  }
+  if (on != K_NONE) return false;
   const double pp = dot3(p, p);
   const double ci = pp - g.rin2;
   const double di = fma(b, b, -ci);
-  const bool s1 = (di >= 0.0) && ((on == K_INNER && b < 0.0) || (on == K_NONE && ci < 0.0));
-  if (!s1) return false;
+  if (!(di >= 0.0) || !(ci < 0.0)) return false;
   const double s = sqrt(di);
   const double tf = s - b;
   const V3 q = axpy(tf, v, p);

@@ -222,8 +222,15 @@ static int next_hit(const geom* g, v3 p, v3 v, int on, v3* q_out) {
     double s = sqrt(di);
     double tn = -b - s, tf = s - b;
     /* Rule S1: a ray inside (or on, heading into) the inner ball whose far root lies on
-     * the mirror patch hits there; nothing else can be nearer. */
-    if ((on == K_INNER && b < 0.0) || (on == K_NONE && ci < 0.0)) {
+     * the mirror patch hits there; nothing else can be nearer.
+     * Rule S1': leaving the inner sphere inwards the far root is taken as -2b (the root of
+     * t^2 + 2bt = 0: p is on the sphere, |v| = 1 to rounding thanks to the Newton step in
+     * interact()); |q|-r_in then random-walks at the 1e-16 level instead of being re-solved,
+     * and the bounce needs no square root. */
+    if (on == K_INNER && b < 0.0) {
+      v3 q = axpy(-2.0 * b, v, p);
+      if (q.z >= g->zcut_in) { *q_out = q; return K_INNER; }
+    } else if (on == K_NONE && ci < 0.0) {
       v3 q = axpy(tf, v, p);
       if (q.z >= g->zcut_in) { *q_out = q; return K_INNER; }
     }
