@@ -81,8 +81,11 @@ def main():
         raise SystemExit("bench.py needs a GPU (no CPU fallback exists in the product path)")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    # ISX_FORCE_DIST=1 exercises the RCCL code path even with one rank (rehearsal on a 1-GPU box)
+    use_dist = world > 1 or os.environ.get("ISX_FORCE_DIST") == "1"
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29517")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     import altair_raytracing_amd as isx
@@ -96,7 +99,7 @@ def main():
     hist_dev = torch.zeros(nb, dtype=torch.int64, device=dev)
 
     def barrier():
-        if world > 1:
+        if use_dist:
             dist.barrier(device_ids=[local_rank])
         torch.cuda.synchronize()
 
@@ -115,7 +118,7 @@ def main():
             mode = "device" if np.array_equal(probe.cpu().numpy().astype(np.uint64), want.reshape(-1)) else "host"
         except Exception:
             mode = "host"
-    if world > 1:
+    if use_dist:
         flag = torch.tensor([1 if mode == "device" else 0], device=dev)
         dist.all_reduce(flag, op=dist.ReduceOp.MIN)
         mode = "device" if int(flag.item()) == 1 else "host"
@@ -134,7 +137,7 @@ def main():
         else:
             h, st = isx.fluxmap(cfg, n, a.seed, first)
             hist_dev.copy_(torch.from_numpy(h.reshape(-1).astype(np.int64)))
-        if world > 1:
+        if use_dist:
             dist.all_reduce(hist_dev, op=dist.ReduceOp.SUM)
         kernel_ms.append(st.t_kernel_ms)
         census.append(st)
@@ -151,7 +154,7 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     t = torch.tensor([dt], dtype=torch.float64, device=dev)
-    if world > 1:
+    if use_dist:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     dt = float(t.item())
 
@@ -203,7 +206,7 @@ def main():
             out["cpu_baseline"] = cpu_baseline(a.seed, a.cpu_rays)
         print(json.dumps(out))
     isx.shutdown()
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 
