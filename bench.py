@@ -67,6 +67,11 @@ def cpu_baseline(seed, n_req):
 
 def main():
     a = parse()
+    # RCCL (NCCL_DEBUG=VERSION on some boxes) and HIP print banners on fd 1; the contract is ONE JSON line on
+    # stdout, so everything else is routed to stderr and the real stdout is kept for the final print.
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -204,7 +209,8 @@ def main():
         }
         if world == 1 and a.cpu_rays != 0:
             out["cpu_baseline"] = cpu_baseline(a.seed, a.cpu_rays)
-        print(json.dumps(out))
+        sys.stdout.flush()
+        os.write(real_stdout, (json.dumps(out) + "\n").encode())
     isx.shutdown()
     if use_dist:
         dist.destroy_process_group()
