@@ -42,7 +42,6 @@ struct State {
   // timing of enqueued-but-not-collected launches
   std::vector<hipEvent_t> ev_pool;
   size_t ev_used = 0;
-  uint64_t launched_pending = 0;
 } S;
 
 #define HIPCHK(expr)                                 \
@@ -278,7 +277,6 @@ int enqueue(int sink, const isx_config* c, uint64_t n, uint64_t seed, uint64_t f
   else hipLaunchKernelGGL(isx_trace_log_kernel, dim3(grid), dim3(kBlock), lds, S.stream, g, d, wk);
   HIPCHK(hipGetLastError());
   HIPCHK(hipEventRecord(e1, S.stream));
-  S.launched_pending += n;
   return ISX_OK;
 }
 
@@ -304,7 +302,6 @@ int collect_stats(isx_stats* out) {
   unsigned long long h[8];
   HIPCHK(hipMemcpy(h, S.d_stats, sizeof(h), hipMemcpyDeviceToHost));
   HIPCHK(hipMemset(S.d_stats, 0, sizeof(h)));
-  S.launched_pending = 0;
   if (out) {
     out->launched = h[0]; out->exited = h[1]; out->counted_below_z = h[2]; out->absorbed = h[3];
     out->suspended = h[4]; out->bin_increments = h[5]; out->wall_hits = h[6];

@@ -453,7 +453,7 @@ __device__ __forceinline__ void persistent_body(const Geom& g_arg, const DetGrid
       }
       const unsigned long long pm = __ballot(parked);
       if (pm) {
-        const bool flush = (__popcll(pm) >= sched_min) || ((iter & (uint32_t)sched_mask) == (uint32_t)sched_mask) ||
+        const bool flush = ((int)__popcll(pm) >= sched_min) || ((iter & (uint32_t)sched_mask) == (uint32_t)sched_mask) ||
                            (__ballot(alive && !parked) == 0ull);
         if (flush && parked) {
           kind = next_hit_generic(g, r.p, r.v, r.on, q);
