@@ -78,6 +78,9 @@ int prepare_geom(const isx_config* c, Geom* g) {
   if (c->surface_model != ISX_SURFACE_ROBAST && c->surface_model != ISX_SURFACE_LOBE) return ISX_ERR_BAD_CONFIG;
   if (c->hit_line_mode != ISX_HITLINE_LAST_SEGMENT && c->hit_line_mode != ISX_HITLINE_ORIGIN_COMPAT) return ISX_ERR_BAD_CONFIG;
   g->surface_model = c->surface_model;
+  if (c->trace_mode != ISX_TRACE_EXPLICIT && c->trace_mode != ISX_TRACE_CHORD) return ISX_ERR_BAD_CONFIG;
+  g->chord = c->trace_mode; g->pad2 = 0;
+  g->r_in = c->r_in;
   g->sched_mask = S.sched_mask;
   g->sched_min = S.sched_min;
   for (int k = 0; k < 3; ++k) g->src[k] = c->src[k];
@@ -263,13 +266,16 @@ int enqueue(int sink, const isx_config* c, uint64_t n, uint64_t seed, uint64_t f
   // the lean kernel serves the headline configuration; anything else takes the full-featured variant
   const bool lean = c->lambertian && c->surface_model == ISX_SURFACE_ROBAST && c->source_model == ISX_SOURCE_PENCIL &&
                     c->hit_line_mode == ISX_HITLINE_LAST_SEGMENT;
-  const void* fn = sink == SINK_FLUX ? (lean ? (const void*)isx_trace_bin_kernel : (const void*)isx_trace_bin_full_kernel)
+  const bool chord = lean && c->trace_mode == ISX_TRACE_CHORD;
+  const void* fn = sink == SINK_FLUX ? (chord ? (const void*)isx_trace_bin_chord_kernel
+                                        : lean ? (const void*)isx_trace_bin_kernel : (const void*)isx_trace_bin_full_kernel)
                    : sink == SINK_DZ ? (const void*)isx_trace_dz_kernel
                    : sink == SINK_DISC ? (const void*)isx_trace_disc_kernel
                    : sink == SINK_PERPOS ? (const void*)isx_trace_perpos_kernel : (const void*)isx_trace_log_kernel;
   HIPCHK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   HIPCHK(hipEventRecord(e0, S.stream));
-  if (sink == SINK_FLUX && lean) hipLaunchKernelGGL(isx_trace_bin_kernel, dim3(grid), dim3(kBlock), lds, S.stream, g, d, wk);
+  if (sink == SINK_FLUX && chord) hipLaunchKernelGGL(isx_trace_bin_chord_kernel, dim3(grid), dim3(kBlock), lds, S.stream, g, d, wk);
+  else if (sink == SINK_FLUX && lean) hipLaunchKernelGGL(isx_trace_bin_kernel, dim3(grid), dim3(kBlock), lds, S.stream, g, d, wk);
   else if (sink == SINK_FLUX) hipLaunchKernelGGL(isx_trace_bin_full_kernel, dim3(grid), dim3(kBlock), lds, S.stream, g, d, wk);
   else if (sink == SINK_DZ) hipLaunchKernelGGL(isx_trace_dz_kernel, dim3(grid), dim3(kBlock), lds, S.stream, g, d, wk);
   else if (sink == SINK_DISC) hipLaunchKernelGGL(isx_trace_disc_kernel, dim3(grid), dim3(kBlock), lds, S.stream, g, d, wk);

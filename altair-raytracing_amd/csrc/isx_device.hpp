@@ -29,20 +29,23 @@ struct Geom {
   double brdf_theta_scale;  // rough * M_PI / 6   (nonLambertianFlux.C:178)
   double brdf_spec;         // specular/(specular+diffuse) (:157-159)
   int lambertian, limit, source_model, surface_model;
-  int sched_mask, sched_min;  // generic-search batching: flush when (iter & mask) == mask or >= min lanes parked
+  int sched_mask, sched_min;
+  int chord, pad2;          // ISX_TRACE_CHORD
+  double r_in;  // generic-search batching: flush when (iter & mask) == mask or >= min lanes parked
 };
 
 // The handful of constants the hot loop needs; kept in SGPRs.  Everything else of Geom is read
 // on demand from an LDS copy (a `const volatile Geom&`), so it never occupies scalar registers
 // across the loop (SGPR spills were >10 % of the issued instructions before this split).
 struct Hot {
-  double rin2, zcut_in, ninv_rin, rho;
-  int lambertian, limit, source_model, surface_model;
+  double rin2, zcut_in, ninv_rin, rho, r_in;
+  int lambertian, limit, source_model, surface_model, chord;
 };
 __device__ __forceinline__ Hot make_hot(const Geom& g) {
   Hot h;
   h.rin2 = g.rin2; h.zcut_in = g.zcut_in; h.ninv_rin = g.ninv_rin; h.rho = g.rho;
   h.lambertian = g.lambertian; h.limit = g.limit; h.source_model = g.source_model; h.surface_model = g.surface_model;
+  h.r_in = g.r_in; h.chord = g.chord;
   return h;
 }
 
@@ -366,6 +369,23 @@ __device__ __forceinline__ V3 surface_normal(const Hot& h, const G& g, int kind,
 }
 
 // returns false if absorbed; otherwise v is the re-emitted direction
+// ISX_TRACE_CHORD: Lambertian bounce off the inner sphere via the integrating-sphere identity - for cosine-law
+// emission from a point of a sphere the far intersection is uniform over the sphere's area, so the next wall
+// point T is sampled directly: no direction, no orthonormal basis, no intersection.  Same Philox words as the
+// explicit bounce (w0,w1 -> point, w2 -> absorb).  Returns false if absorbed.
+__device__ __forceinline__ bool interact_chord(const Hot& h, V3& T, uint64_t seed, uint64_t ray, uint32_t j, uint32_t stream) {
+  uint32_t wl[4];
+  draw_block(seed, ray, 2u * j, stream, wl);
+  if (!(u01(wl[2]) < h.rho)) return false;
+  const double zz = fma(-2.0, u01(wl[0]), 1.0);
+  const double s2 = sqrt(fma(-zz, zz, 1.0));
+  double sf, cf;
+  sincos2pi(u01(wl[1]), sf, cf);
+  const double rxy = h.r_in * s2;
+  T.x = rxy * cf; T.y = rxy * sf; T.z = h.r_in * zz;
+  return true;
+}
+
 // LEAN = the configuration of the headline path (ROBAST Lambertian border, pencil source): the other surface
 // models are compiled out so their registers and code do not burden the hot kernel.
 template <bool LEAN, class G>

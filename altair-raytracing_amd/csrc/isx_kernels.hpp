@@ -268,36 +268,60 @@ struct Ray {
   uint32_t j;       // mirror interactions of the current trace; track points = j + 1 (+1 once it left the box)
   int on;
   int phase;        // 0 primary, 2 scattered (source_model 1)
+  bool tgt;         // ISX_TRACE_CHORD: v holds the next wall point T, not a direction
 };
 
 template <class G>
 __device__ __forceinline__ void ray_start(const G& g, Ray& r, uint64_t id) {
-  r.id = id; r.j = 0; r.on = K_NONE; r.phase = 0;
+  r.id = id; r.j = 0; r.on = K_NONE; r.phase = 0; r.tgt = false;
   r.p.x = g.src[0]; r.p.y = g.src[1]; r.p.z = g.src[2];
   r.v.x = g.dir0[0]; r.v.y = g.dir0[1]; r.v.z = g.dir0[2];
 }
 
 // Second half of a step, once the boundary (kind, q) is known: advance, interact.
+// CH: 0 explicit bounces only, 1 chord identity for every eligible bounce (compile time), 2 decided by h.chord.
 // Returns 0 while running, else the end status of the CURRENT trace.
-template <bool KEEP_PREV, bool LEAN, class G>
+template <bool KEEP_PREV, bool LEAN, int CH, class G>
 __device__ __forceinline__ int ray_arrive(const Hot& h, const G& g, Ray& r, uint64_t seed, int kind, const V3& q) {
   if (KEEP_PREV) r.prev = r.p;
   r.p = q;
   if (kind == K_BOX) { r.on = K_BOX; return ST_EXITED; }
   r.on = kind;
-  const bool alive = interact<LEAN>(h, g, kind, q, r.v, seed, r.id, r.j, (uint32_t)r.phase);
+  bool alive;
+  const bool eligible = (kind == K_INNER) && (LEAN || (h.lambertian && h.surface_model == 0));
+  if (CH != 0 && eligible && (CH == 1 || h.chord)) {
+    alive = interact_chord(h, r.v, seed, r.id, r.j, (uint32_t)r.phase);
+    r.tgt = alive;
+  } else {
+    alive = interact<LEAN>(h, g, kind, q, r.v, seed, r.id, r.j, (uint32_t)r.phase);
+  }
   r.j++;
   if (!alive) return ST_ABSORBED;
   if ((int)r.j + 1 > h.limit) return ST_SUSPENDED;  // npoints = j + 1 after this interaction
   return 0;
 }
 
-// One full step: next boundary + interaction.
+// Chord-mode arrival: the lane holds a target point T in r.v.  Returns true if T is on the mirror patch (then
+// q = T, and r.v becomes the un-normalised last chord); false if T lies in the port opening (then r.v becomes
+// the unit direction P->T and the generic boundary search takes over).
+__device__ __forceinline__ bool chord_arrive(const Hot& h, Ray& r, V3& q) {
+  V3 d;
+  d.x = r.v.x - r.p.x; d.y = r.v.y - r.p.y; d.z = r.v.z - r.p.z;
+  r.tgt = false;
+  if (r.v.z >= h.zcut_in) { q = r.v; r.v = d; return true; }
+  const double mag = sqrt(dot3(d, d));
+  r.v.x = d.x / mag; r.v.y = d.y / mag; r.v.z = d.z / mag;
+  return false;
+}
+
+// One full step: next boundary + interaction (chord mode decided at run time).
 template <bool KEEP_PREV, class G>
 __device__ __forceinline__ int ray_step(const Hot& h, const G& g, Ray& r, uint64_t seed) {
   V3 q;
-  const int kind = next_hit(h, g, r.p, r.v, r.on, q);
-  return ray_arrive<KEEP_PREV, false>(h, g, r, seed, kind, q);
+  int kind;
+  if (r.tgt && chord_arrive(h, r, q)) kind = K_INNER;
+  else kind = next_hit(h, g, r.p, r.v, r.on, q);
+  return ray_arrive<KEEP_PREV, false, 2>(h, g, r, seed, kind, q);
 }
 
 // nonLambertianFlux.C:253-268: restart from the primary's last point along a BRDF-sampled direction
@@ -309,7 +333,7 @@ __device__ __forceinline__ void ray_rescatter(const G& g, Ray& r, uint64_t seed)
   const double mag = sqrt(nd.x * nd.x + nd.y * nd.y + nd.z * nd.z);
   r.v.x = nd.x / mag; r.v.y = nd.y / mag; r.v.z = nd.z / mag;
   r.on = (r.on == K_BOX) ? K_NONE : r.on;
-  r.j = 0; r.phase = 2;
+  r.j = 0; r.phase = 2; r.tgt = false;
 }
 
 // ------------------------------------------------------------------ physical disc test (SINK_DISC)
@@ -364,7 +388,7 @@ __device__ __forceinline__ uint32_t bin_discs(const DG& dd, uint32_t* __restrict
 //   SINK_FLUX: 180x90 detector flux map (the headline path)
 //   SINK_DZ  : histogram of the exit direction's z component (distributionSphereDetectorSweep.C:54,91)
 //   SINK_DISC: physical disc sweep (integratingSphereDetectorSweep.C)
-template <int SINK, bool LEAN = false>
+template <int SINK, bool LEAN = false, int CH = 2>
 __device__ __forceinline__ void persistent_body(const Geom& g_arg, const DetGrid& d_arg, const Work& wk) {
   extern __shared__ __align__(16) unsigned char smem[];
   uint32_t* hist = reinterpret_cast<uint32_t*>(smem);
@@ -448,7 +472,10 @@ __device__ __forceinline__ void persistent_body(const Geom& g_arg, const DetGrid
       int kind = K_NONE;
       bool arrived = false;
       if (alive && !parked) {
-        if (next_hit_s1(h, r.p, r.v, r.on, q)) { kind = K_INNER; arrived = true; }
+        if (CH != 0 && r.tgt) {
+          if (chord_arrive(h, r, q)) { kind = K_INNER; arrived = true; }
+          else parked = true;
+        } else if (next_hit_s1(h, r.p, r.v, r.on, q)) { kind = K_INNER; arrived = true; }
         else parked = true;
       }
       const unsigned long long pm = __ballot(parked);
@@ -463,7 +490,7 @@ __device__ __forceinline__ void persistent_body(const Geom& g_arg, const DetGrid
       }
       iter++;
       if (arrived) {
-        int st = ray_arrive<SINK == SINK_DISC, LEAN>(h, g, r, seed, kind, q);
+        int st = ray_arrive<SINK == SINK_DISC, LEAN, CH>(h, g, r, seed, kind, q);
         if (!LEAN && st != 0 && h.source_model == 1 && r.phase == 0) {
           n_wall += r.j;
           ray_rescatter(g, r, seed);
@@ -587,10 +614,13 @@ __device__ __forceinline__ void persistent_body(const Geom& g_arg, const DetGrid
 }
 
 extern "C" __global__ void ISX_KERNEL_ATTR
-isx_trace_bin_kernel(const Geom g, const DetGrid d, const Work wk) { persistent_body<SINK_FLUX, true>(g, d, wk); }
+isx_trace_bin_kernel(const Geom g, const DetGrid d, const Work wk) { persistent_body<SINK_FLUX, true, 0>(g, d, wk); }
+// the same path with ISX_TRACE_CHORD compiled in (next wall point sampled directly)
+extern "C" __global__ void ISX_KERNEL_ATTR
+isx_trace_bin_chord_kernel(const Geom g, const DetGrid d, const Work wk) { persistent_body<SINK_FLUX, true, 1>(g, d, wk); }
 // every surface / source / hit-line model (BRDF re-scatter, cos^2 lobe, rough specular, origin-compat line)
 extern "C" __global__ void ISX_KERNEL_ATTR
-isx_trace_bin_full_kernel(const Geom g, const DetGrid d, const Work wk) { persistent_body<SINK_FLUX, false>(g, d, wk); }
+isx_trace_bin_full_kernel(const Geom g, const DetGrid d, const Work wk) { persistent_body<SINK_FLUX, false, 2>(g, d, wk); }
 extern "C" __global__ void ISX_KERNEL_ATTR
 isx_trace_dz_kernel(const Geom g, const DetGrid d, const Work wk) { persistent_body<SINK_DZ>(g, d, wk); }
 extern "C" __global__ void ISX_KERNEL_ATTR

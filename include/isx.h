@@ -53,6 +53,14 @@ typedef enum isx_status {
 #define ISX_SURFACE_ROBAST 0 /* ABorderSurfaceCondition: Lambertian if `lambertian`, else rough specular   */
 #define ISX_SURFACE_LOBE 1   /* "nonLambertianFlux copy.C":31-70,188-221 NonLambertianSurface: cos^2 lobe
                                 within 60 deg of the normal by rejection sampling (the de-facto CustomMirror) */
+/* trace_mode: how a Lambertian bounce off the INNER SPHERE finds the next wall point */
+#define ISX_TRACE_EXPLICIT 0 /* sample a cosine-law direction, intersect the ray with the sphere              */
+#define ISX_TRACE_CHORD 1    /* integrating-sphere identity: for cosine-law emission from a point of a sphere
+                                the far intersection is UNIFORM over the sphere's area, so the next wall point
+                                is sampled directly (1 sqrt + 1 sincos, no direction, no intersection); the
+                                direction is only formed when the point falls in the port opening.  Same
+                                distribution, different random history; rim/outer-sphere/non-Lambertian
+                                interactions are always explicit. */
 /* hit_line_mode: which line Detector::checkIntersection sees */
 #define ISX_HITLINE_LAST_SEGMENT 0 /* last point + final direction (fluxAtObserverOptimize.C:309; canonical)   */
 #define ISX_HITLINE_ORIGIN_COMPAT 1 /* what fluxAtObserverFast.C:1181-1201,1285-1288 effectively used because
@@ -86,7 +94,7 @@ typedef struct isx_config {
   int32_t surface_model; /* ISX_SURFACE_*                                             */
   double brdf[3];        /* BRDF(roughness, specular, diffuse) nonLambertianFlux.C:211 */
   int32_t hit_line_mode; /* ISX_HITLINE_*                                             */
-  int32_t reserved1;
+  int32_t trace_mode;    /* ISX_TRACE_*                                               */
 } isx_config;
 
 /* Ray census of one call (all ranks' census add up). */

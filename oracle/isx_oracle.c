@@ -164,7 +164,8 @@ enum { K_NONE = 0, K_INNER = 1, K_OUTER = 2, K_CONE = 3, K_BOX = 4 };
 
 typedef struct {
   double rin2, rout2, zcut_in, zcut_out, k2, ninv_rin, inv_rout, H, rho, sigma;
-  int lambertian, limit, surface_model;
+  int lambertian, limit, surface_model, chord;
+  double r_in;
   v3 src, dir0;
 } geom;
 
@@ -189,6 +190,9 @@ static int prepare(const isxo_config* c, geom* g) {
   g->lambertian = c->lambertian;
   g->limit = c->max_points;
   g->surface_model = c->surface_model;
+  if (c->trace_mode != 0 && c->trace_mode != 1) return -2;
+  g->chord = c->trace_mode;
+  g->r_in = c->r_in;
   if (c->surface_model != 0 && c->surface_model != 1) return -2;
   if (c->hit_line_mode != 0 && c->hit_line_mode != 1) return -2;
   g->src.x = c->src[0]; g->src.y = c->src[1]; g->src.z = c->src[2];
@@ -409,25 +413,65 @@ static int interact(const geom* g, int kind, v3 q, v3* v, uint64_t seed, uint64_
   return 1;
 }
 
-typedef struct { int status, npts, on; v3 p, v; uint64_t wall_hits; } endstate;
+typedef struct { int status, npts, on; v3 p, v, prev; uint64_t wall_hits; } endstate;  /* prev: start of the last segment */
+
+/* ISX_TRACE_CHORD: Lambertian bounce off the inner sphere.  For cosine-law emission from a point of a
+ * sphere the far intersection is uniformly distributed over the sphere (the integrating-sphere identity:
+ * the form factor between two surface elements of a sphere does not depend on where they are), so the next
+ * wall point T is sampled directly.  Same Philox words as the explicit bounce: w0,w1 -> point, w2 -> absorb.
+ * Returns 0 if absorbed. */
+static int interact_chord(const geom* g, v3* T, uint64_t seed, uint64_t ray, uint32_t j, uint32_t stream) {
+  uint32_t wl[4];
+  draw_block(seed, ray, 2u * j, stream, wl);
+  if (!(isxo_u01(wl[2]) < g->rho)) return 0;
+  double zz = fma(-2.0, isxo_u01(wl[0]), 1.0);
+  double s2 = sqrt(fma(-zz, zz, 1.0));
+  double sf, cf;
+  isxo_sincos2pi(isxo_u01(wl[1]), &sf, &cf);
+  double rxy = g->r_in * s2;
+  T->x = rxy * cf; T->y = rxy * sf; T->z = g->r_in * zz;
+  return 1;
+}
 
 static void trace_one(const geom* g, uint64_t seed, uint64_t ray, uint32_t stream, v3 p, v3 v, int on, endstate* out) {
   int npts = 1;
   uint32_t j = 0;
   int status;
+  int tgt = 0;   /* chord mode: v holds the next wall point T instead of a direction */
+  v3 prev = p;
   for (;;) {
     v3 q;
-    int kind = next_hit(g, p, v, on, &q);
+    int kind;
+    prev = p;
+    if (tgt) {
+      v3 d = { v.x - p.x, v.y - p.y, v.z - p.z };  /* chord P -> T */
+      tgt = 0;
+      if (v.z >= g->zcut_in) {
+        kind = K_INNER; q = v; v = d;              /* arrived; v keeps the (unnormalised) last chord */
+      } else {                                     /* T lies in the port opening: leave along the chord */
+        double mag = sqrt(dot3(d, d));
+        v.x = d.x / mag; v.y = d.y / mag; v.z = d.z / mag;
+        kind = next_hit(g, p, v, on, &q);
+      }
+    } else {
+      kind = next_hit(g, p, v, on, &q);
+    }
     p = q;
     npts++;
     if (kind == K_BOX) { status = ISXO_EXITED; on = K_BOX; break; }
     on = kind;
-    int alive = interact(g, kind, q, &v, seed, ray, j, stream);
+    int alive;
+    if (g->chord && kind == K_INNER && g->lambertian && g->surface_model == 0) {
+      alive = interact_chord(g, &v, seed, ray, j, stream);
+      tgt = alive;
+    } else {
+      alive = interact(g, kind, q, &v, seed, ray, j, stream);
+    }
     j++;
     if (!alive) { status = ISXO_ABSORBED; break; }
     if (npts > g->limit) { status = ISXO_SUSPENDED; break; }
   }
-  out->status = status; out->npts = npts; out->on = on; out->p = p; out->v = v; out->wall_hits = j;
+  out->status = status; out->npts = npts; out->on = on; out->p = p; out->v = v; out->prev = prev; out->wall_hits = j;
 }
 
 /* ------------------------------------------------------------------------- */
@@ -845,24 +889,9 @@ int isxo_disc_sweep(const isxo_config* c, const double* ca, int32_t nd, double r
     for (int64_t i = 0; i < (int64_t)n; i++) {
       /* the last mirror point and the exit direction define the forward segment */
       endstate es;
-      v3 p = g.src, v = g.dir0;
-      int on = K_NONE, npts = 1, status;
-      uint32_t j = 0;
-      v3 seg_start = p;
-      for (;;) {
-        v3 q;
-        int kind = next_hit(&g, p, v, on, &q);
-        seg_start = p;
-        p = q;
-        npts++;
-        if (kind == K_BOX) { status = ISXO_EXITED; break; }
-        on = kind;
-        int alive = interact(&g, kind, q, &v, seed, first + (uint64_t)i, j, 0u);
-        j++;
-        if (!alive) { status = ISXO_ABSORBED; break; }
-        if (npts > g.limit) { status = ISXO_SUSPENDED; break; }
-      }
-      es.status = status; es.npts = npts; es.p = p; es.v = v; es.wall_hits = j; es.on = on;
+      trace_one(&g, seed, first + (uint64_t)i, 0u, g.src, g.dir0, K_NONE, &es);
+      const int status = es.status;
+      const v3 seg_start = es.prev, p = es.p, v = es.v;
       int counted;
       census(&es, c->exit_port_z, &st, &counted);
       if (status == ISXO_EXITED) {

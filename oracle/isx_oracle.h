@@ -32,7 +32,7 @@ typedef struct isxo_config {
   double det_diameter, det_distance, exit_port_z;
   int32_t source_model, surface_model;
   double brdf[3];
-  int32_t hit_line_mode, reserved1;
+  int32_t hit_line_mode, trace_mode;
 } isxo_config;
 
 typedef struct isxo_stats {

@@ -26,7 +26,7 @@ class Config(C.Structure):
         ("det_diameter", C.c_double), ("det_distance", C.c_double), ("exit_port_z", C.c_double),
         ("source_model", C.c_int32), ("surface_model", C.c_int32),
         ("brdf", C.c_double * 3),
-        ("hit_line_mode", C.c_int32), ("reserved1", C.c_int32),
+        ("hit_line_mode", C.c_int32), ("trace_mode", C.c_int32),
     ]
 
     def copy(self):

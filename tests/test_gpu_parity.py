@@ -46,6 +46,15 @@ def _cfg_variants(mod):
     out.append(("lobe_surface", c))
     c = mod.default_config(); c.surface_model = 1; c.source_model = 1; c.reflectance = 1.0; c.max_points = 10000; c.box_half = 200.0
     out.append(("lobe_surface_brdf_source", c))
+    # integrating-sphere identity (next wall point sampled directly)
+    c = mod.default_config(); c.trace_mode = 1
+    out.append(("chord_baseline", c))
+    c = mod.default_config(); c.trace_mode = 1; c.theta_max_deg = 160.0; c.reflectance = 1.0; c.max_points = 300
+    out.append(("chord_port160_limit300", c))
+    c = mod.default_config(); c.trace_mode = 1; c.source_model = 1; c.reflectance = 0.98
+    out.append(("chord_brdf_source", c))
+    c = mod.default_config(); c.trace_mode = 1; c.lambertian = 0; c.roughness_rad = 0.2; c.reflectance = 0.9   # not eligible: stays explicit
+    out.append(("chord_requested_on_specular", c))
     return out
 
 
@@ -92,7 +101,7 @@ def test_detector_table_bit_exact(isx, orc):
     assert np.array_equal(_bits(isx.detector_table(isx.default_config())), _bits(orc.detector_table(orc.default_config())))
 
 
-@pytest.mark.parametrize("idx", range(12))
+@pytest.mark.parametrize("idx", range(16))
 def test_endstates_bit_exact(isx, orc, idx):
     name, cg = _cfg_variants(isx)[idx]
     _, co = _cfg_variants(orc)[idx]
@@ -111,7 +120,7 @@ def _census_equal(a, b):
 
 
 @pytest.mark.parametrize("bin_mode", [0, 1])
-@pytest.mark.parametrize("idx", [0, 1, 3, 8, 10])
+@pytest.mark.parametrize("idx", [0, 1, 3, 8, 10, 12, 14])
 def test_fluxmap_bit_exact_small(isx, orc, idx, bin_mode):
     """BASELINE config 1 size (5e4 rays) and variants; brute and culled binning."""
     name, cg = _cfg_variants(isx)[idx]
@@ -360,3 +369,57 @@ def test_origin_compat_hit_line_bit_exact(isx, orc):
     gp, _ = isx.fluxmap_per_position(cg, 2000, 5)
     op, _ = orc.fluxmap_per_position(co, 2000, 5)
     assert np.array_equal(gp, op)
+
+
+def test_chord_mode_all_sinks_bit_exact(isx, orc):
+    """ISX_TRACE_CHORD through every entry point against the oracle in the same mode."""
+    def mk(mod, **kw):
+        c = mod.default_config(); c.trace_mode = 1
+        for k, v in kw.items():
+            setattr(c, k, v)
+        return c
+    gh, gst = isx.fluxmap(mk(isx), 300000, 2024, 55)
+    oh, ost = orc.fluxmap(mk(orc), 300000, 2024, 55)
+    assert np.array_equal(gh, oh)
+    _census_equal(gst, ost)
+    gp, gps = isx.fluxmap_per_position(mk(isx, n_theta=12, n_phi=10), 600, 3, 2)
+    op, ops = orc.fluxmap_per_position(mk(orc, n_theta=12, n_phi=10), 600, 3, 2)
+    assert np.array_equal(gp, op)
+    _census_equal(gps, ops)
+    gz, _ = isx.exit_dz_hist(mk(isx), 200000, 8, 100)
+    oz, _ = orc.exit_dz_hist(mk(orc), 200000, 8, 100)
+    assert np.array_equal(gz, oz)
+    gi, gd, gc, _ = isx.exit_directions(mk(isx), 50000, 8)
+    oi, od, oc = orc.exit_directions(mk(orc), 50000, 8)
+    assert gc == oc and np.array_equal(gi, oi) and np.array_equal(_bits(gd), _bits(od))
+    ca = np.array([[0.0, 0.0, -200.0, 0.0, 0.0, 1.0], [68.4, 0.0, -187.9, -0.61, 0.0, 0.79]])
+    gdsk, _ = isx.disc_sweep(mk(isx, r_out=105.0, reflectance=1.0, max_points=10000, box_half=200.0), ca, 5.0, 0.1, 150000, 4)
+    odsk, _ = orc.disc_sweep(mk(orc, r_out=105.0, reflectance=1.0, max_points=10000, box_half=200.0), ca, 5.0, 0.1, 150000, 4)
+    assert np.array_equal(gdsk, odsk)
+    # culled == brute in chord mode too
+    isx.set_option("bin_mode", 0)
+    try:
+        b, _ = isx.fluxmap(mk(isx), 2_000_000, 77)
+    finally:
+        isx.set_option("bin_mode", 1)
+    k, _ = isx.fluxmap(mk(isx), 2_000_000, 77)
+    assert np.array_equal(b, k)
+
+
+def test_chord_and_explicit_modes_agree_statistically(isx):
+    """Same physics, different random history: 2e7 rays each; census and every theta-row agree within noise."""
+    ce = isx.default_config()
+    cc = isx.default_config(); cc.trace_mode = 1
+    n = 20_000_000
+    he, se = isx.fluxmap(ce, n, 1)
+    hc, sc = isx.fluxmap(cc, n, 1)
+    assert not np.array_equal(he, hc)
+    pe, pc = se.counted_below_z / n, sc.counted_below_z / n
+    assert abs(pe - pc) < 5 * np.sqrt(2 * pe * (1 - pe) / n)
+    assert abs(se.wall_hits / sc.wall_hits - 1) < 1e-3
+    # row sums: each exiting ray adds ~270 correlated increments; allow 6 sigma of a compound-Poisson estimate
+    re, rc = he.sum(axis=1).astype(float), hc.sum(axis=1).astype(float)
+    sig = np.sqrt((re + rc) * 30.0)
+    z = np.abs(re - rc) / np.maximum(sig, 1.0)
+    assert z.max() < 6, (z.max(), int(z.argmax()))
+    assert abs(he.sum() / hc.sum() - 1) < 2e-3

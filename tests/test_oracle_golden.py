@@ -164,3 +164,23 @@ def test_lobe_surface_is_a_valid_diffuser(orc):
     assert 0.30 < frac < 0.55
     st2, npts2, lp2, d2 = orc.trace_endstates(c, 50000, 9)
     assert np.array_equal(lp, lp2) and np.array_equal(npts, npts2)
+
+
+def test_chord_mode_meets_the_same_fixtures(orc, golden):
+    """ISX_TRACE_CHORD (integrating-sphere identity) against the reference's exit counts and 8.1e8-ray map."""
+    for port in (170.0, 160.0):
+        runs = [e["exited"] / e["n"] for e in golden["exit_counts"] if e["port_deg"] == port]
+        c = orc.default_config(); c.theta_max_deg = port; c.trace_mode = 1
+        got = _exit_fraction(orc, c, 400_000)
+        assert abs(got - np.mean(runs)) < 0.004, (port, got)
+    m = [m for m in golden["per_position_maps"] if m["port_deg"] == 170.0 and m["source_direction"] == [5.0, 0.0, 0.0]][0]
+    c = orc.default_config(); c.trace_mode = 1
+    n = 400_000
+    h, _ = orc.fluxmap(c, n, SEED)
+    frac = h / n
+    assert abs(frac.sum() / m["sum_fraction"] - 1) < 0.02
+    prof, gold = frac.mean(axis=1), np.array(m["theta_profile"])
+    sig_ref = np.sqrt(np.maximum(gold, 1e-7) / (m["rays_per_position"] * m["n_phi"]))
+    sig_our = gold / np.sqrt(n * 0.42 * 0.2)
+    z = np.abs(prof - gold) / (np.hypot(sig_ref, sig_our) + 0.01 * gold)
+    assert z.max() < 5, (z.max(), int(z.argmax()))

@@ -16,6 +16,7 @@ if os.environ.get("ISX_QB_CHILD"):
     bpc = int(os.environ["ISX_QB_BPC"])
     isx.set_option("blocks_per_cu", bpc)
     cfg = isx.default_config()
+    cfg.trace_mode = int(os.environ.get("ISX_QB_TRACE_MODE", "0"))
     out = {}
     for k in ("sched_mask", "sched_min"):
         if os.environ.get("ISX_QB_" + k.upper()):
