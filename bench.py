@@ -35,6 +35,9 @@ def parse():
     ap.add_argument("--rays", type=int, default=50_000_000, help="rays per GPU per step (BASELINE configs[1])")
     ap.add_argument("--seed", type=lambda s: int(s, 0), default=0x5EED0001)
     ap.add_argument("--cpu-rays", type=int, default=-1, help="oracle sample size for cpu_baseline (0: skip, -1: auto)")
+    ap.add_argument("--trace-mode", choices=["explicit", "chord"], default="explicit",
+                    help="explicit: cosine direction + ray-sphere intersection per bounce (default, the reference-shaped "
+                         "algorithm); chord: ISX_TRACE_CHORD, next wall point sampled directly (same distribution)")
     ap.add_argument("--reduce", choices=["auto", "device", "host"], default="auto",
                     help="where the histogram lives for the all-reduce")
     return ap.parse_args()
@@ -98,6 +101,7 @@ def main():
     isx.init(local_rank)
     devname, cus = isx.device_info()
     cfg = isx.default_config()
+    cfg.trace_mode = 1 if a.trace_mode == "chord" else 0
     nb = cfg.n_theta * cfg.n_phi
     n = a.rays
 
@@ -191,7 +195,7 @@ def main():
                                    f"(BASELINE configs[1])",
                        "rays_per_gpu_per_step": n, "grid": [cfg.n_theta, cfg.n_phi], "seed": hex(a.seed),
                        "parallelism": f"rays sharded over {world} GPU(s), one RCCL all-reduce of the histogram",
-                       "reduce_path": mode, "device": devname},
+                       "reduce_path": mode, "trace_mode": a.trace_mode, "device": devname},
             "roofline": {"bound": "hbm", "achieved": hbm_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": hbm_gbs / HBM_PEAK_GBS, "traffic": traffic,
                          "kernel": "isx_trace_bin_kernel", "kernel_ms": k_ms, "algorithmic_bytes_per_launch": alg_bytes,
