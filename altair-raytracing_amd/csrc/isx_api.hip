@@ -44,6 +44,17 @@ struct State {
   size_t ev_used = 0;
 } S;
 
+// Scratch device allocation of one call: freed on every return path.
+template <class T>
+struct DevBuf {
+  T* p = nullptr;
+  hipError_t alloc(size_t n) { return hipMalloc(&p, n * sizeof(T)); }
+  ~DevBuf() { if (p) (void)hipFree(p); }
+  DevBuf() = default;
+  DevBuf(const DevBuf&) = delete;
+  DevBuf& operator=(const DevBuf&) = delete;
+};
+
 #define HIPCHK(expr)                                 \
   do {                                               \
     hipError_t e_ = (expr);                          \
@@ -460,41 +471,36 @@ int isx_trace_endstates(const isx_config* cfg, uint64_t n, uint64_t seed, uint64
   Geom g;
   int rc = prepare_geom(cfg, &g);
   if (rc) return rc;
-  int32_t *d_st = nullptr, *d_np = nullptr;
-  double *d_lp = nullptr, *d_dir = nullptr;
-  HIPCHK(hipMalloc(&d_st, n * 4));
-  HIPCHK(hipMalloc(&d_np, n * 4));
-  HIPCHK(hipMalloc(&d_lp, n * 24));
-  HIPCHK(hipMalloc(&d_dir, n * 24));
+  DevBuf<int32_t> b_st, b_np;
+  DevBuf<double> b_lp, b_dir;
+  HIPCHK(b_st.alloc(n)); HIPCHK(b_np.alloc(n)); HIPCHK(b_lp.alloc(n * 3)); HIPCHK(b_dir.alloc(n * 3));
+  int32_t *d_st = b_st.p, *d_np = b_np.p;
+  double *d_lp = b_lp.p, *d_dir = b_dir.p;
   const int blk = 256;
   const unsigned grid = (unsigned)((n + blk - 1) / blk);
   hipLaunchKernelGGL(isx_endstates_kernel, dim3(grid), dim3(blk), 0, S.stream, g, seed, first, n, d_st, d_np, d_lp, d_dir);
-  hipError_t e = hipGetLastError();
-  if (e == hipSuccess) e = hipMemcpyAsync(status, d_st, n * 4, hipMemcpyDeviceToHost, S.stream);
-  if (e == hipSuccess) e = hipMemcpyAsync(n_points, d_np, n * 4, hipMemcpyDeviceToHost, S.stream);
-  if (e == hipSuccess) e = hipMemcpyAsync(last_point, d_lp, n * 24, hipMemcpyDeviceToHost, S.stream);
-  if (e == hipSuccess) e = hipMemcpyAsync(direction, d_dir, n * 24, hipMemcpyDeviceToHost, S.stream);
-  if (e == hipSuccess) e = hipStreamSynchronize(S.stream);
-  (void)hipFree(d_st); (void)hipFree(d_np); (void)hipFree(d_lp); (void)hipFree(d_dir);
-  if (e != hipSuccess) { S.last_hip = (int)e; return ISX_ERR_HIP; }
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipMemcpyAsync(status, d_st, n * 4, hipMemcpyDeviceToHost, S.stream));
+  HIPCHK(hipMemcpyAsync(n_points, d_np, n * 4, hipMemcpyDeviceToHost, S.stream));
+  HIPCHK(hipMemcpyAsync(last_point, d_lp, n * 24, hipMemcpyDeviceToHost, S.stream));
+  HIPCHK(hipMemcpyAsync(direction, d_dir, n * 24, hipMemcpyDeviceToHost, S.stream));
+  HIPCHK(hipStreamSynchronize(S.stream));
   return ISX_OK;
 }
 
 int isx_mathprobe(int op, const double* a, const double* b, const double* c, double* out, int32_t n) {
   if (!S.init) return ISX_ERR_NOT_INIT;
   if (!a || !out || n <= 0) return ISX_ERR_BAD_ARG;
-  double *da = nullptr, *db = nullptr, *dc = nullptr, *dout = nullptr;
+  DevBuf<double> ba, bb, bc, bo;
   const size_t bytes = (size_t)n * 8;
-  HIPCHK(hipMalloc(&da, bytes)); HIPCHK(hipMalloc(&db, bytes)); HIPCHK(hipMalloc(&dc, bytes)); HIPCHK(hipMalloc(&dout, bytes));
-  HIPCHK(hipMemcpy(da, a, bytes, hipMemcpyHostToDevice));
-  HIPCHK(hipMemcpy(db, b ? b : a, bytes, hipMemcpyHostToDevice));
-  HIPCHK(hipMemcpy(dc, c ? c : a, bytes, hipMemcpyHostToDevice));
-  hipLaunchKernelGGL(isx_mathprobe_kernel, dim3((n + 255) / 256), dim3(256), 0, S.stream, op, da, db, dc, dout, n);
-  hipError_t e = hipGetLastError();
-  if (e == hipSuccess) e = hipStreamSynchronize(S.stream);
-  if (e == hipSuccess) e = hipMemcpy(out, dout, bytes, hipMemcpyDeviceToHost);
-  (void)hipFree(da); (void)hipFree(db); (void)hipFree(dc); (void)hipFree(dout);
-  if (e != hipSuccess) { S.last_hip = (int)e; return ISX_ERR_HIP; }
+  HIPCHK(ba.alloc(n)); HIPCHK(bb.alloc(n)); HIPCHK(bc.alloc(n)); HIPCHK(bo.alloc(n));
+  HIPCHK(hipMemcpy(ba.p, a, bytes, hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(bb.p, b ? b : a, bytes, hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(bc.p, c ? c : a, bytes, hipMemcpyHostToDevice));
+  hipLaunchKernelGGL(isx_mathprobe_kernel, dim3((n + 255) / 256), dim3(256), 0, S.stream, op, ba.p, bb.p, bc.p, bo.p, n);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipStreamSynchronize(S.stream));
+  HIPCHK(hipMemcpy(out, bo.p, bytes, hipMemcpyDeviceToHost));
   return ISX_OK;
 }
 
