@@ -423,3 +423,22 @@ def test_chord_and_explicit_modes_agree_statistically(isx):
     z = np.abs(re - rc) / np.maximum(sig, 1.0)
     assert z.max() < 6, (z.max(), int(z.argmax()))
     assert abs(he.sum() / hc.sum() - 1) < 2e-3
+
+
+def test_billion_rays_partition_invariance(isx, golden):
+    """BASELINE config 5 size on one GPU: 1e9 rays in one call == 8 'ranks' x 1.25e8 rays summed (what the 8-GPU
+    all-reduce computes), census included; total hits vs the reference's 8.1e8-ray map."""
+    c = isx.default_config()
+    n = 1_000_000_000
+    full, st = isx.fluxmap(c, n, 0x5EED0001)
+    acc = np.zeros_like(full)
+    counted = 0
+    for r in range(8):
+        h, s = isx.fluxmap(c, n // 8, 0x5EED0001, r * (n // 8))
+        acc += h
+        counted += s.counted_below_z
+    assert np.array_equal(full, acc)
+    assert st.counted_below_z == counted and st.launched == n == st.exited + st.absorbed + st.suspended
+    assert st.bin_increments == int(full.sum())
+    m = [m for m in golden["per_position_maps"] if m["port_deg"] == 170.0 and m["source_direction"] == [5.0, 0.0, 0.0]][0]
+    assert abs((full.sum() / n) / m["sum_fraction"] - 1) < 0.01
