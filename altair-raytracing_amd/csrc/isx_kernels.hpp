@@ -59,6 +59,10 @@ struct Work {
 #define ISX_WAVES_PER_EU 0   // 0: let the compiler choose
 #endif
 constexpr int kBlock = ISX_BLOCK;
+#ifndef ISX_STEPS
+#define ISX_STEPS 4
+#endif
+constexpr int kStepsPerTrip = ISX_STEPS;   // bounces attempted per trip of the persistent loop
 #if ISX_WAVES_PER_EU > 0
 #define ISX_KERNEL_ATTR __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(ISX_WAVES_PER_EU, ISX_WAVES_PER_EU)))
 #else
@@ -467,15 +471,38 @@ __device__ __forceinline__ void persistent_body(const Geom& g_arg, const DetGrid
     // need it, every 4th iteration, or nothing else is left to do.  Scheduling only - a ray's
     // history never depends on it.
     bool bin_me = false;
+    // what happens to a lane once its boundary (kind, q) is known
+    auto arrive = [&](int kind, const V3& q) {
+      int st = ray_arrive<SINK == SINK_DISC, LEAN, CH>(h, g, r, seed, kind, q);
+      if (!LEAN && st != 0 && h.source_model == 1 && r.phase == 0) {
+        n_wall += r.j;
+        ray_rescatter(g, r, seed);
+        st = 0;
+      }
+      if (st != 0) {
+        alive = false;
+        n_ended++;
+        n_wall += r.j;
+        if (n_wall > 0x7fffffffu) { atomicAdd(&sstat[6], (unsigned long long)n_wall); n_wall = 0; }
+        if (st == ST_EXITED) {
+          n_exited++;
+          const bool below = r.p.z < portz;  // isRayPassingThroughExitPort, fluxAtObserver.C:162-166
+          if (below) n_counted++;
+          bin_me = (SINK == SINK_DISC) ? true : below;
+        } else if (st == ST_SUSPENDED) n_susp++;
+      }
+    };
+    // hot boundary search of one lane: true if it arrived on the inner mirror patch, else the lane parks
+    auto hot_search = [&](V3& q) -> bool {
+      if (CH != 0 && r.tgt) return chord_arrive(h, r, q);
+      return next_hit_s1(h, r.p, r.v, r.on, q);
+    };
     {
       V3 q;
       int kind = K_NONE;
       bool arrived = false;
       if (alive && !parked) {
-        if (CH != 0 && r.tgt) {
-          if (chord_arrive(h, r, q)) { kind = K_INNER; arrived = true; }
-          else parked = true;
-        } else if (next_hit_s1(h, r.p, r.v, r.on, q)) { kind = K_INNER; arrived = true; }
+        if (hot_search(q)) { kind = K_INNER; arrived = true; }
         else parked = true;
       }
       const unsigned long long pm = __ballot(parked);
@@ -489,26 +516,18 @@ __device__ __forceinline__ void persistent_body(const Geom& g_arg, const DetGrid
         }
       }
       iter++;
-      if (arrived) {
-        int st = ray_arrive<SINK == SINK_DISC, LEAN, CH>(h, g, r, seed, kind, q);
-        if (!LEAN && st != 0 && h.source_model == 1 && r.phase == 0) {
-          n_wall += r.j;
-          ray_rescatter(g, r, seed);
-          st = 0;
-        }
-        if (st != 0) {
-          alive = false;
-          n_ended++;
-          n_wall += r.j;
-          if (n_wall > 0x7fffffffu) { atomicAdd(&sstat[6], (unsigned long long)n_wall); n_wall = 0; }
-          if (st == ST_EXITED) {
-            n_exited++;
-            const bool below = r.p.z < portz;  // isRayPassingThroughExitPort, fluxAtObserver.C:162-166
-            if (below) n_counted++;
-            bin_me = (SINK == SINK_DISC) ? true : below;
-          } else if (st == ST_SUSPENDED) n_susp++;
-        }
+      if (arrived) arrive(kind, q);
+    }
+    // extra bounces per loop trip (hot search only): amortises refill / flush / exit bookkeeping
+#pragma unroll
+    for (int rep = 1; rep < kStepsPerTrip; ++rep) {
+      V3 q;
+      bool arrived = false;
+      if (alive && !parked) {
+        if (hot_search(q)) arrived = true;
+        else parked = true;
       }
+      if (arrived) arrive(K_INNER, q);
     }
     if (SINK == SINK_LOG) {
       // wave-aggregated append: one atomic on the cursor per wave-step, 32-byte records
