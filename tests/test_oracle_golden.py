@@ -184,3 +184,24 @@ def test_chord_mode_meets_the_same_fixtures(orc, golden):
     sig_our = gold / np.sqrt(n * 0.42 * 0.2)
     z = np.abs(prof - gold) / (np.hypot(sig_ref, sig_our) + 0.01 * gold)
     assert z.max() < 5, (z.max(), int(z.argmax()))
+
+
+@pytest.mark.parametrize("mode", [0, 1])
+def test_wall_points_uniform_on_sphere(orc, mode):
+    """Known answer of the physics (no reference file needed): inside a Lambertian sphere the wall-hit points are
+    uniform over the sphere's area, so the z of the points where rays get absorbed is uniform on [z_cut, r_in]
+    (Archimedes).  Pins cosine emission + intersection in explicit mode and the direct sampling in chord mode."""
+    c = orc.default_config(); c.trace_mode = mode
+    st, npts, lp, _ = orc.trace_endstates(c, 300_000, 99)
+    r = np.linalg.norm(lp, axis=1)
+    sel = (st == 2) & (np.abs(r - c.r_in) < 1e-6) & (npts > 3)     # absorbed on the inner sphere, not at the first hit
+    z = lp[sel, 2]
+    zcut = c.r_in * np.cos(np.deg2rad(c.theta_max_deg))
+    hist, _ = np.histogram(z, bins=40, range=(zcut, c.r_in))
+    exp = sel.sum() / 40.0
+    chi2 = ((hist - exp) ** 2 / exp).sum()
+    assert chi2 < 80, chi2            # 39 dof: mean 39, 99.99 % quantile ~ 80
+    # azimuth uniform too
+    phi = np.arctan2(lp[sel, 1], lp[sel, 0])
+    h2, _ = np.histogram(phi, bins=36, range=(-np.pi, np.pi))
+    assert ((h2 - sel.sum() / 36.0) ** 2 / (sel.sum() / 36.0)).sum() < 75
