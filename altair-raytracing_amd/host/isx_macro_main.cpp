@@ -3,6 +3,9 @@
 // e.g. isx_macro fluxAtObserverFast::sweepDetectorTraceOnce folder=out srcZ=-75 dirY=0 thetaMax=170
 // (what `root -l -b -q 'fluxAtObserverFast.C+' -e 'sweepDetectorTraceOnce(...)'` did in the reference).
 // Environment: ISX_DEVICE, ISX_SEED, ISX_RAYS (override the macro's hard-coded ray count), ISX_QUIET.
+#include <sys/stat.h>
+
+#include <cctype>
 #include <cstdlib>
 #include <cstring>
 #include <iostream>
@@ -39,13 +42,20 @@ int main(int argc, char** argv) {
                  "  fluxAtObserver::sweepDetector | fluxAtObserverOptimize::sweepDetector | fluxAtObserverOptimize::sweepSeries |\n"
                  "  fluxAtObserverFast::sweepDetectorTwofold | fluxAtObserverFast::sweepDetectorTraceOnce | fluxAtObserverFast::sweepSeries |\n"
                  "  nonLambertianFlux::sweepDetector | makeIntegratingSphereNRays | integratingSphereDetectorSweep |\n"
-                 "  distributionSphereDetectorSweep | --selftest-writer <file> | --unique <path> | --analyze <csv>...\n";
+                 "  distributionSphereDetectorSweep | --selftest-writer <file> | --unique <path> | --analyze <csv>... | --analyze <folder> [average]\n";
     return 2;
   }
   const std::string entry = argv[1];
   if (entry == "--selftest-writer" && argc > 2) return selftest_writer(argv[2]);
   if (entry == "--unique" && argc > 2) { std::cout << getUniqueFilename(argv[2]) << std::endl; return 0; }
-  if (entry == "--analyze" && argc > 2) {  // python flux_analysis.py <csv> (numeric part; no GPU)
+  if (entry == "--analyze" && argc > 2) {  // python flux_analysis.py <csv_file_or_folder> [average] (numbers; no GPU)
+    struct stat sb;
+    if (stat(argv[2], &sb) == 0 && S_ISDIR(sb.st_mode)) {
+      std::string mode = argc > 3 ? argv[3] : "";
+      for (char& ch : mode) ch = char(std::tolower(ch));
+      std::vector<ThetaAnalysis> all;
+      return analyzeFluxMapFolder(argv[2], mode == "average", all) ? 0 : 1;
+    }
     int bad = 0;
     for (int i = 2; i < argc; ++i) { ThetaAnalysis ta; if (!analyzeFluxMap(argv[i], ta)) bad++; }
     return bad ? 1 : 0;

@@ -1,6 +1,7 @@
 // isx_macros.cpp — the reference's macro entry points over libisx (see isx_macros.hpp).
 #include "isx_macros.hpp"
 
+#include <dirent.h>
 #include <sys/stat.h>
 #include <sys/types.h>
 
@@ -14,6 +15,7 @@
 #include <iomanip>
 #include <iostream>
 #include <algorithm>
+#include <map>
 #include <sstream>
 
 namespace isxhost {
@@ -225,52 +227,97 @@ bool fit_cosine(const std::vector<double>& x, const std::vector<double>& y, doub
 }
 }  // namespace
 
-bool analyzeFluxMap(const std::string& csvPath, ThetaAnalysis& out, bool writeReport) {
+bool readFluxMap(const std::string& csvPath, FluxMapTable& out) {
   std::ifstream in(csvPath);
   if (!in.is_open()) {
     std::cerr << "File not found: " << csvPath << std::endl;
     return false;
   }
-  // process_file(): '#' lines are "key: value" metadata, the first other line is the header, then theta,phi,fraction
-  std::vector<double> th, fr;
+  // process_file(): '#' lines are "key: value" metadata (split on the first ':'), the first other line is the
+  // header, then theta,phi,fraction rows
+  out = FluxMapTable();
   std::string line;
   bool header = false;
+  auto trim = [](std::string& t) {
+    const size_t a = t.find_first_not_of(" \t\r"), b = t.find_last_not_of(" \t\r");
+    t = a == std::string::npos ? "" : t.substr(a, b - a + 1);
+  };
   while (std::getline(in, line)) {
     if (line.empty()) continue;
     if (line[0] == '#') {
       const size_t colon = line.find(':');
       if (colon != std::string::npos) {
         std::string key = line.substr(1, colon - 1), val = line.substr(colon + 1);
-        auto trim = [](std::string& t) { const size_t a = t.find_first_not_of(" \t\r"), b = t.find_last_not_of(" \t\r"); t = a == std::string::npos ? "" : t.substr(a, b - a + 1); };
         trim(key); trim(val);
-        if (key == "Exit port angle") out.metadata_port_angle = val;
+        out.metadata[key] = val;
       }
       continue;
     }
     if (!header) { header = true; continue; }
     double t, p, f;
-    if (std::sscanf(line.c_str(), "%lf,%lf,%lf", &t, &p, &f) == 3) { th.push_back(t); fr.push_back(f); }
+    if (std::sscanf(line.c_str(), "%lf,%lf,%lf", &t, &p, &f) == 3) { out.theta.push_back(t); out.phi.push_back(p); out.fraction.push_back(f); }
   }
-  if (th.empty()) {
+  if (out.theta.empty()) {
     std::cerr << "Error reading CSV data from " << csvPath << std::endl;
     return false;
   }
-  // groupby('theta'): mean, std (ddof=1, NaN -> 0.001), count
+  return true;
+}
+
+PortModel portModel(double thetaMaxDeg, double reflectance) {
+  PortModel m;
+  m.f = 0.5 * (1.0 - std::cos((180.0 - thetaMaxDeg) * M_PI / 180.0));
+  m.phi_eff = 1.0 / (1.0 - reflectance * (1.0 - m.f));
+  m.p_exit = m.f * m.phi_eff;
+  return m;
+}
+
+double projectionFactor(double theta, double R, double r_p, int num_points) {
+  // the grid sum of safe_projection_factor: r and phi on inclusive linspaces, dA = r (r_p/n)(2 pi/n)
+  const double tt = std::tan(theta);
+  double flux = 0;
+  for (int ip = 0; ip < num_points; ++ip) {
+    const double ph = 2 * M_PI * double(ip) / double(num_points - 1), sp = std::sin(ph);
+    for (int ir = 0; ir < num_points; ++ir) {
+      const double r = r_p * double(ir) / double(num_points - 1);
+      const double den = std::sqrt(std::max(R * R + r * r - 2 * R * r * sp * tt, 1e-10));
+      const double c = std::min(1.0, std::max(-1.0, (R - r * sp * tt) / den));
+      flux += c * r * (r_p / num_points) * (2 * M_PI / num_points);
+    }
+  }
+  return flux;
+}
+
+namespace {
+double leading_number(const std::map<std::string, std::string>& md, const char* key, double dflt) {
+  auto it = md.find(key);
+  if (it == md.end()) return dflt;
+  char* e = nullptr;
+  const double v = std::strtod(it->second.c_str(), &e);
+  return e == it->second.c_str() ? dflt : v;
+}
+
+// per-theta statistics of one table: groupby('theta') mean, std (ddof=1; one row -> 0.001), count
+void theta_groups(const std::vector<double>& th, const std::vector<double>& fr, const std::vector<double>* se_in, ThetaAnalysis& out) {
   std::vector<size_t> order(th.size());
   for (size_t k = 0; k < order.size(); ++k) order[k] = k;
   std::stable_sort(order.begin(), order.end(), [&](size_t a, size_t b) { return th[a] < th[b]; });
   out.theta.clear(); out.mean.clear(); out.stderr_.clear();
   for (size_t k = 0; k < order.size();) {
     size_t e = k;
-    double s = 0;
-    while (e < order.size() && th[order[e]] == th[order[k]]) s += fr[order[e++]];
+    double s = 0, se = 0;
+    while (e < order.size() && th[order[e]] == th[order[k]]) { s += fr[order[e]]; if (se_in) se += (*se_in)[order[e]]; ++e; }
     const double cnt = double(e - k), m = s / cnt;
     double ss = 0;
     for (size_t q = k; q < e; ++q) ss += (fr[order[q]] - m) * (fr[order[q]] - m);
     const double sd = cnt > 1 ? std::sqrt(ss / (cnt - 1)) : 0.001;
-    out.theta.push_back(th[order[k]]); out.mean.push_back(m); out.stderr_.push_back(sd / std::sqrt(cnt));
+    out.theta.push_back(th[order[k]]); out.mean.push_back(m);
+    out.stderr_.push_back(se_in ? se / cnt : sd / std::sqrt(cnt));   // AVERAGE: mean of the per-bin standard errors (:190)
     k = e;
   }
+}
+
+void fit_and_report(const std::string& label, ThetaAnalysis& out) {
   const double mx = *std::max_element(out.mean.begin(), out.mean.end()), mn = *std::min_element(out.mean.begin(), out.mean.end());
   double avg = 0;
   for (double v : out.mean) avg += v;
@@ -285,26 +332,156 @@ bool analyzeFluxMap(const std::string& csvPath, ThetaAnalysis& out, bool writeRe
     ss_res += r * r; ss_tot += (out.mean[k] - avg) * (out.mean[k] - avg);
   }
   out.r_squared = ss_tot > 0 ? 1 - ss_res / ss_tot : 0;
-  const size_t slash = csvPath.find_last_of("/\\");
-  const std::string filename = slash == std::string::npos ? csvPath : csvPath.substr(slash + 1);
   char buf[256];
-  std::cout << "File: " << filename << std::endl;
+  std::cout << "File: " << label << std::endl;
   std::snprintf(buf, sizeof(buf), "  Fit parameters: a=%.5f, b=%.5f, c=%.5f", out.a, out.b, out.c);
   std::cout << buf << std::endl;
   std::snprintf(buf, sizeof(buf), "  R-squared value: %.5f", out.r_squared);
   std::cout << buf << std::endl;
+}
+
+// analytic overlays (finitePort/): ideal Lambertian port P_exit*(rho_d/R_det)^2*cos(theta) and the same
+// scaled by the finite-port projection factor normalised to its maximum
+void overlays(const std::map<std::string, std::string>& md, ThetaAnalysis& out) {
+  const double port = leading_number(md, "Exit port angle", 170.0), refl = leading_number(md, "Mirror reflectance", 0.99);
+  const double r_in = leading_number(md, "Sphere inner radius", 100.1), det = leading_number(md, "Detector dimensions", 40.0);
+  const double r_det = 100.0;  // fluxAtObserver.C:358
+  out.port = portModel(port, refl);
+  const double scale = out.port.p_exit * (0.5 * det / r_det) * (0.5 * det / r_det);
+  const double r_p = r_in * std::sin((180.0 - port) * M_PI / 180.0);
+  std::vector<double> pf(out.theta.size());
+  double pfmax = 0;
+  for (size_t k = 0; k < pf.size(); ++k) { pf[k] = projectionFactor(out.theta[k] * M_PI / 180.0, r_in, r_p); pfmax = std::max(pfmax, pf[k]); }
+  out.lambertian.resize(pf.size()); out.finite_port.resize(pf.size());
+  for (size_t k = 0; k < pf.size(); ++k) {
+    out.lambertian[k] = scale * std::cos(out.theta[k] * M_PI / 180.0);
+    out.finite_port[k] = pfmax > 0 ? scale * pf[k] / pfmax : 0.0;
+  }
+}
+
+void write_report(const std::string& path, const std::string& label, const ThetaAnalysis& out) {
+  std::ofstream o(path);
+  o << "# theta analysis of " << label << " (flux_analysis.py equivalent)" << std::endl;
+  if (!out.metadata_port_angle.empty()) o << "# Exit port angle: " << out.metadata_port_angle << std::endl;
+  o << std::setprecision(10);
+  o << "# fit: fraction = a*cos(b*theta) + c  a=" << out.a << " b=" << out.b << " c=" << out.c << " R2=" << out.r_squared << std::endl;
+  o << "# analytic: port fraction f=" << out.port.f << " Phi_eff=" << out.port.phi_eff << " P_exit=f*Phi_eff=" << out.port.p_exit
+    << " (finitePort/test.py:11-14); lambertian=P_exit*(r_det/R)^2*cos(theta); finite_port=projectionFactor.py:19-46 normalised" << std::endl;
+  o << "theta,mean_fraction,stderr,fit,lambertian,finite_port" << std::endl;
+  for (size_t k = 0; k < out.theta.size(); ++k)
+    o << out.theta[k] << "," << out.mean[k] << "," << out.stderr_[k] << ","
+      << (out.a * std::cos(out.b * out.theta[k] * M_PI / 180.0) + out.c) << "," << out.lambertian[k] << "," << out.finite_port[k] << std::endl;
+}
+
+std::string base_name(const std::string& path) {
+  const size_t slash = path.find_last_of("/\\");
+  return slash == std::string::npos ? path : path.substr(slash + 1);
+}
+}  // namespace
+
+bool analyzeFluxMap(const std::string& csvPath, ThetaAnalysis& out, bool writeReport) {
+  FluxMapTable tab;
+  if (!readFluxMap(csvPath, tab)) return false;
+  if (tab.metadata.count("Exit port angle")) out.metadata_port_angle = tab.metadata["Exit port angle"];
+  theta_groups(tab.theta, tab.fraction, nullptr, out);
+  fit_and_report(base_name(csvPath), out);
+  overlays(tab.metadata, out);
   if (writeReport) {
     const size_t dot = csvPath.find_last_of('.');
-    const std::string rep = getUniqueFilename((dot == std::string::npos ? csvPath : csvPath.substr(0, dot)) + "_theta_analysis.txt");
+    write_report(getUniqueFilename((dot == std::string::npos ? csvPath : csvPath.substr(0, dot)) + "_theta_analysis.txt"), base_name(csvPath), out);
+  }
+  return true;
+}
+
+bool analyzeFluxMapFolder(const std::string& dir, bool average, std::vector<ThetaAnalysis>& out, bool writeReport) {
+  DIR* d = opendir(dir.c_str());
+  if (!d) {
+    std::cerr << "File not found: " << dir << std::endl;
+    return false;
+  }
+  std::vector<std::string> files;
+  while (dirent* e = readdir(d)) {
+    const std::string n = e->d_name;
+    if (n.size() > 4 && n.compare(n.size() - 4, 4, ".csv") == 0) files.push_back(n);
+  }
+  closedir(d);
+  std::sort(files.begin(), files.end());   // os.listdir order is arbitrary; sorted here for reproducible reports
+  if (files.empty()) {
+    std::cerr << "No CSV files found in directory: " << dir << std::endl;
+    return false;
+  }
+  out.clear();
+  std::vector<FluxMapTable> tabs;
+  std::vector<std::string> names;
+  for (const std::string& n : files) {
+    FluxMapTable t;
+    if (!readFluxMap(dir + "/" + n, t)) continue;   // process_file returning None: skipped (:108-109)
+    tabs.push_back(std::move(t)); names.push_back(n);
+  }
+  if (tabs.empty()) return false;
+  for (size_t i = 0; i < tabs.size(); ++i) {
+    ThetaAnalysis ta;
+    if (tabs[i].metadata.count("Exit port angle")) ta.metadata_port_angle = tabs[i].metadata["Exit port angle"];
+    theta_groups(tabs[i].theta, tabs[i].fraction, nullptr, ta);
+    fit_and_report(names[i], ta);
+    overlays(tabs[i].metadata, ta);
+    out.push_back(ta);
+  }
+  std::string norm = dir;
+  while (norm.size() > 1 && (norm.back() == '/' || norm.back() == '\\')) norm.pop_back();
+  std::string base = base_name(norm);
+  if (average && tabs.size() > 1) {
+    // groupby(['theta','phi']) over all files: mean, std (ddof=1), count, stderr = std/sqrt(count) (:136-147)
+    std::cout << "Averaging data across all files..." << std::endl;
+    std::map<std::pair<double, double>, std::vector<double>> cells;
+    for (const FluxMapTable& t : tabs)
+      for (size_t k = 0; k < t.theta.size(); ++k) cells[{t.theta[k], t.phi[k]}].push_back(t.fraction[k]);
+    std::vector<double> th, fr, se;
+    for (const auto& kv : cells) {
+      const std::vector<double>& v = kv.second;
+      double m = 0;
+      for (double x : v) m += x;
+      m /= double(v.size());
+      double ss = 0;
+      for (double x : v) ss += (x - m) * (x - m);
+      // pandas: std of a single value is NaN; NaN stderr rows then vanish from the per-theta mean (skipna)
+      th.push_back(kv.first.first); fr.push_back(m);
+      se.push_back(v.size() > 1 ? std::sqrt(ss / double(v.size() - 1)) / std::sqrt(double(v.size())) : std::nan(""));
+    }
+    ThetaAnalysis ta;
+    // per-theta mean of the cell means, error bar = per-theta mean of the cell standard errors, NaNs skipped
+    theta_groups(th, fr, nullptr, ta);
+    {
+      std::map<double, std::pair<double, int>> acc;
+      for (size_t k = 0; k < th.size(); ++k) if (!std::isnan(se[k])) { acc[th[k]].first += se[k]; acc[th[k]].second++; }
+      for (size_t k = 0; k < ta.theta.size(); ++k) {
+        auto it = acc.find(ta.theta[k]);
+        ta.stderr_[k] = it == acc.end() ? std::nan("") : it->second.first / it->second.second;
+      }
+    }
+    fit_and_report("AVERAGE", ta);
+    overlays(tabs[0].metadata, ta);
+    out.push_back(ta);
+    names.push_back("AVERAGE");
+    base += "_averaged";
+  }
+  if (writeReport) {
+    // one text file where the script saved <base>_theta_comparison.png
+    const std::string rep = getUniqueFilename(base + "_theta_comparison.txt");
     std::ofstream o(rep);
-    o << "# theta analysis of " << filename << " (flux_analysis.py equivalent)" << std::endl;
-    if (!out.metadata_port_angle.empty()) o << "# Exit port angle: " << out.metadata_port_angle << std::endl;
+    o << "# theta comparison of " << norm << " (flux_analysis.py equivalent, numbers instead of the PNG)" << std::endl;
     o << std::setprecision(10);
-    o << "# fit: fraction = a*cos(b*theta) + c  a=" << out.a << " b=" << out.b << " c=" << out.c << " R2=" << out.r_squared << std::endl;
-    o << "theta,mean_fraction,stderr,fit" << std::endl;
-    for (size_t k = 0; k < out.theta.size(); ++k)
-      o << out.theta[k] << "," << out.mean[k] << "," << out.stderr_[k] << ","
-        << (out.a * std::cos(out.b * out.theta[k] * M_PI / 180.0) + out.c) << std::endl;
+    o << "file,a,b,c,r_squared" << std::endl;
+    for (size_t i = 0; i < out.size(); ++i) o << names[i] << "," << out[i].a << "," << out[i].b << "," << out[i].c << "," << out[i].r_squared << std::endl;
+    o << "# per-theta means, one block per file" << std::endl;
+    for (size_t i = 0; i < out.size(); ++i) {
+      o << "# " << names[i] << std::endl << "theta,mean_fraction,stderr,fit,lambertian,finite_port" << std::endl;
+      for (size_t k = 0; k < out[i].theta.size(); ++k)
+        o << out[i].theta[k] << "," << out[i].mean[k] << "," << out[i].stderr_[k] << ","
+          << (out[i].a * std::cos(out[i].b * out[i].theta[k] * M_PI / 180.0) + out[i].c) << "," << out[i].lambertian[k] << ","
+          << out[i].finite_port[k] << std::endl;
+    }
+    std::cout << "Analysis saved as " << rep << std::endl;
   }
   return true;
 }

@@ -18,6 +18,7 @@
 // fluxAtObserverOptimize.C:485-488); existing files are never overwritten (getUniqueFilename).
 #pragma once
 #include <cstdint>
+#include <map>
 #include <string>
 #include <vector>
 
@@ -77,13 +78,29 @@ std::string fluxmap_rows(const uint64_t* hits, long n, int nTheta, int nPhi, int
 // --- offline analysis of a flux-map CSV, the numeric part of flux_at_observer/flux_analysis.py
 // (process_file :11-57, per-theta mean + standard error :182-199, fit a*cos(b*theta)+c :60-62,200-209,
 // R^2 :229-233).  Writes "<stem>_theta_analysis.txt" next to the CSV and prints the script's lines.
+struct FluxMapTable {                           // process_file(): metadata dict + the three columns
+  std::map<std::string, std::string> metadata;
+  std::vector<double> theta, phi, fraction;
+};
+bool readFluxMap(const std::string& csvPath, FluxMapTable& out);
+// Analytic integrating-sphere model of finitePort/: port area fraction f = (1-cos(180deg-thetaMax))/2,
+// Phi_eff = 1/(1-rho(1-f)) (test.py:11-14, subtendedFlux.py:18-20), exit probability f*Phi_eff.
+struct PortModel { double f = 0, phi_eff = 0, p_exit = 0; };
+PortModel portModel(double thetaMaxDeg, double reflectance);
+// finite-port projection factor, projectionFactor.py:19-46 (theta in radians, grid of num_points^2)
+double projectionFactor(double theta, double R, double r_p, int num_points = 100);
 struct ThetaAnalysis {
   std::vector<double> theta, mean, stderr_;   // one entry per theta row
+  std::vector<double> lambertian, finite_port; // analytic overlays in the map's units (fraction of launched rays)
+  PortModel port;
   double a = 0, b = 0, c = 0, r_squared = 0;
   bool fit_ok = false;
   std::string metadata_port_angle;            // "Exit port angle" header value, if present
 };
 bool analyzeFluxMap(const std::string& csvPath, ThetaAnalysis& out, bool writeReport = true);
+// `flux_analysis.py <dir> [average]`: every *.csv of the folder, plus (average) the per-(theta,phi) mean over
+// files with standard error across files (:128-160) as a last entry.  Writes "<dir>[_averaged]_theta_comparison.txt".
+bool analyzeFluxMapFolder(const std::string& dir, bool average, std::vector<ThetaAnalysis>& out, bool writeReport = true);
 
 namespace fluxAtObserver {
 void setupOpticsManager(OpticsManager* manager);                                  // :147-160

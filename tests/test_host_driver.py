@@ -104,8 +104,60 @@ def test_theta_analysis_matches_scipy(cli, golden, tmp_path):
     assert [a, b, c] == pytest.approx(list(popt), abs=2e-5)
     res = means - cosine_func(theta, *popt)
     assert r2 == pytest.approx(1 - (res ** 2).sum() / ((means - means.mean()) ** 2).sum(), abs=2e-5)
-    rep = np.loadtxt(tmp_path / "map_theta_analysis.txt", delimiter=",", comments="#", skiprows=4)
-    assert rep.shape == (180, 4) and np.allclose(rep[:, 1], means, atol=1e-9)
+    rep = np.loadtxt(tmp_path / "map_theta_analysis.txt", delimiter=",", comments="#", skiprows=5)
+    assert rep.shape == (180, 6) and np.allclose(rep[:, 1], means, atol=1e-9)
+    # analytic overlays: closed form of finitePort/test.py:11-14 and the grid sum of projectionFactor.py:19-46
+    f = (1 - np.cos(np.deg2rad(10.0))) / 2
+    p_exit = f / (1 - 0.99 * (1 - f))
+    assert np.allclose(rep[:, 4], p_exit * 0.04 * np.cos(np.deg2rad(theta)), rtol=1e-9)
+
+    def projection(t, R, r_p, n=100):
+        r, ph = np.meshgrid(np.linspace(0, r_p, n), np.linspace(0, 2 * np.pi, n))
+        den = np.sqrt(np.maximum(R ** 2 + r ** 2 - 2 * R * r * np.sin(ph) * np.tan(t), 1e-10))
+        c = np.clip((R - r * np.sin(ph) * np.tan(t)) / den, -1, 1)
+        return np.sum(c * r * (r_p / n) * (2 * np.pi / n))
+    pf = np.array([projection(np.deg2rad(t), 100.1, 100.1 * np.sin(np.deg2rad(10.0))) for t in theta])
+    assert np.allclose(rep[:, 5], p_exit * 0.04 * pf / pf.max(), rtol=1e-8)
+
+
+def test_folder_average_matches_pandas(cli, tmp_path):
+    """isx_macro --analyze <folder> average == flux_analysis.py:128-160,182-192 (groupby theta,phi over files:
+    mean, std/sqrt(count); then per-theta means) + the same cosine fit."""
+    import pandas as pd
+    from scipy.optimize import curve_fit
+    rng = np.random.default_rng(11)
+    folder = tmp_path / "series"
+    folder.mkdir()
+    frames = []
+    for k in range(3):
+        rows = [((i + .5) * 3.0, (j + .5) * 36.0, round(max(0.0, 0.016 * np.cos(np.deg2rad((i + .5) * 3.0)) * (1 + 0.1 * rng.standard_normal())), 6))
+                for i in range(30) for j in range(10)]
+        with open(folder / f"fluxmap_{k}.csv", "w") as f:
+            f.write("# Flux Map Data - Generated: x\n# Exit port angle: 164 degrees\n# Mirror reflectance: 0.99\ntheta,phi,fraction\n")
+            f.writelines(f"{t:.6f},{p:.6f},{v:.6f}\n" for t, p, v in rows)
+        frames.append(pd.DataFrame(rows, columns=["theta", "phi", "fraction"]))
+    (folder / "notes.txt").write_text("ignored")
+    out = subprocess.check_output([cli, "--analyze", str(folder), "AVERAGE"], text=True, cwd=tmp_path)
+    assert "Averaging data across all files..." in out
+    blocks = re.findall(r"File: (\S+)\n  Fit parameters: a=([-\d.]+), b=([-\d.]+), c=([-\d.]+)\n  R-squared value: ([-\d.]+)", out)
+    assert [b[0] for b in blocks] == ["fluxmap_0.csv", "fluxmap_1.csv", "fluxmap_2.csv", "AVERAGE"]
+    g = pd.concat(frames, ignore_index=True).groupby(["theta", "phi"])["fraction"]
+    avg = g.mean().reset_index()
+    avg["stderr"] = (g.std() / np.sqrt(g.size())).values
+    gt = avg.groupby("theta")
+    theta, means, errs = np.array(gt["fraction"].mean().index), gt["fraction"].mean().values, gt["stderr"].mean().values
+
+    def cosine_func(x, a, b, c):
+        return a * np.cos(np.deg2rad(b * x)) + c
+    popt, _ = curve_fit(cosine_func, theta, means, p0=[(means.max() - means.min()) / 2, 1.0, means.mean()])
+    assert [float(x) for x in blocks[3][1:4]] == pytest.approx(list(popt), abs=2e-5)
+    txt = (tmp_path / "series_averaged_theta_comparison.txt").read_text().split("# AVERAGE\n")[1].splitlines()[1:]
+    rep = np.array([[float(x) for x in ln.split(",")] for ln in txt])
+    assert rep.shape == (30, 6)
+    assert np.allclose(rep[:, 0], theta) and np.allclose(rep[:, 1], means, atol=1e-12) and np.allclose(rep[:, 2], errs, atol=1e-12)
+    # without "average": per-file analyses only
+    out2 = subprocess.check_output([cli, "--analyze", str(folder)], text=True, cwd=tmp_path)
+    assert "AVERAGE" not in out2 and (tmp_path / "series_theta_comparison.txt").exists()
 
 
 def test_cli_fails_loudly_without_gpu(cli, tmp_path):
