@@ -82,6 +82,11 @@ int prepare_geom(const isx_config* c, Geom* g) {
   g->inv_rout = 1.0 / c->r_out;
   g->H = c->box_half;
   g->rho = c->reflectance;
+  {
+    // (w + 0.5) * 2^-32 < rho  <=>  w < rho * 2^32 - 0.5 =: x (both scalings exact)  <=>  w < ceil(x) for integer w
+    const double x = std::ldexp(c->reflectance, 32) - 0.5;
+    g->rho_thr = !(x > 0.0) ? 0ull : (x >= 4294967296.0 ? 4294967296ull : (unsigned long long)std::ceil(x));
+  }
   g->sigma = c->roughness_rad;
   g->lambertian = c->lambertian;
   g->limit = c->max_points;

@@ -30,20 +30,22 @@ struct Geom {
   double brdf_spec;         // specular/(specular+diffuse) (:157-159)
   int lambertian, limit, source_model, surface_model;
   int sched_mask, sched_min;
-  int chord, pad2;          // ISX_TRACE_CHORD
-  double r_in;  // generic-search batching: flush when (iter & mask) == mask or >= min lanes parked
+  int chord, pad2;          // ISX_TRACE_CHORD; sched_*: generic-search batching, flush when (iter & mask) == mask or >= min lanes parked
+  double r_in;
+  unsigned long long rho_thr;  // absorb test on the raw Philox word: (w + 0.5) 2^-32 < rho  <=>  w < rho_thr (exact, see prepare_geom)
 };
 
 // The handful of constants the hot loop needs; kept in SGPRs.  Everything else of Geom is read
 // on demand from an LDS copy (a `const volatile Geom&`), so it never occupies scalar registers
 // across the loop (SGPR spills were >10 % of the issued instructions before this split).
 struct Hot {
-  double rin2, zcut_in, ninv_rin, rho, r_in;
+  double rin2, zcut_in, ninv_rin, r_in;
+  unsigned long long rho_thr;
   int lambertian, limit, source_model, surface_model, chord;
 };
 __device__ __forceinline__ Hot make_hot(const Geom& g) {
   Hot h;
-  h.rin2 = g.rin2; h.zcut_in = g.zcut_in; h.ninv_rin = g.ninv_rin; h.rho = g.rho;
+  h.rin2 = g.rin2; h.zcut_in = g.zcut_in; h.ninv_rin = g.ninv_rin; h.rho_thr = g.rho_thr;
   h.lambertian = g.lambertian; h.limit = g.limit; h.source_model = g.source_model; h.surface_model = g.surface_model;
   h.r_in = g.r_in; h.chord = g.chord;
   return h;
@@ -79,6 +81,30 @@ __device__ __forceinline__ void draw_block(uint64_t seed, uint64_t ray, uint32_t
 __device__ __forceinline__ double u01(uint32_t w) { return fma((double)w, 0x1.0p-32, 0x1.0p-33); }
 
 // ---------------------------------------------------------------- elementary functions
+// IEEE sqrt and 1/x for operands KNOWN to be normal and far from the exponent limits (u in [2^-33,1), 1-u,
+// sg+n.z in +-[1,2]).  The arithmetic is the compiler's own f64 expansion (v_rsq/v_rcp seed, Goldschmidt/Newton
+// steps in fma, final residual correction) without the range scaling and special-case fix-ups those operands
+// never need, so the results are the correctly rounded ones -- checked against the CPU over the whole input
+// family in tests/test_gpu_parity.py::test_unit_range_sqrt_rcp_are_ieee.
+__device__ __forceinline__ double sqrt_unit(double x) {
+  const double y = __builtin_amdgcn_rsq(x);
+  double g = x * y, h = 0.5 * y;
+  const double r = fma(-h, g, 0.5);
+  g = fma(g, r, g);
+  h = fma(h, r, h);
+  const double d0 = fma(-g, g, x);
+  g = fma(d0, h, g);
+  const double d1 = fma(-g, g, x);
+  return fma(d1, h, g);
+}
+__device__ __forceinline__ double neg_rcp_unit(double d) {   // -1.0 / d
+  double y = __builtin_amdgcn_rcp(d);
+  y = fma(fma(-d, y, 1.0), y, y);
+  y = fma(fma(-d, y, 1.0), y, y);
+  const double q = -y;                       // -1 * y (exact)
+  const double r = fma(-d, q, -1.0);         // residual of q against the numerator -1
+  return fma(r, y, q);
+}
 // A 64-bit literal cannot be an inline VALU operand.  Left alone, hipcc hoists the polynomial
 // coefficients into VGPRs outside the trace loop, runs out of registers and reloads them from
 // SCRATCH inside the loop (10 dependent scratch loads per bounce).  sconst() pins a literal to an
@@ -340,9 +366,10 @@ __device__ inline V3 lobe_sample(const V3 normal, uint64_t seed, uint64_t ray, u
 }
 
 // ---------------------------------------------------------------- surface interaction
+template <bool UNIT = false>
 __device__ __forceinline__ void onb(const V3& n, V3& t1, V3& t2) {
   const double sg = copysign(1.0, n.z);
-  const double a = -1.0 / (sg + n.z);
+  const double a = UNIT ? neg_rcp_unit(sg + n.z) : -1.0 / (sg + n.z);
   const double b = (n.x * n.y) * a;
   t1.x = fma(sg * n.x, n.x * a, 1.0);
   t1.y = sg * b;
@@ -376,9 +403,9 @@ __device__ __forceinline__ V3 surface_normal(const Hot& h, const G& g, int kind,
 __device__ __forceinline__ bool interact_chord(const Hot& h, V3& T, uint64_t seed, uint64_t ray, uint32_t j, uint32_t stream) {
   uint32_t wl[4];
   draw_block(seed, ray, 2u * j, stream, wl);
-  if (!(u01(wl[2]) < h.rho)) return false;
+  if (!((unsigned long long)wl[2] < h.rho_thr)) return false;   // u01(wl[2]) < rho, decided on the integer
   const double zz = fma(-2.0, u01(wl[0]), 1.0);
-  const double s2 = sqrt(fma(-zz, zz, 1.0));
+  const double s2 = sqrt_unit(fma(-zz, zz, 1.0));   // 1 - zz^2 in [2^-32, 1]
   double sf, cf;
   sincos2pi(u01(wl[1]), sf, cf);
   const double rxy = h.r_in * s2;
@@ -393,7 +420,7 @@ __device__ __forceinline__ bool interact(const Hot& h, const G& g, int kind, con
                                          uint64_t ray, uint32_t j, uint32_t stream) {
   uint32_t wl[4];
   draw_block(seed, ray, 2u * j, stream, wl);
-  if (!(u01(wl[2]) < h.rho)) return false;
+  if (!((unsigned long long)wl[2] < h.rho_thr)) return false;   // u01(wl[2]) < rho, decided on the integer
   const V3 n = surface_normal(h, g, kind, q);
   V3 w;
   if (!LEAN && h.surface_model == 1) {
@@ -402,10 +429,10 @@ __device__ __forceinline__ bool interact(const Hot& h, const G& g, int kind, con
     // cosine-law re-emission about the geometric normal; roughness does not act on a
     // Lambertian border
     V3 A, Bv;
-    onb(n, A, Bv);
+    onb<true>(n, A, Bv);                 // |n| = 1: sg + n.z in +-[1,2]
     const double u1 = u01(wl[0]), u2 = u01(wl[1]);
-    const double r = sqrt(u1);
-    const double z = sqrt(1.0 - u1);
+    const double r = sqrt_unit(u1);      // u1, 1-u1 in [2^-33, 1)
+    const double z = sqrt_unit(1.0 - u1);
     double sf, cf;
     sincos2pi(u2, sf, cf);
     const double x = r * cf, y = r * sf;
@@ -435,8 +462,12 @@ __device__ __forceinline__ bool interact(const Hot& h, const G& g, int kind, con
     const double d2 = -2.0 * dot3(v, M);
     w = axpy(d2, M, v);
   }
-  const double dn = dot3(w, n);
-  if (dn <= 0.0) w = axpy(-2.0 * dn, n, w);
+  // into-wall fix.  Cosine emission cannot need it: w.n = z + O(1e-16) with z >= 2^-16.5, so the lean
+  // kernel (Lambertian only) does not evaluate it; the oracle always does and never takes the branch there.
+  if (!LEAN) {
+    const double dn = dot3(w, n);
+    if (dn <= 0.0) w = axpy(-2.0 * dn, n, w);
+  }
   // one Newton step towards unit length (keeps the |v| error at rounding level instead of letting it
   // random-walk multiplicatively through hit point -> normal -> new direction)
   const double k = fma(-0.5, dot3(w, w), 1.5);

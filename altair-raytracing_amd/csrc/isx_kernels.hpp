@@ -144,7 +144,6 @@ __device__ inline uint32_t bin_culled(const DG& dd, uint32_t* __restrict__ hist,
   d.n_theta = dd.n_theta; d.n_phi = dd.n_phi; d.half_w2 = dd.half_w2; d.rho_d = dd.rho_d; d.R = dd.R;
   d.portz = dd.portz; d.table = dd.table;
   // ---- line vs the sphere of detector centres S(O,R), O=(0,0,portz): wave-uniform, f32 is enough (cull only)
-  const double vv = dot3(V, V);
   const double wz = P.z - d.portz;
   const double wv = fma(P.x, V.x, fma(P.y, V.y, wz * V.z));
   const double hx = fma(-wv, V.x, P.x), hy = fma(-wv, V.y, P.y), hz = fma(-wv, V.z, wz);
@@ -153,7 +152,7 @@ __device__ inline uint32_t bin_culled(const DG& dd, uint32_t* __restrict__ hist,
   const float R2 = Rf * Rf;
   const float dO = sqrt_cull(dO2);
   const float a1 = dO + rho;
-  if (!(a1 < 0.999f * Rf)) return bin_brute(dd, hist, P, V, lane);
+  if (!(a1 < 0.999f * Rf)) { const uint32_t c = bin_brute(dd, hist, P, V, lane); return lane == 0 ? c : 0u; }
   const float sF = sqrt_cull(R2 - dO2);
   const float smin = sqrt_cull(R2 - a1 * a1);
   const float a0 = fmaxf(0.f, dO - rho);
@@ -161,7 +160,7 @@ __device__ inline uint32_t bin_culled(const DG& dd, uint32_t* __restrict__ hist,
   const float ext = fmaxf(sF - smin, smax - sF);
   // every detector centre within rho_d of the line lies within chord ch of a piercing point
   const float ch2 = fmaf(ext, ext, rho * rho) * 1.0001f + 1e-3f;
-  if (!(4.0f * (R2 - dO2) > 4.04f * ch2)) return bin_brute(dd, hist, P, V, lane);
+  if (!(4.0f * (R2 - dO2) > 4.04f * ch2)) { const uint32_t c = bin_brute(dd, hist, P, V, lane); return lane == 0 ? c : 0u; }
   const float ch = sqrt_cull(ch2);
   const float inv_dphi = (float)d.n_phi * 0.15915494309f;  // 1/dphi
   const float inv_dth = (float)d.n_theta * 0.63661977237f;   // 1 / row spacing in theta
@@ -186,7 +185,7 @@ __device__ inline uint32_t bin_culled(const DG& dd, uint32_t* __restrict__ hist,
     for (int i0 = ilo; i0 <= ihi; i0 += 64) {
       const int i = i0 + lane;
       int jlo = 0, cnt = 0;
-      double a0c = 0, a1c = 0, a2c = 0, b0c = 0, b1c = 0, b2c = 0, e0c = 0, e1c = 0, e2c = 0, f0c = 0, f1c = 0, f2c = 0;
+      double a0c = 0, a1c = 0, a2c = 0, b0c = 0, b1c = 0, b2c = 0, e0c = 0, e1c = 0, e2c = 0, f0c = 0, f1c = 0, f2c = 0, bandc = 0;
       if (i <= ihi) {
         const double Sd = rowt[4 * i + 0], Cd = rowt[4 * i + 1], zd = rowt[4 * i + 2], Ad = rowt[4 * i + 3];
         const float zi = (float)zd, Ai = (float)Ad;
@@ -210,8 +209,15 @@ __device__ inline uint32_t bin_culled(const DG& dd, uint32_t* __restrict__ hist,
           const double pz = P.z - zd;
           a0c = -(Cd * V.z); a1c = Sd * V.y; a2c = -(Sd * V.x);
           b0c = -(Cd * pz);  b1c = Sd * P.y; b2c = -(Sd * P.x);
-          e0c = fma(P.x, V.x, fma(P.y, V.y, pz * V.z)); e1c = -(Ad * V.x); e2c = -(Ad * V.y);
-          f0c = fma(P.x, P.x, fma(P.y, P.y, fma(Ad, Ad, pz * pz))); f1c = -2.0 * (Ad * P.x); f2c = -2.0 * (Ad * P.y);
+          // e: -2 dv,  f: dd - (w/2)^2   (the factors the sign test needs, folded into the row constants)
+          e0c = -2.0 * fma(P.x, V.x, fma(P.y, V.y, pz * V.z)); e1c = 2.0 * (Ad * V.x); e2c = 2.0 * (Ad * V.y);
+          const double f0 = fma(P.x, P.x, fma(P.y, P.y, fma(Ad, Ad, pz * pz)));
+          f0c = f0 - d.half_w2; f1c = -2.0 * (Ad * P.x); f2c = -2.0 * (Ad * P.y);
+          // bound of 2e-9 (t1 + t3 + rhs) over every column of the row: |form| <= |k0|+|k1|+|k2|
+          const double sdot = fabs(a0c) + (fabs(a1c) + fabs(a2c));
+          const double snum = fabs(b0c) + (fabs(b1c) + fabs(b2c));
+          const double sdd = f0 + (fabs(f1c) + fabs(f2c));
+          bandc = 2e-9 * fma(sdot * sdot, sdd + d.half_w2, snum * snum);
           if (jlo < 0) jlo += d.n_phi;   // keep the running column in [0, n_phi)
         }
       }
@@ -228,25 +234,20 @@ __device__ inline uint32_t bin_culled(const DG& dd, uint32_t* __restrict__ hist,
           const double cph = colt[2 * j + 0], sph = colt[2 * j + 1];
           const double dot = fma(a1c, cph, fma(a2c, sph, a0c));
           const double num = fma(b1c, cph, fma(b2c, sph, b0c));
-          const double dv = fma(e1c, cph, fma(e2c, sph, e0c));
-          const double dd = fma(f1c, cph, fma(f2c, sph, f0c));
-          const double dot2 = dot * dot;
-          const double t1 = dd * dot2;
-          const double t2 = (2.0 * num) * (dot * dv);
-          const double t3 = (num * num) * vv;     // |d + tV|^2 carries |V|^2 (= 1 to rounding; kept for robustness)
-          const double rhs = d.half_w2 * dot2;
-          const double diff = (t1 - t2) + (t3 - rhs);
-          // |t2| = 2|num||dot*dv| <= 2 sqrt(t3) sqrt(t1) <= t1 + t3, so this bounds the scale of all four terms
+          const double m2dv = fma(e1c, cph, fma(e2c, sph, e0c));
+          const double ddw = fma(f1c, cph, fma(f2c, sph, f0c));
+          // sign of  dot^2 (dd - (w/2)^2) - 2 num dot dv + num^2  (|V| = 1 to rounding: Newton-renormalised)
+          const double diff = fma(dot, fma(dot, ddw, num * m2dv), num * num);
+          // evaluation error ~1e-15 of the terms' scale; bandc >= 2e-9 of that scale for every column of the row
           // (an f32 version of this test was tried and rejected: its error grows like 1/|dot| and it
           //  mis-decided 16 of 2.3e9 hits at 2e7 rays; f64 keeps >100x margin down to |dot| = 1e-4)
-          const double band = 2e-9 * (t1 + t3 + rhs);
           hit = diff < 0.0;
-          if (fabs(dot) < 1e-4 || fabs(diff) <= band)  // too close to call: exact reference-order test
+          if (fabs(dot) < 1e-4 || fabs(diff) <= bandc)  // too close to call: exact reference-order test
             hit = check_intersection(d.table + 6 * (size_t)bin, d.half_w2, P, V);
           j++;
         }
         if (hit) atomicAdd(&hist[bin], 1u);
-        inc += (uint32_t)__popcll(__ballot(hit));
+        inc += hit ? 1u : 0u;   // per lane
       }
     }
   }
@@ -449,6 +450,7 @@ __device__ __forceinline__ void persistent_body(const Geom& g_arg, const DetGrid
   uint32_t iter = 0;
   uint32_t n_exited = 0, n_counted = 0, n_susp = 0, n_ended = 0, n_wall = 0;   // per lane
   unsigned long long n_inc = 0;                                                  // per wave
+  uint32_t n_inc_lane = 0;                                                       // per lane (culled binning)
 
   for (;;) {
     // ---- refill dead lanes from this wave's range
@@ -604,7 +606,7 @@ __device__ __forceinline__ void persistent_body(const Geom& g_arg, const DetGrid
         } else {
           if (!LEAN && hit_line_mode == 1) hit_line_compat(P, V);
           if (bin_mode == 0) n_inc += bin_brute(d, hist, P, V, lane);
-          else if (bin_mode == 1) n_inc += bin_culled(d, hist, rowt, colt, P, V, lane);
+          else if (bin_mode == 1) n_inc_lane += bin_culled(d, hist, rowt, colt, P, V, lane);
           // bin_mode 2: diagnostic only (trace without binning; results are NOT a flux map)
         }
       }
@@ -617,6 +619,7 @@ __device__ __forceinline__ void persistent_body(const Geom& g_arg, const DetGrid
   atomicAdd(&sstat[3], (unsigned long long)(n_ended - n_exited - n_susp));  // absorbed
   atomicAdd(&sstat[4], (unsigned long long)n_susp);
   atomicAdd(&sstat[6], (unsigned long long)n_wall);
+  if (n_inc_lane) atomicAdd(&sstat[5], (unsigned long long)n_inc_lane);
   if (lane == 0) {
     atomicAdd(&sstat[0], (unsigned long long)(range_end - range_first));       // launched = this wave's range
     atomicAdd(&sstat[5], n_inc);
@@ -671,7 +674,8 @@ isx_endstates_kernel(const Geom g, uint64_t seed, uint64_t first, uint64_t n, in
 }
 
 // ------------------------------------------------------------------ device-side self test of the numeric contract
-// out[k] for k in [0,n): op 0 sqrt(a), 1 a/b, 2 fma(a,b,c), 3 log_pos(a), 4/5 sincos2pi(a), 6/7 sincos_cw(a)
+// out[k] for k in [0,n): op 0 sqrt(a), 1 a/b, 2 fma(a,b,c), 3 log_pos(a), 4/5 sincos2pi(a), 6/7 sincos_cw(a),
+// 8 sqrt_unit(a), 9 neg_rcp_unit(a)
 extern "C" __global__ void isx_mathprobe_kernel(int op, const double* __restrict__ a, const double* __restrict__ b,
                                                 const double* __restrict__ c, double* __restrict__ out, int n) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -685,6 +689,8 @@ extern "C" __global__ void isx_mathprobe_kernel(int op, const double* __restrict
     case 4: sincos2pi(a[i], s, co); out[i] = s; break;
     case 5: sincos2pi(a[i], s, co); out[i] = co; break;
     case 6: sincos_cw(a[i], s, co); out[i] = s; break;
+    case 8: out[i] = sqrt_unit(a[i]); break;
+    case 9: out[i] = neg_rcp_unit(a[i]); break;
     default: sincos_cw(a[i], s, co); out[i] = co; break;
   }
 }

@@ -97,6 +97,23 @@ def test_elementary_functions_bit_exact(isx, orc):
     assert np.array_equal(_bits(isx.mathprobe(7, x)), _bits(sc[:, 1]))
 
 
+def test_unit_range_sqrt_rcp_are_ieee(isx):
+    """The hot loop's sqrt/(-1/x) drop the range scaling and special-case fix-ups of the general expansions;
+    on their operand families (u=(w+.5)2^-32, 1-u, 1-zz^2; sg+n.z in +-[1,2]) they must stay correctly rounded."""
+    rng = np.random.default_rng(12)
+    w = np.concatenate([rng.integers(0, 2 ** 32, 4_000_000, dtype=np.uint64),
+                        np.arange(0, 4096, dtype=np.uint64), 2 ** 32 - 1 - np.arange(0, 4096, dtype=np.uint64),
+                        (np.uint64(1) << np.arange(0, 32, dtype=np.uint64))])
+    u = (w.astype(np.float64) + 0.5) * 2.0 ** -32
+    zz = 1.0 - 2.0 * u
+    for x in (u, 1.0 - u, 1.0 - zz * zz, np.array([2.0 ** -33, 2.0 ** -32, 0.25, 0.5, 1.0, 1.0 - 2.0 ** -53])):
+        x = x[x > 0]
+        assert np.array_equal(_bits(isx.mathprobe(8, x)), _bits(np.sqrt(x)))
+    nz = np.concatenate([rng.uniform(-1, 1, 4_000_000), [-1.0, 1.0, 0.0, -0.0, 1e-300, -1e-300, 1 - 2.0 ** -53, -(1 - 2.0 ** -53)]])
+    d = np.copysign(1.0, nz) + nz
+    assert np.array_equal(_bits(isx.mathprobe(9, d)), _bits(-1.0 / d))
+
+
 def test_detector_table_bit_exact(isx, orc):
     assert np.array_equal(_bits(isx.detector_table(isx.default_config())), _bits(orc.detector_table(orc.default_config())))
 

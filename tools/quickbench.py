@@ -30,8 +30,11 @@ if os.environ.get("ISX_QB_CHILD"):
             ts.append(st.t_kernel_ms)
         out[f"mode{mode}_ms"] = min(ts)
         out[f"mode{mode}_Mrays"] = n / min(ts) / 1e3
+        out[f"mode{mode}_ns_per_wallhit"] = min(ts) * 1e6 / max(st.wall_hits, 1)
         if mode == 1:
             out["hist_sum"] = int(h.sum())
+            out["wall_hits_per_ray"] = st.wall_hits / n
+            out["p_exit"] = st.counted_below_z / n
     print(json.dumps(out))
     sys.exit(0)
 
