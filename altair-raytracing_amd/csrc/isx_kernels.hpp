@@ -110,23 +110,29 @@ __device__ __forceinline__ float atan2_cull(float y, float x) {
   return r;
 }
 
+// acos in f32 for |x| <= 1, |error| < 1e-4 rad (Abramowitz & Stegun 4.4.45 on |x|, reflected for x < 0;
+// restated in numpy and checked in tests/test_cull_math.py)
+__device__ __forceinline__ float acos_cull(float x) {
+  const float ax = fabsf(x);
+  const float p = fmaf(ax, fmaf(ax, fmaf(ax, -0.0187293f, 0.0742610f), -0.2121144f), 1.5707288f);
+  const float r = sqrt_cull(fmaxf(0.f, 1.f - ax)) * p;
+  return x < 0.f ? 3.14159274f - r : r;
+}
+
 // ------------------------------------------------------------------ binning of one exit line by a whole wave
-// P,V are wave-uniform.  Returns the number of bins incremented (wave-uniform).
+// P,V are wave-uniform.  (The number of increments is read off the LDS histogram when the block flushes it.)
 template <class DG>
-__device__ __forceinline__ uint32_t bin_brute(const DG& dd, uint32_t* __restrict__ hist, const V3& P, const V3& V,
+__device__ __forceinline__ void bin_brute(const DG& dd, uint32_t* __restrict__ hist, const V3& P, const V3& V,
                                               int lane) {
   const int nbins = dd.nbins;
   const double* table = dd.table;
   const double half_w2 = dd.half_w2;
-  uint32_t inc = 0;
   for (int b0 = 0; b0 < nbins; b0 += 64) {
     const int b = b0 + lane;
     bool hit = false;
     if (b < nbins) hit = check_intersection(table + 6 * (size_t)b, half_w2, P, V);
     if (hit) atomicAdd(&hist[b], 1u);
-    inc += (uint32_t)__popcll(__ballot(hit));
   }
-  return inc;
 }
 
 // Culled binning, "lane = detector row": every lane owns one theta-row of the cap around a piercing
@@ -136,7 +142,7 @@ __device__ __forceinline__ uint32_t bin_brute(const DG& dd, uint32_t* __restrict
 // are all of the form k0 + k1*cos(phi_j) + k2*sin(phi_j)  (c = (A c, A s, z), n = (-S s, S c, -C)),
 // so one candidate costs 8 fma + the sign test of  dd*dot^2 - 2*num*dot*dv + num^2 - (w/2)^2*dot^2.
 template <class DG>
-__device__ inline uint32_t bin_culled(const DG& dd, uint32_t* __restrict__ hist,
+__device__ inline void bin_culled(const DG& dd, uint32_t* __restrict__ hist,
                                       const double* __restrict__ rowt, const double* __restrict__ colt,
                                       const V3 P, const V3 V, int lane) {
   // one read of each constant (dd is a volatile LDS copy: nothing of it lives in SGPRs across the trace loop)
@@ -152,7 +158,7 @@ __device__ inline uint32_t bin_culled(const DG& dd, uint32_t* __restrict__ hist,
   const float R2 = Rf * Rf;
   const float dO = sqrt_cull(dO2);
   const float a1 = dO + rho;
-  if (!(a1 < 0.999f * Rf)) { const uint32_t c = bin_brute(dd, hist, P, V, lane); return lane == 0 ? c : 0u; }
+  if (!(a1 < 0.999f * Rf)) { bin_brute(dd, hist, P, V, lane); return; }
   const float sF = sqrt_cull(R2 - dO2);
   const float smin = sqrt_cull(R2 - a1 * a1);
   const float a0 = fmaxf(0.f, dO - rho);
@@ -160,12 +166,11 @@ __device__ inline uint32_t bin_culled(const DG& dd, uint32_t* __restrict__ hist,
   const float ext = fmaxf(sF - smin, smax - sF);
   // every detector centre within rho_d of the line lies within chord ch of a piercing point
   const float ch2 = fmaf(ext, ext, rho * rho) * 1.0001f + 1e-3f;
-  if (!(4.0f * (R2 - dO2) > 4.04f * ch2)) { const uint32_t c = bin_brute(dd, hist, P, V, lane); return lane == 0 ? c : 0u; }
+  if (!(4.0f * (R2 - dO2) > 4.04f * ch2)) { bin_brute(dd, hist, P, V, lane); return; }
   const float ch = sqrt_cull(ch2);
   const float inv_dphi = (float)d.n_phi * 0.15915494309f;  // 1/dphi
   const float inv_dth = (float)d.n_theta * 0.63661977237f;   // 1 / row spacing in theta
   const float omega = ch * rcp_cull(Rf) * 1.01f + 2e-3f;          // cap angular radius 2*asin(ch/2R), conservatively
-  uint32_t inc = 0;
 #pragma unroll 1
   for (int side = 0; side < 2; ++side) {
     const double s = side == 0 ? ((double)sF - wv) : (-(double)sF - wv);
@@ -198,7 +203,7 @@ __device__ inline uint32_t bin_culled(const DG& dd, uint32_t* __restrict__ hist,
         else {
           float K = (num - slack) * rcp_cull(den) - 2e-5f;
           K = fminf(1.f, fmaxf(-1.f, K));
-          const float dl = atan2_cull(sqrt_cull(fmaxf(0.f, 1.f - K * K)), K) + 1e-3f;
+          const float dl = acos_cull(K) + 1e-3f;
           const float hw = dl * inv_dphi;
           const int lo = (int)ceilf(jf - hw), hi = (int)floorf(jf + hw);
           jlo = lo; cnt = hi - lo + 1;
@@ -221,11 +226,11 @@ __device__ inline uint32_t bin_culled(const DG& dd, uint32_t* __restrict__ hist,
           if (jlo < 0) jlo += d.n_phi;   // keep the running column in [0, n_phi)
         }
       }
-      const int gmax = wave_max_i32(cnt);
       int j = jlo;
       const int rowbase = i * d.n_phi;
-      for (int k = 0; k < gmax; ++k) {
+      for (int k = 0;; ++k) {                    // until the widest window of the wave is done
         const bool act = k < cnt;
+        if (__ballot(act) == 0ull) break;
         bool hit = false;
         int bin = 0;
         if (act) {
@@ -247,11 +252,9 @@ __device__ inline uint32_t bin_culled(const DG& dd, uint32_t* __restrict__ hist,
           j++;
         }
         if (hit) atomicAdd(&hist[bin], 1u);
-        inc += hit ? 1u : 0u;   // per lane
       }
     }
   }
-  return inc;
 }
 
 // ISX_HITLINE_ORIGIN_COMPAT (fluxAtObserverFast.C:1181-1201,1285): start (0,0,0), direction last/|last|,
@@ -372,21 +375,18 @@ __device__ __forceinline__ bool segment_hits_tube(const V3& p, const V3& v, doub
 }
 
 template <class DG>
-__device__ __forceinline__ uint32_t bin_discs(const DG& dd, uint32_t* __restrict__ hist, const V3& P0, const V3& P1,
+__device__ __forceinline__ void bin_discs(const DG& dd, uint32_t* __restrict__ hist, const V3& P0, const V3& P1,
                                               const V3& V, int lane) {
   struct { int nbins; const double* discs; double disc_r, disc_h; } d;
   d.nbins = dd.nbins; d.discs = dd.discs; d.disc_r = dd.disc_r; d.disc_h = dd.disc_h;
   V3 dl; dl.x = P1.x - P0.x; dl.y = P1.y - P0.y; dl.z = P1.z - P0.z;
   const double tmax = dot3(dl, V);
-  uint32_t inc = 0;
   for (int b0 = 0; b0 < d.nbins; b0 += 64) {
     const int b = b0 + lane;
     bool hit = false;
     if (b < d.nbins) hit = segment_hits_tube(P0, V, tmax, d.discs + 6 * (size_t)b, d.disc_r, d.disc_h);
     if (hit) atomicAdd(&hist[b], 1u);
-    inc += (uint32_t)__popcll(__ballot(hit));
   }
-  return inc;
 }
 
 // ------------------------------------------------------------------ persistent trace kernel, one per sink
@@ -449,8 +449,7 @@ __device__ __forceinline__ void persistent_body(const Geom& g_arg, const DetGrid
   bool alive = false, parked = false;
   uint32_t iter = 0;
   uint32_t n_exited = 0, n_counted = 0, n_susp = 0, n_ended = 0, n_wall = 0;   // per lane
-  unsigned long long n_inc = 0;                                                  // per wave
-  uint32_t n_inc_lane = 0;                                                       // per lane (culled binning)
+  unsigned long long n_inc = 0;                                                  // per wave (SINK_LOG; the histogram sinks count at flush)
 
   for (;;) {
     // ---- refill dead lanes from this wave's range
@@ -578,7 +577,6 @@ __device__ __forceinline__ void persistent_body(const Geom& g_arg, const DetGrid
       }
       if (hit0) atomicAdd(&hist[b0], 1u);
       if (hit1) atomicAdd(&hist[b1], 1u);
-      n_inc += (unsigned long long)(__popcll(__ballot(hit0)) + __popcll(__ballot(hit1)));
     } else if (SINK == SINK_DZ) {
       // per-lane: TH1D(nbins,-1,1)->Fill(dz)
       bool hit = false;
@@ -589,7 +587,6 @@ __device__ __forceinline__ void persistent_body(const Geom& g_arg, const DetGrid
         hit = b >= 0 && b < nbins;
       }
       if (hit) atomicAdd(&hist[b], 1u);
-      n_inc += (unsigned long long)__popcll(__ballot(hit));
     } else {
       // ---- wave-cooperative binning of every line that left in this step
       unsigned long long em = __ballot(bin_me);
@@ -602,11 +599,11 @@ __device__ __forceinline__ void persistent_body(const Geom& g_arg, const DetGrid
         if (SINK == SINK_DISC) {
           V3 P0;
           P0.x = readlane_f64(r.prev.x, src); P0.y = readlane_f64(r.prev.y, src); P0.z = readlane_f64(r.prev.z, src);
-          n_inc += bin_discs(d, hist, P0, P, V, lane);
+          bin_discs(d, hist, P0, P, V, lane);
         } else {
           if (!LEAN && hit_line_mode == 1) hit_line_compat(P, V);
-          if (bin_mode == 0) n_inc += bin_brute(d, hist, P, V, lane);
-          else if (bin_mode == 1) n_inc_lane += bin_culled(d, hist, rowt, colt, P, V, lane);
+          if (bin_mode == 0) bin_brute(d, hist, P, V, lane);
+          else if (bin_mode == 1) bin_culled(d, hist, rowt, colt, P, V, lane);
           // bin_mode 2: diagnostic only (trace without binning; results are NOT a flux map)
         }
       }
@@ -619,16 +616,18 @@ __device__ __forceinline__ void persistent_body(const Geom& g_arg, const DetGrid
   atomicAdd(&sstat[3], (unsigned long long)(n_ended - n_exited - n_susp));  // absorbed
   atomicAdd(&sstat[4], (unsigned long long)n_susp);
   atomicAdd(&sstat[6], (unsigned long long)n_wall);
-  if (n_inc_lane) atomicAdd(&sstat[5], (unsigned long long)n_inc_lane);
   if (lane == 0) {
     atomicAdd(&sstat[0], (unsigned long long)(range_end - range_first));       // launched = this wave's range
     atomicAdd(&sstat[5], n_inc);
   }
   __syncthreads();
+  unsigned long long flushed = 0;   // increments of this block = sum of its LDS bins
   for (int b = tid; b < nbins; b += kBlock) {
     const uint32_t c = hist[b];
-    if (c) atomicAdd(&wk.hist[b], (unsigned long long)c);
+    if (c) { atomicAdd(&wk.hist[b], (unsigned long long)c); flushed += c; }
   }
+  if (SINK != SINK_LOG && flushed) atomicAdd(&sstat[5], flushed);
+  __syncthreads();
   if (tid < 7) {
     const unsigned long long c = sstat[tid];
     if (c) atomicAdd(&wk.stats[tid], c);

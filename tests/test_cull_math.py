@@ -1,0 +1,49 @@
+"""The f32 helper functions of the binning pre-selection (isx_kernels.hpp: atan2_cull, acos_cull) never decide a
+result, but the windows they produce must be conservative by the margins the kernel adds (1e-3 rad on the column
+half-width, 2e-3 rad on the row range).  Their polynomials are restated here in numpy float32 and their error
+claims checked against numpy's double-precision functions."""
+import numpy as np
+
+f32 = np.float32
+
+
+def atan2_cull(y, x):
+    y, x = y.astype(f32), x.astype(f32)
+    ax, ay = np.abs(x), np.abs(y)
+    mx, mn = np.maximum(ax, ay), np.minimum(ax, ay)
+    a = np.where(mx > 0, mn / np.where(mx > 0, mx, f32(1)), f32(0)).astype(f32)
+    s = (a * a).astype(f32)
+    r = f32(-0.01172120)
+    for c in (0.05265332, -0.11643287, 0.19354346, -0.33262347, 0.99997726):
+        r = (s * r + f32(c)).astype(f32)
+    r = (r * a).astype(f32)
+    r = np.where(ay > ax, f32(1.57079637) - r, r).astype(f32)
+    r = np.where(x < 0, f32(3.14159274) - r, r).astype(f32)
+    return np.where(y < 0, -r, r).astype(f32)
+
+
+def acos_cull(x):
+    x = x.astype(f32)
+    ax = np.abs(x)
+    p = f32(-0.0187293)
+    for c in (0.0742610, -0.2121144, 1.5707288):
+        p = (ax * p + f32(c)).astype(f32)
+    r = (np.sqrt(np.maximum(f32(0), f32(1) - ax)).astype(f32) * p).astype(f32)
+    return np.where(x < 0, f32(3.14159274) - r, r).astype(f32)
+
+
+def test_atan2_cull_error_below_2e5():
+    rng = np.random.default_rng(0)
+    y, x = rng.standard_normal(2_000_000) * 100, rng.standard_normal(2_000_000) * 100
+    err = np.abs(atan2_cull(y, x).astype(np.float64) - np.arctan2(y.astype(f32).astype(np.float64), x.astype(f32).astype(np.float64)))
+    assert err.max() < 2e-5
+    # axes and diagonals
+    for yy, xx in ((0.0, 1.0), (1.0, 0.0), (0.0, -1.0), (-1.0, 0.0), (1.0, 1.0), (-1.0, -1.0), (1e-30, 1.0)):
+        got = float(atan2_cull(np.array([yy]), np.array([xx]))[0])
+        assert abs(got - np.arctan2(yy, xx)) < 2e-5 or abs(abs(got - np.arctan2(yy, xx)) - 2 * np.pi) < 2e-5
+
+
+def test_acos_cull_error_below_1e4():
+    x = np.concatenate([np.linspace(-1, 1, 2_000_001), 1 - np.logspace(-8, 0, 2000), -1 + np.logspace(-8, 0, 2000)])
+    err = np.abs(acos_cull(x).astype(np.float64) - np.arccos(x.astype(f32).astype(np.float64)))
+    assert err.max() < 1e-4
