@@ -241,7 +241,7 @@ int enqueue(int sink, const isx_config* c, uint64_t n, uint64_t seed, uint64_t f
     d.rho_d = c->det_diameter / 2;
     d.R = c->det_distance;
     d.table = S.d_table; d.rowtab = S.d_rowtab; d.coltab = S.d_coltab;
-    lds = (((size_t)d.nbins * 4 + 15) & ~(size_t)15) + (size_t)(4 * d.n_theta + 2 * d.n_phi) * 8 + 64 + sizeof(Geom) + sizeof(DetGrid);
+    lds = (((size_t)d.nbins * 4 + 15) & ~(size_t)15) + (size_t)(4 * d.n_theta) * 8 + (size_t)(2 * d.n_phi) * sizeof(ColX) + 64 + sizeof(Geom) + sizeof(DetGrid);
   } else if (sink == SINK_PERPOS) {
     if (!pp || pp->rays_per_group < 1 || (pp->fold != 1 && pp->fold != 2)) return ISX_ERR_BAD_ARG;
     if (pp->d_table) {  // caller-supplied detector list (traceRays with one Detector)

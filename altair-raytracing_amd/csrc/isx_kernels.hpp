@@ -110,6 +110,15 @@ __device__ __forceinline__ float atan2_cull(float y, float x) {
   return r;
 }
 
+// One column of the detector grid as the binning loop wants it: (cos phi_j, sin phi_j) and the byte offset of
+// column (j mod n_phi) inside a histogram row.  The LDS table holds 2*n_phi entries, so a lane walks its
+// phi-window with a running pointer and never wraps an index.
+struct __align__(16) ColX {
+  double c, s;
+  uint32_t off4;
+  uint32_t pad[3];
+};
+
 // acos in f32 for |x| <= 1, |error| < 1e-4 rad (Abramowitz & Stegun 4.4.45 on |x|, reflected for x < 0;
 // restated in numpy and checked in tests/test_cull_math.py)
 __device__ __forceinline__ float acos_cull(float x) {
@@ -143,7 +152,7 @@ __device__ __forceinline__ void bin_brute(const DG& dd, uint32_t* __restrict__ h
 // so one candidate costs 8 fma + the sign test of  dd*dot^2 - 2*num*dot*dv + num^2 - (w/2)^2*dot^2.
 template <class DG>
 __device__ inline void bin_culled(const DG& dd, uint32_t* __restrict__ hist,
-                                      const double* __restrict__ rowt, const double* __restrict__ colt,
+                                      const double* __restrict__ rowt, const ColX* __restrict__ colx,
                                       const V3 P, const V3 V, int lane) {
   // one read of each constant (dd is a volatile LDS copy: nothing of it lives in SGPRs across the trace loop)
   struct { int n_theta, n_phi; double half_w2, rho_d, R, portz; const double* table; } d;
@@ -218,25 +227,24 @@ __device__ inline void bin_culled(const DG& dd, uint32_t* __restrict__ hist,
           e0c = -2.0 * fma(P.x, V.x, fma(P.y, V.y, pz * V.z)); e1c = 2.0 * (Ad * V.x); e2c = 2.0 * (Ad * V.y);
           const double f0 = fma(P.x, P.x, fma(P.y, P.y, fma(Ad, Ad, pz * pz)));
           f0c = f0 - d.half_w2; f1c = -2.0 * (Ad * P.x); f2c = -2.0 * (Ad * P.y);
-          // bound of 2e-9 (t1 + t3 + rhs) over every column of the row: |form| <= |k0|+|k1|+|k2|
-          const double sdot = fabs(a0c) + (fabs(a1c) + fabs(a2c));
-          const double snum = fabs(b0c) + (fabs(b1c) + fabs(b2c));
-          const double sdd = f0 + (fabs(f1c) + fabs(f2c));
-          bandc = 2e-9 * fma(sdot * sdot, sdd + d.half_w2, snum * snum);
-          if (jlo < 0) jlo += d.n_phi;   // keep the running column in [0, n_phi)
+          // bound of 2e-9 (t1 + t3 + rhs) over every column of the row (t1 = dd dot^2, t3 = num^2, rhs = (w/2)^2 dot^2
+          // in the notation of the header comment): |dot| <= |V||n| = 1 and num^2 <= dd |n|^2 = dd (Cauchy-Schwarz),
+          // dd <= f0 + |f1| + |f2|, so t1 + t3 + rhs <= 2 dd_max + (w/2)^2.
+          bandc = 2.1e-9 * fma(2.0, f0 + (fabs(f1c) + fabs(f2c)), d.half_w2);
+          if (jlo < 0) jlo += d.n_phi;   // start column in [0, n_phi); the window then runs to < 2 n_phi
         }
       }
-      int j = jlo;
-      const int rowbase = i * d.n_phi;
+      const ColX* cp = colx + jlo;
+      const uint32_t rowoff = (uint32_t)(i * d.n_phi) * 4u;
       for (int k = 0;; ++k) {                    // until the widest window of the wave is done
         const bool act = k < cnt;
         if (__ballot(act) == 0ull) break;
         bool hit = false;
-        int bin = 0;
+        uint32_t boff = 0;
         if (act) {
-          if (j >= d.n_phi) j -= d.n_phi;
-          bin = rowbase + j;
-          const double cph = colt[2 * j + 0], sph = colt[2 * j + 1];
+          const double cph = cp->c, sph = cp->s;
+          boff = rowoff + cp->off4;
+          cp++;
           const double dot = fma(a1c, cph, fma(a2c, sph, a0c));
           const double num = fma(b1c, cph, fma(b2c, sph, b0c));
           const double m2dv = fma(e1c, cph, fma(e2c, sph, e0c));
@@ -248,10 +256,9 @@ __device__ inline void bin_culled(const DG& dd, uint32_t* __restrict__ hist,
           //  mis-decided 16 of 2.3e9 hits at 2e7 rays; f64 keeps >100x margin down to |dot| = 1e-4)
           hit = diff < 0.0;
           if (fabs(dot) < 1e-4 || fabs(diff) <= bandc)  // too close to call: exact reference-order test
-            hit = check_intersection(d.table + 6 * (size_t)bin, d.half_w2, P, V);
-          j++;
+            hit = check_intersection(d.table + 6 * (size_t)(boff >> 2), d.half_w2, P, V);
         }
-        if (hit) atomicAdd(&hist[bin], 1u);
+        if (hit) atomicAdd(reinterpret_cast<uint32_t*>(reinterpret_cast<unsigned char*>(hist) + boff), 1u);
       }
     }
   }
@@ -400,8 +407,8 @@ __device__ __forceinline__ void persistent_body(const Geom& g_arg, const DetGrid
   const int nbins = d_arg.nbins;
   const size_t off_row = ((size_t)nbins * 4 + 15) & ~(size_t)15;
   double* rowt = reinterpret_cast<double*>(smem + off_row);
-  double* colt = rowt + (SINK == SINK_FLUX ? 4 * d_arg.n_theta : 0);
-  unsigned long long* sstat = reinterpret_cast<unsigned long long*>(colt + (SINK == SINK_FLUX ? 2 * d_arg.n_phi : 0));
+  ColX* colx = reinterpret_cast<ColX*>(rowt + (SINK == SINK_FLUX ? 4 * d_arg.n_theta : 0));
+  unsigned long long* sstat = reinterpret_cast<unsigned long long*>(colx + (SINK == SINK_FLUX ? 2 * d_arg.n_phi : 0));
   // LDS copies of the parameter blocks: rare paths read them on demand (volatile), the hot loop
   // keeps only `Hot` + a few scalars in SGPRs.
   Geom* g_lds = reinterpret_cast<Geom*>(sstat + 8);
@@ -411,7 +418,12 @@ __device__ __forceinline__ void persistent_body(const Geom& g_arg, const DetGrid
   for (int b = tid; b < nbins; b += kBlock) hist[b] = 0u;
   if (SINK == SINK_FLUX) {
     for (int b = tid; b < 4 * d_arg.n_theta; b += kBlock) rowt[b] = d_arg.rowtab[b];
-    for (int b = tid; b < 2 * d_arg.n_phi; b += kBlock) colt[b] = d_arg.coltab[b];
+    for (int b = tid; b < 2 * d_arg.n_phi; b += kBlock) {
+      const int j = b < d_arg.n_phi ? b : b - d_arg.n_phi;
+      ColX e;
+      e.c = d_arg.coltab[2 * j]; e.s = d_arg.coltab[2 * j + 1]; e.off4 = (uint32_t)j * 4u; e.pad[0] = e.pad[1] = e.pad[2] = 0u;
+      colx[b] = e;
+    }
   }
   if (tid < 8) sstat[tid] = 0ull;
   if (tid == 64) *g_lds = g_arg;
@@ -603,7 +615,7 @@ __device__ __forceinline__ void persistent_body(const Geom& g_arg, const DetGrid
         } else {
           if (!LEAN && hit_line_mode == 1) hit_line_compat(P, V);
           if (bin_mode == 0) bin_brute(d, hist, P, V, lane);
-          else if (bin_mode == 1) bin_culled(d, hist, rowt, colt, P, V, lane);
+          else if (bin_mode == 1) bin_culled(d, hist, rowt, colx, P, V, lane);
           // bin_mode 2: diagnostic only (trace without binning; results are NOT a flux map)
         }
       }
