@@ -367,17 +367,23 @@ static int interact(const geom* g, int kind, v3 q, v3* v, uint64_t seed, uint64_
      * roughness does not act on a Lambertian border: the reference's own sigma=0.5 map
      * (flux_at_observer/fluxmap_data.csv) is reproduced with the roughness ignored and is
      * missed by 9.5 % on axis with a roughness-tilted normal. */
-    v3 A, Bv;
-    onb(n, &A, &Bv);
     double u1 = isxo_u01(wl[0]), u2 = isxo_u01(wl[1]);
     double r = sqrt(u1);
     double z = sqrt(1.0 - u1);
     double sf, cf;
     isxo_sincos2pi(u2, &sf, &cf);
     double x = r * cf, y = r * sf;
-    w.x = fma(x, A.x, fma(y, Bv.x, z * n.x));
-    w.y = fma(x, A.y, fma(y, Bv.y, z * n.y));
-    w.z = fma(x, A.z, fma(y, Bv.z, z * n.z));
+    /* local sample (x, y, z), z = cos(polar) > 0, carried to the normal by the Householder reflection that maps
+     * sp*e_z onto n, sp = -sign(n.z) (the well-conditioned choice: |u|^2 = 2(1+|n.z|) for u = sp*e_z - n):
+     *   w = H (x, y, sp z),  H = I - 2 u u^T / |u|^2
+     * written out:  t = n.x x + n.y y,  c = z - t/(1+|n.z|),  w = (x + c n.x, y + c n.y, sp t + n.z z);  w.n = z. */
+    double sp = -copysign(1.0, n.z);
+    double t = fma(n.x, x, n.y * y);
+    double ia = -1.0 / (1.0 + fabs(n.z));
+    double c = fma(t, ia, z);
+    w.x = fma(c, n.x, x);
+    w.y = fma(c, n.y, y);
+    w.z = fma(n.z, z, sp * t);
   } else {
     /* specular reflection about the normal, tilted by a Gaussian polar angle (SetGaussianRoughness) */
     v3 M = n;

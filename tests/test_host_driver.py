@@ -244,7 +244,9 @@ def test_small_macros(cli, isx, tmp_path):
     dirs = np.loadtxt(tmp_path / "3dRayLog.txt", comments="#")
     assert np.abs((dirs ** 2).sum(1) - 1).max() < 1e-4 and (dirs[:, 2] < 0).all()
     h, _ = np.histogram(dirs[:, 2], bins=100, range=(-1, 1))
-    assert np.abs(h - ad[:, 1]).sum() <= 4          # 6 significant digits in the text log
+    # the log keeps 6 significant digits: a value within 5e-7 of a bin edge may land next door when re-binned
+    # (expected ~1 of 20000 values, each flip counts twice)
+    assert np.abs(h - ad[:, 1]).sum() <= 12
 
 
 @pytest.mark.gpu
