@@ -686,7 +686,7 @@ isx_endstates_kernel(const Geom g, uint64_t seed, uint64_t first, uint64_t n, in
 
 // ------------------------------------------------------------------ device-side self test of the numeric contract
 // out[k] for k in [0,n): op 0 sqrt(a), 1 a/b, 2 fma(a,b,c), 3 log_pos(a), 4/5 sincos2pi(a), 6/7 sincos_cw(a),
-// 8 sqrt_unit(a), 9 neg_rcp_unit(a)
+// 8 sqrt_unit(a), 9 neg_rcp_unit(a), 10/11 circle_point(a) cos/sin
 extern "C" __global__ void isx_mathprobe_kernel(int op, const double* __restrict__ a, const double* __restrict__ b,
                                                 const double* __restrict__ c, double* __restrict__ out, int n) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -702,6 +702,8 @@ extern "C" __global__ void isx_mathprobe_kernel(int op, const double* __restrict
     case 6: sincos_cw(a[i], s, co); out[i] = s; break;
     case 8: out[i] = sqrt_unit(a[i]); break;
     case 9: out[i] = neg_rcp_unit(a[i]); break;
+    case 10: circle_point(a[i], co, s); out[i] = co; break;
+    case 11: circle_point(a[i], co, s); out[i] = s; break;
     default: sincos_cw(a[i], s, co); out[i] = co; break;
   }
 }

@@ -116,6 +116,23 @@ void isxo_sincos2pi(double u, double* s, double* c) {
   double x = r * PIO2;
   quadrant((int)kd, kern_sin(x), kern_cos(x), s, c);
 }
+/* A point uniformly distributed on the unit circle from u in (0,1), for the azimuth of the cosine emission (only
+ * uniformity matters there, not which angle a given u maps to): psi = (u - 1/2) pi/2 lies in (-pi/4, pi/4), where
+ * the polynomial kernels need no quadrant logic, and two angle doublings carry it to 4 psi, uniform on (-pi, pi).
+ * The cosine is the plain Horner form (no fdlibm tail correction): |c^2 + s^2 - 1| < 3e-15, and every direction
+ * built from it is renormalised by the Newton step of interact(). */
+void isxo_circle_point(double u, double* c, double* s) {
+  const double PIO2 = 1.57079632679489655800e+00;
+  const double C1 = 4.16666666666666019037e-02, C2 = -1.38888888888741095749e-03, C3 = 2.48015872894767294178e-05,
+               C4 = -2.75573143513906633035e-07, C5 = 2.08757232129817482790e-09, C6 = -1.13596475577881948265e-11;
+  double psi = (u - 0.5) * PIO2;
+  double z = psi * psi;
+  double sn = kern_sin(psi);
+  double cs = fma(z, fma(z, fma(z, fma(z, fma(z, fma(z, fma(z, C6, C5), C4), C3), C2), C1), -0.5), 1.0);
+  double c2 = fma(cs, cs, -(sn * sn)), s2 = fma(cs, sn, cs * sn);
+  *c = fma(c2, c2, -(s2 * s2));
+  *s = fma(c2, s2, c2 * s2);
+}
 /* general argument, Cody-Waite two-constant reduction by pi/2 */
 void isxo_sincos(double x, double* s, double* c) {
   const double INVPIO2 = 6.36619772367581382433e-01;
@@ -371,7 +388,7 @@ static int interact(const geom* g, int kind, v3 q, v3* v, uint64_t seed, uint64_
     double r = sqrt(u1);
     double z = sqrt(1.0 - u1);
     double sf, cf;
-    isxo_sincos2pi(u2, &sf, &cf);
+    isxo_circle_point(u2, &cf, &sf);
     double x = r * cf, y = r * sf;
     /* local sample (x, y, z), z = cos(polar) > 0, carried to the normal by the Householder reflection that maps
      * sp*e_z onto n, sp = -sign(n.z) (the well-conditioned choice: |u|^2 = 2(1+|n.z|) for u = sp*e_z - n):
@@ -433,7 +450,7 @@ static int interact_chord(const geom* g, v3* T, uint64_t seed, uint64_t ray, uin
   double zz = fma(-2.0, isxo_u01(wl[0]), 1.0);
   double s2 = sqrt(fma(-zz, zz, 1.0));
   double sf, cf;
-  isxo_sincos2pi(isxo_u01(wl[1]), &sf, &cf);
+  isxo_circle_point(isxo_u01(wl[1]), &cf, &sf);
   double rxy = g->r_in * s2;
   T->x = rxy * cf; T->y = rxy * sf; T->z = g->r_in * zz;
   return 1;

@@ -49,6 +49,7 @@ void isxo_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t o
 double isxo_u01(uint32_t w);
 double isxo_log(double x);                            /* x in (0,1], normal            */
 void isxo_sincos2pi(double u, double* s, double* c);  /* sin/cos(2*pi*u), u in [0,1)   */
+void isxo_circle_point(double u, double* c, double* s); /* uniform point of the unit circle, u in (0,1) */
 void isxo_sincos(double x, double* s, double* c);     /* |x| < 1e5                     */
 
 /* Detector::setPosition (fluxAtObserver.C:49-68) for the whole grid: out[(i*n_phi+j)*6]. */

@@ -73,6 +73,8 @@ def lib():
         L.isxo_log.restype = dbl
         L.isxo_sincos2pi.argtypes = [dbl, P(dbl), P(dbl)]
         L.isxo_sincos2pi.restype = None
+        L.isxo_circle_point.argtypes = [dbl, P(dbl), P(dbl)]
+        L.isxo_circle_point.restype = None
         L.isxo_sincos.argtypes = [dbl, P(dbl), P(dbl)]
         L.isxo_sincos.restype = None
         L.isxo_detector_table.argtypes = [P(Config), P(dbl)]
@@ -111,6 +113,12 @@ def sincos2pi(u):
     s, c = C.c_double(), C.c_double()
     lib().isxo_sincos2pi(u, C.byref(s), C.byref(c))
     return s.value, c.value
+
+
+def circle_point(u):
+    c, s = C.c_double(), C.c_double()
+    lib().isxo_circle_point(u, C.byref(c), C.byref(s))
+    return c.value, s.value
 
 
 def sincos(x):

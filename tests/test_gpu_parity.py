@@ -91,6 +91,9 @@ def test_elementary_functions_bit_exact(isx, orc):
     sc = np.array([orc.sincos2pi(float(x)) for x in u])
     assert np.array_equal(_bits(isx.mathprobe(4, u)), _bits(sc[:, 0]))
     assert np.array_equal(_bits(isx.mathprobe(5, u)), _bits(sc[:, 1]))
+    cp = np.array([orc.circle_point(float(x)) for x in u])
+    assert np.array_equal(_bits(isx.mathprobe(10, u)), _bits(cp[:, 0]))
+    assert np.array_equal(_bits(isx.mathprobe(11, u)), _bits(cp[:, 1]))
     x = (rng.random(20000) - 0.5) * 30
     sc = np.array([orc.sincos(float(v)) for v in x])
     assert np.array_equal(_bits(isx.mathprobe(6, x)), _bits(sc[:, 0]))

@@ -96,3 +96,15 @@ def test_check_intersection_geometry(orc):
     assert hit((0, 0, -300), (1, 0, 0)) == 0            # parallel: |dot| < 1e-10
     assert hit((0, 0, -300), (1, 0, 1e-11)) == 0
     assert hit((5, 5, -150), (0.1, -0.2, -0.97), 10.0) == 0
+
+
+def test_circle_point_is_a_uniform_unit_circle_point(orc):
+    """isxo_circle_point(u) = (cos 4psi, sin 4psi), psi = (u - 1/2) pi/2: unit and exact to a few 1e-16,
+    and therefore uniform on the circle when u is uniform."""
+    rng = np.random.default_rng(21)
+    w = np.concatenate([rng.integers(0, 2 ** 32, 50000, dtype=np.uint64), [0, 1, 2 ** 31 - 1, 2 ** 31, 2 ** 32 - 1]])
+    u = (w.astype(np.float64) + 0.5) * 2.0 ** -32
+    cs = np.array([orc.circle_point(float(x)) for x in u])
+    assert np.abs((cs ** 2).sum(1) - 1).max() < 3e-15
+    ang = 2 * np.pi * (u - 0.5)
+    assert np.abs(cs[:, 0] - np.cos(ang)).max() < 2e-15 and np.abs(cs[:, 1] - np.sin(ang)).max() < 2e-15
