@@ -484,6 +484,7 @@ __device__ __forceinline__ void persistent_body(const Geom& g_arg, const DetGrid
     // need it, every 4th iteration, or nothing else is left to do.  Scheduling only - a ray's
     // history never depends on it.
     bool bin_me = false;
+    int pend = 0;     // end status of the ray this lane finished during the trip, 0 if none
     // what happens to a lane once its boundary (kind, q) is known
     auto arrive = [&](int kind, const V3& q) {
       int st = ray_arrive<SINK == SINK_DISC, LEAN, CH>(h, g, r, seed, kind, q);
@@ -492,18 +493,7 @@ __device__ __forceinline__ void persistent_body(const Geom& g_arg, const DetGrid
         ray_rescatter(g, r, seed);
         st = 0;
       }
-      if (st != 0) {
-        alive = false;
-        n_ended++;
-        n_wall += r.j;
-        if (n_wall > 0x7fffffffu) { atomicAdd(&sstat[6], (unsigned long long)n_wall); n_wall = 0; }
-        if (st == ST_EXITED) {
-          n_exited++;
-          const bool below = r.p.z < portz;  // isRayPassingThroughExitPort, fluxAtObserver.C:162-166
-          if (below) n_counted++;
-          bin_me = (SINK == SINK_DISC) ? true : below;
-        } else if (st == ST_SUSPENDED) n_susp++;
-      }
+      if (st != 0) { alive = false; pend = st; }   // the census is taken once per trip (below), not per bounce
     };
     // hot boundary search of one lane: true if it arrived on the inner mirror patch, else the lane parks
     auto hot_search = [&](V3& q) -> bool {
@@ -541,6 +531,19 @@ __device__ __forceinline__ void persistent_body(const Geom& g_arg, const DetGrid
         else parked = true;
       }
       if (arrived) arrive(K_INNER, q);
+    }
+    // ---- census of the rays that ended in this trip (a dead lane stays dead until the next refill, so each ended
+    // ray is seen exactly once, with its final point and direction still in place)
+    if (pend != 0) {
+      n_ended++;
+      n_wall += r.j;
+      if (n_wall > 0x7fffffffu) { atomicAdd(&sstat[6], (unsigned long long)n_wall); n_wall = 0; }
+      if (pend == ST_EXITED) {
+        n_exited++;
+        const bool below = r.p.z < portz;  // isRayPassingThroughExitPort, fluxAtObserver.C:162-166
+        if (below) n_counted++;
+        bin_me = (SINK == SINK_DISC) ? true : below;
+      } else if (pend == ST_SUSPENDED) n_susp++;
     }
     if (SINK == SINK_LOG) {
       // wave-aggregated append: one atomic on the cursor per wave-step, 32-byte records
