@@ -20,4 +20,5 @@ from ._abi import (  # noqa: F401
 
 __all__ = ["abi", "sharding", "shard", "fluxmap_sharded", "Config", "Stats", "IsxError", "default_config", "init", "shutdown", "device_info", "set_option",
            "fluxmap", "fluxmap_device", "fluxmap_per_position", "trace_rays_detector", "exit_directions", "fluxmap_series", "sync", "take_stats", "trace_endstates", "disc_sweep", "exit_dz_hist",
-           "detector_table", "mathprobe", "load", "LIB_PATH", "EXPORTS"]
+           "detector_table", "mathprobe", "load", "LIB_PATH", "EXPORTS",
+           "SOURCE_PENCIL", "SOURCE_BRDF", "RAY_EXITED", "RAY_ABSORBED", "RAY_SUSPENDED"]

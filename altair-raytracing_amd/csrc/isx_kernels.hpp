@@ -150,6 +150,85 @@ __device__ __forceinline__ void bin_brute(const DG& dd, uint32_t* __restrict__ h
 //   dot = V.n, num = (P-c).n, dv = (P-c).V, dd = |P-c|^2
 // are all of the form k0 + k1*cos(phi_j) + k2*sin(phi_j)  (c = (A c, A s, z), n = (-S s, S c, -C)),
 // so one candidate costs 8 fma + the sign test of  dd*dot^2 - 2*num*dot*dv + num^2 - (w/2)^2*dot^2.
+struct CapWin { float Fz, AF2, AF, jf, ch2, inv_dphi; };   // the cap around one piercing point, as the row windows need it
+
+// Rows ilo..ihi, 64 at a time (lane = row).  CAPS: each row's phi-window is its intersection with the cap `w`;
+// otherwise the whole row.  Then the column walk with the exact decision.
+template <bool CAPS, class D>
+__device__ __forceinline__ void walk_rows(const D& d, uint32_t* __restrict__ hist, const double* __restrict__ rowt,
+                                          const ColX* __restrict__ colx, const V3& P, const V3& V, int lane, int ilo,
+                                          int ihi, const CapWin& w) {
+#pragma unroll 1
+  for (int i0 = ilo; i0 <= ihi; i0 += 64) {
+    const int i = i0 + lane;
+    int jlo = 0, cnt = 0;
+    double a0c = 0, a1c = 0, a2c = 0, b0c = 0, b1c = 0, b2c = 0, e0c = 0, e1c = 0, e2c = 0, f0c = 0, f1c = 0, f2c = 0, bandc = 0;
+    if (i <= ihi) {
+      const double Sd = rowt[4 * i + 0], Cd = rowt[4 * i + 1], zd = rowt[4 * i + 2], Ad = rowt[4 * i + 3];
+      if (!CAPS) { jlo = 0; cnt = d.n_phi; }
+      else {
+        const float zi = (float)zd, Ai = (float)Ad;
+        const float dzi = zi - w.Fz;
+        const float num = fmaf(Ai, Ai, fmaf(dzi, dzi, w.AF2)) - w.ch2;
+        const float den = 2.0f * Ai * w.AF;
+        const float slack = 2e-5f * (fmaf(Ai, Ai, w.AF2) + w.ch2);  // f32 rounding of num
+        if (num - slack <= -den) { jlo = 0; cnt = d.n_phi; }
+        else if (num - slack > den) { cnt = 0; }
+        else {
+          float K = (num - slack) * rcp_cull(den) - 2e-5f;
+          K = fminf(1.f, fmaxf(-1.f, K));
+          const float dl = acos_cull(K) + 1e-3f;
+          const float hw = dl * w.inv_dphi;
+          const int lo = (int)ceilf(w.jf - hw), hi = (int)floorf(w.jf + hw);
+          jlo = lo; cnt = hi - lo + 1;
+          if (cnt < 0) cnt = 0;
+          if (cnt >= d.n_phi) { jlo = 0; cnt = d.n_phi; }
+        }
+      }
+      if (cnt > 0) {
+        const double pz = P.z - zd;
+        a0c = -(Cd * V.z); a1c = Sd * V.y; a2c = -(Sd * V.x);
+        b0c = -(Cd * pz);  b1c = Sd * P.y; b2c = -(Sd * P.x);
+        // e: -2 dv,  f: dd - (w/2)^2   (the factors the sign test needs, folded into the row constants)
+        e0c = -2.0 * fma(P.x, V.x, fma(P.y, V.y, pz * V.z)); e1c = 2.0 * (Ad * V.x); e2c = 2.0 * (Ad * V.y);
+        const double f0 = fma(P.x, P.x, fma(P.y, P.y, fma(Ad, Ad, pz * pz)));
+        f0c = f0 - d.half_w2; f1c = -2.0 * (Ad * P.x); f2c = -2.0 * (Ad * P.y);
+        // bound of 2e-9 (t1 + t3 + rhs) over every column of the row (t1 = dd dot^2, t3 = num^2, rhs = (w/2)^2 dot^2
+        // in the notation of the header comment): |dot| <= |V||n| = 1 and num^2 <= dd |n|^2 = dd (Cauchy-Schwarz),
+        // dd <= f0 + |f1| + |f2|, so t1 + t3 + rhs <= 2 dd_max + (w/2)^2.
+        bandc = 2.1e-9 * fma(2.0, f0 + (fabs(f1c) + fabs(f2c)), d.half_w2);
+        if (jlo < 0) jlo += d.n_phi;   // start column in [0, n_phi); the window then runs to < 2 n_phi
+      }
+    }
+    const ColX* cp = colx + jlo;
+    const uint32_t rowoff = (uint32_t)(i * d.n_phi) * 4u;
+    for (int k = 0;; ++k) {                    // until the widest window of the wave is done
+      const bool act = k < cnt;
+      if (__ballot(act) == 0ull) break;
+      bool hit = false;
+      uint32_t boff = 0;
+      if (act) {
+        const double cph = cp->c, sph = cp->s;
+        boff = rowoff + cp->off4;
+        cp++;
+        const double dot = fma(a1c, cph, fma(a2c, sph, a0c));
+        const double num = fma(b1c, cph, fma(b2c, sph, b0c));
+        const double m2dv = fma(e1c, cph, fma(e2c, sph, e0c));
+        const double ddw = fma(f1c, cph, fma(f2c, sph, f0c));
+        // sign of  dot^2 (dd - (w/2)^2) - 2 num dot dv + num^2  (|V| = 1 to rounding: Newton-renormalised)
+        const double diff = fma(dot, fma(dot, ddw, num * m2dv), num * num);
+        // evaluation error ~1e-15 of the terms' scale; bandc >= 2e-9 of that scale for every column of the row
+        // (an f32 version of this test was tried and rejected: its error grows like 1/|dot| and it
+        //  mis-decided 16 of 2.3e9 hits at 2e7 rays; f64 keeps >100x margin down to |dot| = 1e-4)
+        hit = diff < 0.0;
+        if (fabs(dot) < 1e-4 || fabs(diff) <= bandc)  // too close to call: exact reference-order test
+          hit = check_intersection(d.table + 6 * (size_t)(boff >> 2), d.half_w2, P, V);
+      }
+      if (hit) atomicAdd(reinterpret_cast<uint32_t*>(reinterpret_cast<unsigned char*>(hist) + boff), 1u);
+    }
+  }
+}
+
 template <class DG>
 __device__ inline void bin_culled(const DG& dd, uint32_t* __restrict__ hist,
                                       const double* __restrict__ rowt, const ColX* __restrict__ colx,
@@ -167,100 +246,58 @@ __device__ inline void bin_culled(const DG& dd, uint32_t* __restrict__ hist,
   const float R2 = Rf * Rf;
   const float dO = sqrt_cull(dO2);
   const float a1 = dO + rho;
-  if (!(a1 < 0.999f * Rf)) { bin_brute(dd, hist, P, V, lane); return; }
-  const float sF = sqrt_cull(R2 - dO2);
-  const float smin = sqrt_cull(R2 - a1 * a1);
-  const float a0 = fmaxf(0.f, dO - rho);
-  const float smax = sqrt_cull(R2 - a0 * a0);
-  const float ext = fmaxf(sF - smin, smax - sF);
-  // every detector centre within rho_d of the line lies within chord ch of a piercing point
-  const float ch2 = fmaf(ext, ext, rho * rho) * 1.0001f + 1e-3f;
-  if (!(4.0f * (R2 - dO2) > 4.04f * ch2)) { bin_brute(dd, hist, P, V, lane); return; }
-  const float ch = sqrt_cull(ch2);
-  const float inv_dphi = (float)d.n_phi * 0.15915494309f;  // 1/dphi
+  CapWin w;
+  w.inv_dphi = (float)d.n_phi * 0.15915494309f;            // 1/dphi
   const float inv_dth = (float)d.n_theta * 0.63661977237f;   // 1 / row spacing in theta
-  const float omega = ch * rcp_cull(Rf) * 1.01f + 2e-3f;          // cap angular radius 2*asin(ch/2R), conservatively
+  // Normal case (a line that left through the port passes near O): every detector centre within rho_d of the line
+  // lies within chord ch of one of the two points where the line pierces S(O,R) -> cap windows.
+  bool caps = a1 < 0.999f * Rf;
+  float sF = 0.f, ch = 0.f, omega = 0.f;
+  w.ch2 = 0.f;
+  if (caps) {
+    sF = sqrt_cull(R2 - dO2);
+    const float smin = sqrt_cull(R2 - a1 * a1);
+    const float a0 = fmaxf(0.f, dO - rho);
+    const float smax = sqrt_cull(R2 - a0 * a0);
+    const float ext = fmaxf(sF - smin, smax - sF);
+    w.ch2 = fmaf(ext, ext, rho * rho) * 1.0001f + 1e-3f;
+    caps = 4.0f * (R2 - dO2) > 4.04f * w.ch2;
+    ch = sqrt_cull(w.ch2);
+    omega = ch * rcp_cull(Rf) * 1.01f + 2e-3f;          // cap angular radius 2*asin(ch/2R), conservatively
+  }
+  if (!caps) {
+    // Grazing or nearly tangent line (caps would merge), or one that misses S(O,R): typical for the re-scattered rays
+    // of the BRDF source model, which start on the world box.  A hit needs dist(c,L) <= rho_d with |c-O| = R, hence
+    // dist(O,L) <= R + rho_d: farther out nothing can be hit.  Else whole rows, limited to the z-extent of the stretch
+    // of the line inside the shell R +- rho_d: a centre within rho_d of the line point X = H + s V has
+    // | |X-O| - R | <= rho_d, so s^2 <= (R+rho_d)^2 - dO^2, and its height differs from X's by at most rho_d, i.e.
+    // z_i - O_z = -R cos(theta_i) lies in [hz - dz, hz + dz].  Same exact decision as in the cap case.
+    if (dO - rho > 1.001f * Rf) return;
+    const float sm = sqrt_cull(fmaxf(0.f, fmaf(Rf + rho, Rf + rho, -dO2))) * 1.001f;
+    const float dz = fmaf(sm, fabsf((float)V.z), rho) * 1.001f + 1e-3f;
+    const float iR = rcp_cull(Rf);
+    const float clo = fminf(1.f, fmaxf(-1.f, -((float)hz - dz) * iR)), chi = fminf(1.f, fmaxf(-1.f, -((float)hz + dz) * iR));
+    const int ilo = max((int)floorf((acos_cull(clo) - 2e-3f) * inv_dth - 0.5f - 1e-2f), 0);
+    const int ihi = min((int)ceilf((acos_cull(chi) + 2e-3f) * inv_dth - 0.5f + 1e-2f), d.n_theta - 1);
+    walk_rows<false>(d, hist, rowt, colx, P, V, lane, ilo, ihi, w);
+    return;
+  }
 #pragma unroll 1
   for (int side = 0; side < 2; ++side) {
     const double s = side == 0 ? ((double)sF - wv) : (-(double)sF - wv);
-    const float Fx = (float)fma(s, V.x, P.x), Fy = (float)fma(s, V.y, P.y), Fz = (float)fma(s, V.z, P.z);
-    if (Fz - ch > (float)d.portz) continue;  // cap entirely above every detector row
-    const float AF2 = fmaf(Fx, Fx, Fy * Fy);
-    const float AF = sqrt_cull(AF2);
+    const float Fx = (float)fma(s, V.x, P.x), Fy = (float)fma(s, V.y, P.y);
+    w.Fz = (float)fma(s, V.z, P.z);
+    if (w.Fz - ch > (float)d.portz) continue;  // cap entirely above every detector row
+    w.AF2 = fmaf(Fx, Fx, Fy * Fy);
+    w.AF = sqrt_cull(w.AF2);
     float phiF = atan2_cull(Fy, Fx);
     if (phiF < 0.f) phiF += 6.28318530718f;
-    const float jf = phiF * inv_dphi - 0.5f;
+    w.jf = phiF * w.inv_dphi - 0.5f;
     // rows that can intersect the cap: |theta_i - theta_F| <= omega, theta measured from -z about O
-    const float thF = atan2_cull(AF, (float)d.portz - Fz);
-    int ilo = (int)floorf((thF - omega) * inv_dth - 0.5f - 1e-3f), ihi = (int)ceilf((thF + omega) * inv_dth - 0.5f + 1e-3f);
-    ilo = max(ilo, 0);
-    ihi = min(ihi, d.n_theta - 1);
-#pragma unroll 1
-    for (int i0 = ilo; i0 <= ihi; i0 += 64) {
-      const int i = i0 + lane;
-      int jlo = 0, cnt = 0;
-      double a0c = 0, a1c = 0, a2c = 0, b0c = 0, b1c = 0, b2c = 0, e0c = 0, e1c = 0, e2c = 0, f0c = 0, f1c = 0, f2c = 0, bandc = 0;
-      if (i <= ihi) {
-        const double Sd = rowt[4 * i + 0], Cd = rowt[4 * i + 1], zd = rowt[4 * i + 2], Ad = rowt[4 * i + 3];
-        const float zi = (float)zd, Ai = (float)Ad;
-        const float dzi = zi - Fz;
-        const float num = fmaf(Ai, Ai, fmaf(dzi, dzi, AF2)) - ch2;
-        const float den = 2.0f * Ai * AF;
-        const float slack = 2e-5f * (fmaf(Ai, Ai, AF2) + ch2);  // f32 rounding of num
-        if (num - slack <= -den) { jlo = 0; cnt = d.n_phi; }
-        else if (num - slack > den) { cnt = 0; }
-        else {
-          float K = (num - slack) * rcp_cull(den) - 2e-5f;
-          K = fminf(1.f, fmaxf(-1.f, K));
-          const float dl = acos_cull(K) + 1e-3f;
-          const float hw = dl * inv_dphi;
-          const int lo = (int)ceilf(jf - hw), hi = (int)floorf(jf + hw);
-          jlo = lo; cnt = hi - lo + 1;
-          if (cnt < 0) cnt = 0;
-          if (cnt >= d.n_phi) { jlo = 0; cnt = d.n_phi; }
-        }
-        if (cnt > 0) {
-          const double pz = P.z - zd;
-          a0c = -(Cd * V.z); a1c = Sd * V.y; a2c = -(Sd * V.x);
-          b0c = -(Cd * pz);  b1c = Sd * P.y; b2c = -(Sd * P.x);
-          // e: -2 dv,  f: dd - (w/2)^2   (the factors the sign test needs, folded into the row constants)
-          e0c = -2.0 * fma(P.x, V.x, fma(P.y, V.y, pz * V.z)); e1c = 2.0 * (Ad * V.x); e2c = 2.0 * (Ad * V.y);
-          const double f0 = fma(P.x, P.x, fma(P.y, P.y, fma(Ad, Ad, pz * pz)));
-          f0c = f0 - d.half_w2; f1c = -2.0 * (Ad * P.x); f2c = -2.0 * (Ad * P.y);
-          // bound of 2e-9 (t1 + t3 + rhs) over every column of the row (t1 = dd dot^2, t3 = num^2, rhs = (w/2)^2 dot^2
-          // in the notation of the header comment): |dot| <= |V||n| = 1 and num^2 <= dd |n|^2 = dd (Cauchy-Schwarz),
-          // dd <= f0 + |f1| + |f2|, so t1 + t3 + rhs <= 2 dd_max + (w/2)^2.
-          bandc = 2.1e-9 * fma(2.0, f0 + (fabs(f1c) + fabs(f2c)), d.half_w2);
-          if (jlo < 0) jlo += d.n_phi;   // start column in [0, n_phi); the window then runs to < 2 n_phi
-        }
-      }
-      const ColX* cp = colx + jlo;
-      const uint32_t rowoff = (uint32_t)(i * d.n_phi) * 4u;
-      for (int k = 0;; ++k) {                    // until the widest window of the wave is done
-        const bool act = k < cnt;
-        if (__ballot(act) == 0ull) break;
-        bool hit = false;
-        uint32_t boff = 0;
-        if (act) {
-          const double cph = cp->c, sph = cp->s;
-          boff = rowoff + cp->off4;
-          cp++;
-          const double dot = fma(a1c, cph, fma(a2c, sph, a0c));
-          const double num = fma(b1c, cph, fma(b2c, sph, b0c));
-          const double m2dv = fma(e1c, cph, fma(e2c, sph, e0c));
-          const double ddw = fma(f1c, cph, fma(f2c, sph, f0c));
-          // sign of  dot^2 (dd - (w/2)^2) - 2 num dot dv + num^2  (|V| = 1 to rounding: Newton-renormalised)
-          const double diff = fma(dot, fma(dot, ddw, num * m2dv), num * num);
-          // evaluation error ~1e-15 of the terms' scale; bandc >= 2e-9 of that scale for every column of the row
-          // (an f32 version of this test was tried and rejected: its error grows like 1/|dot| and it
-          //  mis-decided 16 of 2.3e9 hits at 2e7 rays; f64 keeps >100x margin down to |dot| = 1e-4)
-          hit = diff < 0.0;
-          if (fabs(dot) < 1e-4 || fabs(diff) <= bandc)  // too close to call: exact reference-order test
-            hit = check_intersection(d.table + 6 * (size_t)(boff >> 2), d.half_w2, P, V);
-        }
-        if (hit) atomicAdd(reinterpret_cast<uint32_t*>(reinterpret_cast<unsigned char*>(hist) + boff), 1u);
-      }
-    }
+    const float thF = atan2_cull(w.AF, (float)d.portz - w.Fz);
+    const int ilo = max((int)floorf((thF - omega) * inv_dth - 0.5f - 1e-3f), 0);
+    const int ihi = min((int)ceilf((thF + omega) * inv_dth - 0.5f + 1e-3f), d.n_theta - 1);
+    walk_rows<true>(d, hist, rowt, colx, P, V, lane, ilo, ihi, w);
   }
 }
 

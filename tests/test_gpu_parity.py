@@ -330,6 +330,23 @@ def test_culled_binning_equals_brute_force_at_scale(isx):
     assert sb.bin_increments == sc.bin_increments == int(culled.sum())
 
 
+def test_whole_row_fallback_equals_brute_force(isx):
+    """Lines that do not come from the port (re-scattered rays of the BRDF source model start on the world box) graze or
+    miss the sphere of detector centres: the cap construction does not apply and the binning walks whole rows (or skips
+    the line when it stays farther than R + rho_d from O).  2e6 such rays, culled == brute."""
+    c = dict(_cfg_variants(isx))["brdf_source"]
+    assert c.source_model == 1
+    n = 2_000_000
+    isx.set_option("bin_mode", 0)
+    try:
+        brute, sb = isx.fluxmap(c, n, 24680)
+    finally:
+        isx.set_option("bin_mode", 1)
+    culled, sc = isx.fluxmap(c, n, 24680)
+    assert np.array_equal(brute, culled)
+    assert sb.bin_increments == sc.bin_increments == int(culled.sum()) and sc.bin_increments > 0
+
+
 def test_exit_direction_log_bit_exact(isx, orc):
     """Un-binned exit log (3dRayLog.txt): ids and directions equal the oracle's, in ray order; overflow is reported."""
     def mk(mod):
