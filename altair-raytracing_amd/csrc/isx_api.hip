@@ -280,11 +280,13 @@ int enqueue(int sink, const isx_config* c, uint64_t n, uint64_t seed, uint64_t f
   rc = get_event(&e0); if (rc) return rc;
   rc = get_event(&e1); if (rc) return rc;
   // the lean kernel serves the headline configuration; anything else takes the full-featured variant
-  const bool lean = c->lambertian && c->surface_model == ISX_SURFACE_ROBAST && c->source_model == ISX_SOURCE_PENCIL &&
-                    c->hit_line_mode == ISX_HITLINE_LAST_SEGMENT;
+  const bool lean_surface = c->lambertian && c->surface_model == ISX_SURFACE_ROBAST && c->hit_line_mode == ISX_HITLINE_LAST_SEGMENT;
+  const bool lean = lean_surface && c->source_model == ISX_SOURCE_PENCIL;
   const bool chord = lean && c->trace_mode == ISX_TRACE_CHORD;
+  const bool brdf = lean_surface && c->source_model == ISX_SOURCE_BRDF && c->trace_mode != ISX_TRACE_CHORD;
   const void* fn = sink == SINK_FLUX ? (chord ? (const void*)isx_trace_bin_chord_kernel
-                                        : lean ? (const void*)isx_trace_bin_kernel : (const void*)isx_trace_bin_full_kernel)
+                                        : lean ? (const void*)isx_trace_bin_kernel
+                                        : brdf ? (const void*)isx_trace_bin_brdf_kernel : (const void*)isx_trace_bin_full_kernel)
                    : sink == SINK_DZ ? (const void*)isx_trace_dz_kernel
                    : sink == SINK_DISC ? (const void*)isx_trace_disc_kernel
                    : sink == SINK_PERPOS ? (const void*)isx_trace_perpos_kernel : (const void*)isx_trace_log_kernel;
@@ -292,6 +294,7 @@ int enqueue(int sink, const isx_config* c, uint64_t n, uint64_t seed, uint64_t f
   HIPCHK(hipEventRecord(e0, S.stream));
   if (sink == SINK_FLUX && chord) hipLaunchKernelGGL(isx_trace_bin_chord_kernel, dim3(grid), dim3(kBlock), lds, S.stream, g, d, wk);
   else if (sink == SINK_FLUX && lean) hipLaunchKernelGGL(isx_trace_bin_kernel, dim3(grid), dim3(kBlock), lds, S.stream, g, d, wk);
+  else if (sink == SINK_FLUX && brdf) hipLaunchKernelGGL(isx_trace_bin_brdf_kernel, dim3(grid), dim3(kBlock), lds, S.stream, g, d, wk);
   else if (sink == SINK_FLUX) hipLaunchKernelGGL(isx_trace_bin_full_kernel, dim3(grid), dim3(kBlock), lds, S.stream, g, d, wk);
   else if (sink == SINK_DZ) hipLaunchKernelGGL(isx_trace_dz_kernel, dim3(grid), dim3(kBlock), lds, S.stream, g, d, wk);
   else if (sink == SINK_DISC) hipLaunchKernelGGL(isx_trace_disc_kernel, dim3(grid), dim3(kBlock), lds, S.stream, g, d, wk);

@@ -437,7 +437,7 @@ __device__ __forceinline__ void bin_discs(const DG& dd, uint32_t* __restrict__ h
 //   SINK_FLUX: 180x90 detector flux map (the headline path)
 //   SINK_DZ  : histogram of the exit direction's z component (distributionSphereDetectorSweep.C:54,91)
 //   SINK_DISC: physical disc sweep (integratingSphereDetectorSweep.C)
-template <int SINK, bool LEAN = false, int CH = 2>
+template <int SINK, bool LEAN = false, int CH = 2, bool RESC = !LEAN>
 __device__ __forceinline__ void persistent_body(const Geom& g_arg, const DetGrid& d_arg, const Work& wk) {
   extern __shared__ __align__(16) unsigned char smem[];
   uint32_t* hist = reinterpret_cast<uint32_t*>(smem);
@@ -524,13 +524,8 @@ __device__ __forceinline__ void persistent_body(const Geom& g_arg, const DetGrid
     int pend = 0;     // end status of the ray this lane finished during the trip, 0 if none
     // what happens to a lane once its boundary (kind, q) is known
     auto arrive = [&](int kind, const V3& q) {
-      int st = ray_arrive<SINK == SINK_DISC, LEAN, CH>(h, g, r, seed, kind, q);
-      if (!LEAN && st != 0 && h.source_model == 1 && r.phase == 0) {
-        n_wall += r.j;
-        ray_rescatter(g, r, seed);
-        st = 0;
-      }
-      if (st != 0) { alive = false; pend = st; }   // the census is taken once per trip (below), not per bounce
+      const int st = ray_arrive<SINK == SINK_DISC, LEAN, CH>(h, g, r, seed, kind, q);
+      if (st != 0) { alive = false; pend = st; }   // census / re-scatter once per trip (below), not per bounce
     };
     // hot boundary search of one lane: true if it arrived on the inner mirror patch, else the lane parks
     auto hot_search = [&](V3& q) -> bool {
@@ -571,6 +566,14 @@ __device__ __forceinline__ void persistent_body(const Geom& g_arg, const DetGrid
     }
     // ---- census of the rays that ended in this trip (a dead lane stays dead until the next refill, so each ended
     // ray is seen exactly once, with its final point and direction still in place)
+    if (RESC && pend != 0 && h.source_model == 1 && r.phase == 0) {
+      // nonLambertianFlux.C:253-268: the primary trace is over (whatever its status); the ray restarts from its last
+      // point along a BRDF-sampled direction.  One copy of this code per trip instead of one per bounce.
+      n_wall += r.j;
+      ray_rescatter(g, r, seed);
+      alive = true;
+      pend = 0;
+    }
     if (pend != 0) {
       n_ended++;
       n_wall += r.j;
@@ -691,6 +694,9 @@ isx_trace_bin_kernel(const Geom g, const DetGrid d, const Work wk) { persistent_
 // the same path with ISX_TRACE_CHORD compiled in (next wall point sampled directly)
 extern "C" __global__ void ISX_KERNEL_ATTR
 isx_trace_bin_chord_kernel(const Geom g, const DetGrid d, const Work wk) { persistent_body<SINK_FLUX, true, 1>(g, d, wk); }
+// the lean path plus the BRDF re-scatter of nonLambertianFlux.C (BASELINE.json configs[2])
+extern "C" __global__ void ISX_KERNEL_ATTR
+isx_trace_bin_brdf_kernel(const Geom g, const DetGrid d, const Work wk) { persistent_body<SINK_FLUX, true, 0, true>(g, d, wk); }
 // every surface / source / hit-line model (BRDF re-scatter, cos^2 lobe, rough specular, origin-compat line)
 extern "C" __global__ void ISX_KERNEL_ATTR
 isx_trace_bin_full_kernel(const Geom g, const DetGrid d, const Work wk) { persistent_body<SINK_FLUX, false, 2>(g, d, wk); }
