@@ -38,7 +38,7 @@ struct State {
   int bin_mode = 1;
   int blocks_per_cu = 1;   // 1024-thread blocks: 16 waves/CU, 4 per SIMD
   int grid_blocks = 0;  // 0 = auto
-  int sched_mask = 3, sched_min = 12;   // generic boundary search: every 4th loop trip (16 bounces) or when 12 lanes wait
+  int sched_mask = 3, sched_min = 12;   // generic boundary search: every 4th loop trip (24 bounces) or when 12 lanes wait
   // timing of enqueued-but-not-collected launches
   std::vector<hipEvent_t> ev_pool;
   size_t ev_used = 0;

@@ -60,7 +60,7 @@ struct Work {
 #endif
 constexpr int kBlock = ISX_BLOCK;
 #ifndef ISX_STEPS
-#define ISX_STEPS 4
+#define ISX_STEPS 6
 #endif
 constexpr int kStepsPerTrip = ISX_STEPS;   // bounces attempted per trip of the persistent loop
 #if ISX_WAVES_PER_EU > 0
