@@ -150,10 +150,13 @@ __device__ __forceinline__ void bin_brute(const DG& dd, uint32_t* __restrict__ h
 //   dot = V.n, num = (P-c).n, dv = (P-c).V, dd = |P-c|^2
 // are all of the form k0 + k1*cos(phi_j) + k2*sin(phi_j)  (c = (A c, A s, z), n = (-S s, S c, -C)),
 // so one candidate costs 8 fma + the sign test of  dd*dot^2 - 2*num*dot*dv + num^2 - (w/2)^2*dot^2.
-struct CapWin { float Fz, AF2, AF, jf, ch2, inv_dphi; };   // the cap around one piercing point, as the row windows need it
+struct CapWin {            // what the row windows need:
+  float Fz, AF2, AF, jf, ch2, inv_dphi;   // CAPS: the cap around one piercing point
+  int jlo_u, cnt_u;                       // otherwise: one phi-window shared by all rows
+};
 
 // Rows ilo..ihi, 64 at a time (lane = row).  CAPS: each row's phi-window is its intersection with the cap `w`;
-// otherwise the whole row.  Then the column walk with the exact decision.
+// otherwise the same window [jlo_u, jlo_u + cnt_u) for every row.  Then the column walk with the exact decision.
 template <bool CAPS, class D>
 __device__ __forceinline__ void walk_rows(const D& d, uint32_t* __restrict__ hist, const double* __restrict__ rowt,
                                           const ColX* __restrict__ colx, const V3& P, const V3& V, int lane, int ilo,
@@ -165,7 +168,7 @@ __device__ __forceinline__ void walk_rows(const D& d, uint32_t* __restrict__ his
     double a0c = 0, a1c = 0, a2c = 0, b0c = 0, b1c = 0, b2c = 0, e0c = 0, e1c = 0, e2c = 0, f0c = 0, f1c = 0, f2c = 0, bandc = 0;
     if (i <= ihi) {
       const double Sd = rowt[4 * i + 0], Cd = rowt[4 * i + 1], zd = rowt[4 * i + 2], Ad = rowt[4 * i + 3];
-      if (!CAPS) { jlo = 0; cnt = d.n_phi; }
+      if (!CAPS) { jlo = w.jlo_u; cnt = w.cnt_u; }
       else {
         const float zi = (float)zd, Ai = (float)Ad;
         const float dzi = zi - w.Fz;
@@ -279,6 +282,37 @@ __device__ inline void bin_culled(const DG& dd, uint32_t* __restrict__ hist,
     const float clo = fminf(1.f, fmaxf(-1.f, -((float)hz - dz) * iR)), chi = fminf(1.f, fmaxf(-1.f, -((float)hz + dz) * iR));
     const int ilo = max((int)floorf((acos_cull(clo) - 2e-3f) * inv_dth - 0.5f - 1e-2f), 0);
     const int ihi = min((int)ceilf((acos_cull(chi) + 2e-3f) * inv_dth - 0.5f + 1e-2f), d.n_theta - 1);
+    // phi-window common to all rows: in the xy-plane every candidate lies within rho_d of the projected stretch
+    // [Xa, Xb] = H -+ sm V, a stadium; seen from the z-axis its angular hull is that of its two end discs plus the arc
+    // the segment sweeps between them (the tangents from an outside point to the hull of two discs touch a disc).
+    w.jlo_u = 0; w.cnt_u = d.n_phi;
+    {
+      const float Hx = (float)hx, Hy = (float)hy, Vx = (float)V.x, Vy = (float)V.y;   // O is on the z-axis: H_xy = h_xy
+      const float xa = fmaf(-sm, Vx, Hx), ya = fmaf(-sm, Vy, Hy), xb = fmaf(sm, Vx, Hx), yb = fmaf(sm, Vy, Hy);
+      const float vxy2 = fmaf(Vx, Vx, Vy * Vy);
+      // closest approach of the segment to the axis: parameter of the foot point, clamped to the stretch
+      const float tf = vxy2 > 1e-12f ? fminf(sm, fmaxf(-sm, -fmaf(Hx, Vx, Hy * Vy) * rcp_cull(vxy2))) : 0.f;
+      const float xf = fmaf(tf, Vx, Hx), yf = fmaf(tf, Vy, Hy);
+      const float dseg = sqrt_cull(fmaf(xf, xf, yf * yf));
+      const float rm = rho * 1.01f + 1e-2f;
+      if (dseg > rm * 1.05f) {                     // the stadium does not reach the axis: a proper interval
+        const float ra = sqrt_cull(fmaf(xa, xa, ya * ya)), rb = sqrt_cull(fmaf(xb, xb, yb * yb));   // both >= dseg > rm
+        const float al_a = 1.57079637f - acos_cull(fminf(1.f, rm * rcp_cull(ra))) + 2e-3f;   // asin(rm/ra), padded
+        const float al_b = 1.57079637f - acos_cull(fminf(1.f, rm * rcp_cull(rb))) + 2e-3f;
+        const float pa = atan2_cull(ya, xa);
+        float dl = atan2_cull(yb, xb) - pa;                // signed sweep a -> b, |sweep| < pi because the axis is outside
+        if (dl > 3.14159274f) dl -= 6.28318531f;
+        if (dl < -3.14159274f) dl += 6.28318531f;
+        const float lo = pa + fminf(-al_a, dl - al_b), hi = pa + fmaxf(al_a, dl + al_b);
+        const int j0 = (int)ceilf(lo * w.inv_dphi - 0.5f - 1e-2f), j1 = (int)floorf(hi * w.inv_dphi - 0.5f + 1e-2f);
+        const int c = j1 - j0 + 1;
+        if (c < d.n_phi) {
+          w.cnt_u = c < 0 ? 0 : c;
+          int jw = j0 % d.n_phi;
+          w.jlo_u = jw < 0 ? jw + d.n_phi : jw;
+        }
+      }
+    }
     walk_rows<false>(d, hist, rowt, colx, P, V, lane, ilo, ihi, w);
     return;
   }
