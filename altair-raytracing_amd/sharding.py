@@ -48,3 +48,13 @@ def fluxmap_sharded(trace: Callable, cfg, n_total: int, seed: int, first_ray: in
         hits = buf[:-len(CENSUS_FIELDS)].astype(np.uint64).reshape(hits.shape)
         census = buf[-len(CENSUS_FIELDS):]
     return hits, dict(zip(CENSUS_FIELDS, (int(x) for x in census)))
+
+
+def disc_sweep_sharded(sweep: Callable, cfg, discs, radius: float, half_thick: float, n_total: int, seed: int,
+                       first_ray: int = 0, device=None):
+    """BASELINE.json configs[3] (integratingSphereDetectorSweep.C ray-sharded): every rank traces its slice of the
+    n_total rays against ALL discs with `sweep(cfg, discs, radius, half_thick, count, seed, first) -> (hits, stats)`
+    (altair_raytracing_amd.disc_sweep on a GPU box), then the per-disc counts and the census are summed by the same
+    single all-reduce as the flux map."""
+    return fluxmap_sharded(lambda c, count, s, first: sweep(c, discs, radius, half_thick, count, s, first),
+                           cfg, n_total, seed, first_ray, device)

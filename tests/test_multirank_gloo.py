@@ -23,6 +23,18 @@ def _free_port():
     return p
 
 
+def _disc_case(mod):
+    c = mod.default_config()
+    c.r_out = 105.0; c.reflectance = 1.0; c.roughness_rad = 0.0; c.max_points = 10000; c.box_half = 200.0; c.src[2] = -80.0
+    discs = []
+    for th in (-30.0, -10.0, 0.0, 10.0, 30.0):
+        t = np.deg2rad(th)
+        cx, cz = 200 * np.sin(t), -200 * np.cos(t)
+        ax = np.array([-cx, 0.0, -100.0 - cz]); ax /= np.linalg.norm(ax)
+        discs.append([cx, 0.0, cz, ax[0], ax[1], ax[2]])
+    return c, np.array(discs)
+
+
 def _worker(rank, world, port, q):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -39,7 +51,11 @@ def _worker(rank, world, port, q):
         return oracle.fluxmap(c, count, seed, first, 2)
 
     hits, census = isx.fluxmap_sharded(trace, cfg, N, SEED, first_ray=1000)
-    q.put((rank, hits, census))
+    # BASELINE configs[3]: the physical-disc sweep, ray-sharded the same way
+    dcfg, discs = _disc_case(oracle)
+    dh, dc = isx.disc_sweep_sharded(lambda c, d, r, h, count, seed, first: oracle.disc_sweep(c, d, r, h, count, seed, first),
+                                    dcfg, discs, 5.0, 0.1, 3000, SEED + 1, first_ray=50)
+    q.put((rank, hits, census, dh, dc))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -61,7 +77,10 @@ def test_sharded_allreduce_equals_single_rank(world, orc):
     cfg = orc.default_config()
     cfg.n_theta, cfg.n_phi = 60, 30
     want, st = orc.fluxmap(cfg, N, SEED, 1000)
-    for rank, hits, census in got:
+    dcfg, discs = _disc_case(orc)
+    dwant, dst = orc.disc_sweep(dcfg, discs, 5.0, 0.1, 3000, SEED + 1, 50)
+    for rank, hits, census, dh, dc in got:
+        assert np.array_equal(dh, dwant) and dc["launched"] == 3000 and dc["bin_increments"] == int(dwant.sum()), rank
         assert np.array_equal(hits, want), rank
         assert census["launched"] == N and census["counted_below_z"] == st.counted_below_z
         assert census["bin_increments"] == int(want.sum()) and census["wall_hits"] == st.wall_hits
