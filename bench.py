@@ -87,8 +87,10 @@ def main():
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (no CPU fallback exists in the product path)")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # one GPU per rank; if the launcher restricted this rank's visible devices, fall back to what is visible
+    dev_index = local_rank % max(torch.cuda.device_count(), 1)
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     # ISX_FORCE_DIST=1 exercises the RCCL code path even with one rank (rehearsal on a 1-GPU box)
     use_dist = world > 1 or os.environ.get("ISX_FORCE_DIST") == "1"
     if use_dist:
@@ -98,7 +100,7 @@ def main():
 
     import altair_raytracing_amd as isx
     isx.load()
-    isx.init(local_rank)
+    isx.init(dev_index)
     devname, cus = isx.device_info()
     cfg = isx.default_config()
     cfg.trace_mode = 1 if a.trace_mode == "chord" else 0
@@ -109,7 +111,7 @@ def main():
 
     def barrier():
         if use_dist:
-            dist.barrier(device_ids=[local_rank])
+            dist.barrier(device_ids=[dev_index])
         torch.cuda.synchronize()
 
     # --- pick the reduce path: device-resident histogram if this process's two HIP runtimes
