@@ -1,0 +1,48 @@
+// isx_comm.hpp — multi-GPU for the host driver: one PROCESS per GPU, rays (or per-position groups) sharded over the
+// ranks, ONE RCCL all-reduce (ncclSum over xGMI) of the hit histogram + census at the end of every trace call
+// (SURVEY.md §8e).  The reference has nothing like it (one process, <=4 threads sharing gRandom); results do not
+// depend on the number of ranks because ray i always draws from Philox stream (seed, i).
+//
+// Launch (any launcher that exports a rank and a world size works; the names tried are, in order,
+// ISX_RANK/ISX_WORLD/ISX_LOCAL_RANK, RANK/WORLD_SIZE/LOCAL_RANK (torchrun), OMPI_COMM_WORLD_RANK/_SIZE/_LOCAL_RANK):
+//     for r in 0..7:  ISX_RANK=$r ISX_WORLD=8 ISX_RENDEZVOUS=/tmp/isx_job42 isx_macro fluxAtObserverFast::sweepDetectorTraceOnce ...
+// Rank r binds GPU ISX_LOCAL_RANK (unless ISX_DEVICE says otherwise); rank 0 writes the files, the other ranks write
+// to /dev/null.  The 128-byte ncclUniqueId travels through the file ISX_RENDEZVOUS (default /tmp/isx_rccl_<MASTER_PORT
+// or uid>; give every job its own path): rank 0 writes it atomically, the others wait for it (120 s), rank 0 removes it.
+#pragma once
+#include <cstdint>
+#include <string>
+
+#include "../../include/isx.h"
+
+namespace isxhost {
+
+struct Comm {
+  int rank = 0, world = 1, local_rank = 0;
+  bool forced = false;             // ISX_FORCE_COMM=1: go through RCCL even with one rank (rehearsal on a 1-GPU box)
+  bool active() const { return world > 1 || forced; }
+  bool writer() const { return rank == 0; }
+  // contiguous share of [0,n): the first n % world ranks get one extra unit (same rule as sharding.py)
+  void shard(uint64_t n, uint64_t& first, uint64_t& count) const;
+  // in-place SUM of hits[count] and of the census in *st over all ranks (t_kernel_ms: MAX); false + message on failure
+  bool reduce(uint64_t* hits, size_t count, isx_stats* st, int n_stats = 1);
+  void finalize();
+};
+Comm& comm();
+
+// file the writer rank should create for `base` (never overwriting, getUniqueFilename); "/dev/null" on the other ranks
+std::string outputPath(const std::string& base);
+
+// Sharded equivalents of the ABI calls used by the sweeps: this rank's share, then Comm::reduce.  With one rank they
+// are the plain calls.
+int fluxmap_all(const isx_config* cfg, uint64_t n_rays, uint64_t seed, uint64_t first_ray, uint64_t* hits, isx_stats* st);
+int fluxmap_per_position_all(const isx_config* cfg, uint64_t rays_per_position, int32_t fold, uint64_t n_groups, uint64_t seed,
+                             uint64_t first_ray, uint64_t* hits, isx_stats* st);
+int fluxmap_series_all(const isx_config* cfgs, int32_t n_cfg, uint64_t n_rays, uint64_t seed, uint64_t first_ray, uint64_t* hits,
+                       isx_stats* st);
+int disc_sweep_all(const isx_config* cfg, const double* centers_axes, int32_t n_disc, double radius, double half_thick,
+                   uint64_t n_rays, uint64_t seed, uint64_t first_ray, uint64_t* hits, isx_stats* st);
+int exit_dz_hist_all(const isx_config* cfg, uint64_t n_rays, uint64_t seed, uint64_t first_ray, int32_t nbins, uint64_t* hist,
+                     isx_stats* st);
+
+}  // namespace isxhost

@@ -12,6 +12,7 @@
 #include <map>
 #include <string>
 
+#include "isx_comm.hpp"
 #include "isx_macros.hpp"
 
 using namespace isxhost;
@@ -42,11 +43,17 @@ int main(int argc, char** argv) {
                  "  fluxAtObserver::sweepDetector | fluxAtObserverOptimize::sweepDetector | fluxAtObserverOptimize::sweepSeries |\n"
                  "  fluxAtObserverFast::sweepDetectorTwofold | fluxAtObserverFast::sweepDetectorTraceOnce | fluxAtObserverFast::sweepSeries |\n"
                  "  nonLambertianFlux::sweepDetector | makeIntegratingSphereNRays | integratingSphereDetectorSweep |\n"
-                 "  distributionSphereDetectorSweep | --selftest-writer <file> | --unique <path> | --analyze <csv>... | --analyze <folder> [average]\n";
+                 "  distributionSphereDetectorSweep | --selftest-writer <file> | --unique <path> | --shard <n> | --analyze <csv>... | --analyze <folder> [average]\n";
     return 2;
   }
   const std::string entry = argv[1];
   if (entry == "--selftest-writer" && argc > 2) return selftest_writer(argv[2]);
+  if (entry == "--shard" && argc > 2) {  // this rank's share of n units (rank/world from the environment, isx_comm.hpp)
+    uint64_t f, c;
+    comm().shard(std::strtoull(argv[2], nullptr, 10), f, c);
+    std::cout << comm().rank << " " << comm().world << " " << f << " " << c << std::endl;
+    return 0;
+  }
   if (entry == "--unique" && argc > 2) { std::cout << getUniqueFilename(argv[2]) << std::endl; return 0; }
   if (entry == "--analyze" && argc > 2) {  // python flux_analysis.py <csv_file_or_folder> [average] (numbers; no GPU)
     struct stat sb;
@@ -82,6 +89,7 @@ int main(int argc, char** argv) {
   else if (entry == "distributionSphereDetectorSweep") rootMacros::distributionSphereDetectorSweep();
   else { std::cerr << "unknown entry point " << entry << "\n"; return 2; }
   const bool ok = ensure_device();  // false: the entry point printed its error and returned early
+  comm().finalize();
   isx_shutdown();
-  return ok ? 0 : 3;
+  return !ok ? 3 : (anyError() ? 4 : 0);
 }

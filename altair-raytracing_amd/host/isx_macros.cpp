@@ -1,5 +1,6 @@
 // isx_macros.cpp — the reference's macro entry points over libisx (see isx_macros.hpp).
 #include "isx_macros.hpp"
+#include "isx_comm.hpp"
 
 #include <dirent.h>
 #include <sys/stat.h>
@@ -20,6 +21,12 @@
 
 namespace isxhost {
 
+// Errors go to std::cerr and the entry point returns early (reference behaviour); the driver also remembers that one
+// happened so that a command-line front end can exit non-zero.
+static bool g_failed = false;
+bool anyError() { return g_failed; }
+static std::ostream& err() { g_failed = true; return std::cerr; }
+
 // ---------------------------------------------------------------------------------------------
 // run options / device
 // ---------------------------------------------------------------------------------------------
@@ -38,9 +45,10 @@ RunOptions& options() {
 bool ensure_device() {
   static int state = 0;  // 0 unknown, 1 ok, -1 failed
   if (state == 0) {
+    (void)comm();        // a multi-rank launch picks this rank's GPU before the first bind
     const int rc = isx_init(options().device);
     if (rc != ISX_OK) {
-      std::cerr << "Error: libisx cannot bind GPU " << options().device << ": " << isx_strerror(rc) << std::endl;
+      err() << "Error: libisx cannot bind GPU " << options().device << ": " << isx_strerror(rc) << std::endl;
       state = -1;
     } else {
       state = 1;
@@ -258,7 +266,7 @@ bool readFluxMap(const std::string& csvPath, FluxMapTable& out) {
     if (std::sscanf(line.c_str(), "%lf,%lf,%lf", &t, &p, &f) == 3) { out.theta.push_back(t); out.phi.push_back(p); out.fraction.push_back(f); }
   }
   if (out.theta.empty()) {
-    std::cerr << "Error reading CSV data from " << csvPath << std::endl;
+    err() << "Error reading CSV data from " << csvPath << std::endl;
     return false;
   }
   return true;
@@ -520,7 +528,7 @@ static int trace_one_detector(OpticsManager* m, int n, double exitPortZ, Detecto
   isx_stats st;
   const int rc = isx_trace_rays_detector(&c, d6, det.width, (uint64_t)n, options().seed, take_rays((uint64_t)n), &hits, &st);
   if (rc != ISX_OK) {
-    std::cerr << "Error: isx_trace_rays_detector: " << isx_strerror(rc) << std::endl;
+    err() << "Error: isx_trace_rays_detector: " << isx_strerror(rc) << std::endl;
     return 0;
   }
   det.hitCount += (int)hits;
@@ -544,10 +552,10 @@ void sweepDetector() {
   else say(std::string("Using directory: ") + saveFolder);
   std::string fullPath = std::string(saveFolder) + "/fluxmap_data_" + std::to_string(n) + "rays_" +
                          std::to_string(nThetaBins * nPhiBins) + "points.csv";
-  fullPath = getUniqueFilename(fullPath);
+  fullPath = outputPath(fullPath);
   std::ofstream csvFile(fullPath);
   if (!csvFile.is_open()) {
-    std::cerr << "Error: Could not open file " << fullPath << " for writing." << std::endl;
+    err() << "Error: Could not open file " << fullPath << " for writing." << std::endl;
     return;
   }
   const std::string timeBuffer = currentTimeString();
@@ -570,9 +578,9 @@ void sweepDetector() {
   std::vector<uint64_t> hits((size_t)nThetaBins * nPhiBins);
   isx_stats st;
   const uint64_t total = (uint64_t)n * hits.size();
-  const int rc = isx_fluxmap_per_position(&c, (uint64_t)n, 1, 0, hits.size(), options().seed, take_rays(total), hits.data(), &st);
+  const int rc = fluxmap_per_position_all(&c, (uint64_t)n, 1, hits.size(), options().seed, take_rays(total), hits.data(), &st);
   if (rc != ISX_OK) {
-    std::cerr << "Error: isx_fluxmap_per_position: " << isx_strerror(rc) << std::endl;
+    err() << "Error: isx_fluxmap_per_position: " << isx_strerror(rc) << std::endl;
     return;
   }
   csvFile << fluxmap_rows(hits.data(), n, nThetaBins, nPhiBins);
@@ -634,10 +642,10 @@ void sweepDetector(bool notify, const char* saveFolder, int /*threads: ignored, 
   std::string fullPath = std::string(saveFolder) + "/fluxmap_" + std::to_string(n) + "rays_" + std::to_string(nThetaBins) +
                          "x" + std::to_string(nPhiBins) + "_src" + std::to_string(int(srcX / cm)) + "_" +
                          std::to_string(int(srcY / cm)) + "_" + std::to_string(int(srcZ / cm)) + ".csv";
-  fullPath = getUniqueFilename(fullPath);
+  fullPath = outputPath(fullPath);
   std::ofstream csvFile(fullPath);
   if (!csvFile.is_open()) {
-    std::cerr << "Error: Could not open file " << fullPath << " for writing." << std::endl;
+    err() << "Error: Could not open file " << fullPath << " for writing." << std::endl;
     return;
   }
   Detector detector(40 * cm, 40 * cm);
@@ -655,10 +663,10 @@ void sweepDetector(bool notify, const char* saveFolder, int /*threads: ignored, 
   std::vector<uint64_t> hits((size_t)totalPositions);
   isx_stats st;
   const uint64_t total = (uint64_t)n * (uint64_t)totalPositions;
-  const int rc = isx_fluxmap_per_position(&c, (uint64_t)n, 1, 0, (uint64_t)totalPositions, options().seed, take_rays(total),
+  const int rc = fluxmap_per_position_all(&c, (uint64_t)n, 1, (uint64_t)totalPositions, options().seed, take_rays(total),
                                           hits.data(), &st);
   if (rc != ISX_OK) {
-    std::cerr << "Error: isx_fluxmap_per_position: " << isx_strerror(rc) << std::endl;
+    err() << "Error: isx_fluxmap_per_position: " << isx_strerror(rc) << std::endl;
     return;
   }
   csvFile << fluxmap_rows(hits.data(), n, nThetaBins, nPhiBins);
@@ -713,7 +721,7 @@ int traceRaysParallelTwofold(OpticsManager* m, int n, double exitPortZ, Detector
     isx_stats st;
     const int rc = isx_trace_rays_detector(&c, d6, d->width, (uint64_t)n, options().seed, first, &h, &st);
     if (rc != ISX_OK) {
-      std::cerr << "Error: isx_trace_rays_detector: " << isx_strerror(rc) << std::endl;
+      err() << "Error: isx_trace_rays_detector: " << isx_strerror(rc) << std::endl;
       return total;
     }
     d->hitCount += (int)h;
@@ -738,7 +746,7 @@ static void sweep_common(bool traceOnce, bool notify, const char* saveFolder, do
                          std::to_string(n) + "rays_" + std::to_string(nThetaBins) + "x" + std::to_string(nPhiBins) +
                          "_src" + std::to_string(int(srcX / cm)) + "_" + std::to_string(int(srcY / cm)) + "_" +
                          std::to_string(int(srcZ / cm)) + ".csv";
-  fullPath = getUniqueFilename(fullPath);
+  fullPath = outputPath(fullPath);
   const double src[3] = {srcX, srcY, srcZ}, dir[3] = {dirX, dirY, dirZ};
   FluxMapMeta mm;
   mm.title = traceOnce ? "Flux Map Data (Trace-Once Method)" : "Flux Map Data (Twofold Method)";
@@ -749,7 +757,7 @@ static void sweep_common(bool traceOnce, bool notify, const char* saveFolder, do
   for (int k = 0; k < 3; ++k) { mm.src[k] = src[k] / cm; mm.dir[k] = dir[k]; }
   std::ofstream csvFile(fullPath, std::ios::trunc);
   if (!csvFile.is_open()) {
-    std::cerr << "Error: Could not open file " << fullPath << " for writing." << std::endl;
+    err() << "Error: Could not open file " << fullPath << " for writing." << std::endl;
     return;
   }
   csvFile << fluxmap_header(mm, currentTimeString());
@@ -770,13 +778,13 @@ static void sweep_common(bool traceOnce, bool notify, const char* saveFolder, do
     // one trace, every exiting line tested against all 16200 positions (fluxAtObserverFast.C:1143-1315), with
     // the per-position hit semantics (last point + final direction); the reference's GetPoint(nPoints-2)
     // defect (:1181,:1225) is deliberately not reproduced.
-    rc = isx_fluxmap(&c, (uint64_t)n, options().seed, take_rays((uint64_t)n), hits.data(), &st);
+    rc = fluxmap_all(&c, (uint64_t)n, options().seed, take_rays((uint64_t)n), hits.data(), &st);
   } else {
     const uint64_t groups = (uint64_t)totalPositions / 2;
-    rc = isx_fluxmap_per_position(&c, (uint64_t)n, 2, 0, groups, options().seed, take_rays((uint64_t)n * groups), hits.data(), &st);
+    rc = fluxmap_per_position_all(&c, (uint64_t)n, 2, groups, options().seed, take_rays((uint64_t)n * groups), hits.data(), &st);
   }
   if (rc != ISX_OK) {
-    std::cerr << "Error: libisx: " << isx_strerror(rc) << std::endl;
+    err() << "Error: libisx: " << isx_strerror(rc) << std::endl;
     return;
   }
   const double rayTime = st.t_kernel_ms * 1e-3;
@@ -835,9 +843,9 @@ void sweepSeries() {
   std::vector<isx_config> cfgs(reps, c);
   std::vector<uint64_t> hits((size_t)reps * 16200);
   std::vector<isx_stats> st(reps);
-  const int rc = isx_fluxmap_series(cfgs.data(), reps, (uint64_t)n, options().seed, take_rays((uint64_t)n * reps), hits.data(), st.data());
+  const int rc = fluxmap_series_all(cfgs.data(), reps, (uint64_t)n, options().seed, take_rays((uint64_t)n * reps), hits.data(), st.data());
   if (rc != ISX_OK) {
-    std::cerr << "Error: isx_fluxmap_series: " << isx_strerror(rc) << std::endl;
+    err() << "Error: isx_fluxmap_series: " << isx_strerror(rc) << std::endl;
     return;
   }
   for (int i = 0; i < reps; i++) {
@@ -880,15 +888,15 @@ void sweepDetector() {
   std::vector<uint64_t> hits((size_t)nThetaBins * nPhiBins);
   isx_stats st;
   const uint64_t total = (uint64_t)n * hits.size();
-  const int rc = isx_fluxmap_per_position(&c, (uint64_t)n, 1, 0, hits.size(), options().seed, take_rays(total), hits.data(), &st);
+  const int rc = fluxmap_per_position_all(&c, (uint64_t)n, 1, hits.size(), options().seed, take_rays(total), hits.data(), &st);
   if (rc != ISX_OK) {
-    std::cerr << "Error: isx_fluxmap_per_position: " << isx_strerror(rc) << std::endl;
+    err() << "Error: isx_fluxmap_per_position: " << isx_strerror(rc) << std::endl;
     return;
   }
-  const std::string path = getUniqueFilename("fluxmap_data.csv");  // the reference overwrites; this driver never does
+  const std::string path = outputPath("fluxmap_data.csv");  // the reference overwrites; this driver never does
   std::ofstream csvFile(path);
   if (!csvFile.is_open()) {
-    std::cerr << "Error: Could not open file " << path << " for writing." << std::endl;
+    err() << "Error: Could not open file " << path << " for writing." << std::endl;
     return;
   }
   csvFile << "theta,phi,fraction\n";
@@ -920,9 +928,9 @@ void makeIntegratingSphereNRays() {
   c.n_theta = 1; c.n_phi = 1;
   std::vector<uint64_t> hist(1);
   isx_stats st;
-  const int rc = isx_exit_dz_hist(&c, (uint64_t)n, options().seed, take_rays((uint64_t)n), 1, hist.data(), &st);
+  const int rc = exit_dz_hist_all(&c, (uint64_t)n, options().seed, take_rays((uint64_t)n), 1, hist.data(), &st);
   if (rc != ISX_OK) {
-    std::cerr << "Error: libisx: " << isx_strerror(rc) << std::endl;
+    err() << "Error: libisx: " << isx_strerror(rc) << std::endl;
     return;
   }
   std::cout << "Flux of rays through the exit port: " << st.counted_below_z << std::endl;  // :93
@@ -943,9 +951,9 @@ void detectorDiskPlacement(double theta, double phi, double out[6]) {
 
 void sweepDetector(OpticsManager* manager, double diskRadius, int nRays, double dtheta, double thetaMax) {
   const double dphi = 180;
-  std::ofstream outFile(getUniqueFilename("detector_sweep3.txt"));
+  std::ofstream outFile(outputPath("detector_sweep3.txt"));
   if (!outFile.is_open()) {
-    std::cerr << "Error: Could not open file detector_sweep3.txt for writing." << std::endl;
+    err() << "Error: Could not open file detector_sweep3.txt for writing." << std::endl;
     return;
   }
   outFile << "Theta(deg)\tPhi(deg)\tHitFraction\n";
@@ -957,10 +965,10 @@ void sweepDetector(OpticsManager* manager, double diskRadius, int nRays, double 
       uint64_t hits = 0;
       isx_stats st;
       // fresh rays per position, as the reference's inner loop (:67-77)
-      const int rc = isx_disc_sweep(&manager->cfg, ca, 1, diskRadius, 0.1 * cm, (uint64_t)nRays, options().seed,
+      const int rc = disc_sweep_all(&manager->cfg, ca, 1, diskRadius, 0.1 * cm, (uint64_t)nRays, options().seed,
                                     take_rays((uint64_t)nRays), &hits, &st);
       if (rc != ISX_OK) {
-        std::cerr << "Error: isx_disc_sweep: " << isx_strerror(rc) << std::endl;
+        err() << "Error: isx_disc_sweep: " << isx_strerror(rc) << std::endl;
         return;
       }
       const double hitFraction = static_cast<double>(hits) / nRays;
@@ -986,14 +994,14 @@ void distributionSphereDetectorSweep() {
   const long n = pick_n(10000);
   std::vector<uint64_t> hist(100);
   isx_stats st;
-  const int rc = isx_exit_dz_hist(&c, (uint64_t)n, options().seed, take_rays((uint64_t)n), 100, hist.data(), &st);
+  const int rc = exit_dz_hist_all(&c, (uint64_t)n, options().seed, take_rays((uint64_t)n), 100, hist.data(), &st);
   if (rc != ISX_OK) {
-    std::cerr << "Error: libisx: " << isx_strerror(rc) << std::endl;
+    err() << "Error: libisx: " << isx_strerror(rc) << std::endl;
     return;
   }
   std::cout << "Flux of rays through the exit port: " << st.counted_below_z << std::endl;
   // hDirectionZ = TH1D(100,-1,1) (:54,:91); written in the format of the committed angular_dist.txt
-  std::ofstream f(getUniqueFilename("angular_dist.txt"));
+  std::ofstream f(outputPath("angular_dist.txt"));
   f << "# bin_center content\n";
   for (int b = 0; b < 100; ++b) f << (-1.0 + (b + 0.5) * 0.02) << " " << hist[b] << "\n";
   // the un-binned log of the same rays, in the format of the committed 3dRayLog.txt
@@ -1003,10 +1011,10 @@ void distributionSphereDetectorSweep() {
   const uint64_t first = options().next_ray - (uint64_t)n;  // the very rays the histogram was made from
   const int rc2 = isx_exit_directions(&c, (uint64_t)n, options().seed, first, (uint64_t)n, ids.data(), dirs.data(), &count, &st);
   if (rc2 != ISX_OK) {
-    std::cerr << "Error: isx_exit_directions: " << isx_strerror(rc2) << std::endl;
+    err() << "Error: isx_exit_directions: " << isx_strerror(rc2) << std::endl;
     return;
   }
-  std::ofstream lg(getUniqueFilename("3dRayLog.txt"));
+  std::ofstream lg(outputPath("3dRayLog.txt"));
   lg << "# dx dy dz\n";
   for (uint64_t k = 0; k < count; ++k) lg << dirs[3 * k] << " " << dirs[3 * k + 1] << " " << dirs[3 * k + 2] << "\n";
 }

@@ -55,6 +55,8 @@ struct RunOptions {
 RunOptions& options();
 // Binds libisx to options().device on first use; false (and a message on cerr) if no GPU.
 bool ensure_device();
+// true once any entry point has reported an error (they never throw and return void, like the reference's)
+bool anyError();
 
 // --- CSV plumbing shared by the sweeps (exposed for tests)
 std::string getUniqueFilename(const std::string& basePath);  // fluxAtObserverOptimize.C:336-387

@@ -160,6 +160,21 @@ def test_folder_average_matches_pandas(cli, tmp_path):
     assert "AVERAGE" not in out2 and (tmp_path / "series_theta_comparison.txt").exists()
 
 
+def test_rank_sharding_rule_matches_python(cli):
+    """isxhost::Comm::shard (C++ driver, one process per GPU) == altair_raytracing_amd.shard (bench.py / sharding.py)."""
+    from altair_raytracing_amd import shard
+    for n in (0, 1, 7, 16200, 50_000_000, 10 ** 9 + 3):
+        for world in (1, 2, 3, 8):
+            for rank in range(world):
+                env = dict(os.environ, ISX_RANK=str(rank), ISX_WORLD=str(world))
+                out = subprocess.check_output([cli, "--shard", str(n)], text=True, env=env).split()
+                assert [int(x) for x in out] == [rank, world, *shard(n, rank, world)]
+    # torchrun-style variables are understood too
+    env = {k: v for k, v in os.environ.items() if not k.startswith("ISX_")}
+    env.update(RANK="1", WORLD_SIZE="4", LOCAL_RANK="1")
+    assert subprocess.check_output([cli, "--shard", "10"], text=True, env=env).split() == ["1", "4", "3", "3"]
+
+
 def test_cli_fails_loudly_without_gpu(cli, tmp_path):
     import altair_raytracing_amd as isx
     if isx.load().isx_init(0) == 0:
@@ -247,6 +262,34 @@ def test_small_macros(cli, isx, tmp_path):
     # the log keeps 6 significant digits: a value within 5e-7 of a bin edge may land next door when re-binned
     # (expected ~1 of 20000 values, each flip counts twice)
     assert np.abs(h - ad[:, 1]).sum() <= 12
+
+
+@pytest.mark.gpu
+def test_rccl_reduce_path_of_the_cpp_driver(cli, isx, tmp_path):
+    """One process per GPU + one RCCL all-reduce (isx_comm.cpp).  A 1-GPU box can only rehearse it with one rank
+    (ISX_FORCE_COMM=1: same file as without RCCL); two ranks on the SAME GPU must be refused loudly, not summed wrongly."""
+    def rows(path):
+        return [ln for ln in open(path).read().splitlines() if not ln.startswith("#")]
+    a, b = tmp_path / "plain", tmp_path / "rccl"
+    a.mkdir(); b.mkdir()
+    args = ("fluxAtObserverFast::sweepDetectorTraceOnce", "folder=out", "srcZ=-75", "dirY=0", "thetaMax=170")
+    _run(cli, a, *args, rays=100000, seed=5)
+    env = dict(os.environ, ISX_QUIET="1", ISX_RAYS="100000", ISX_SEED="5", ISX_FORCE_COMM="1", ISX_RENDEZVOUS=str(b / "rv"))
+    r = subprocess.run([cli, *args], cwd=b, env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    name = "fluxmap_traceonce_100000rays_180x90_src-60_0_-75.csv"
+    assert rows(a / "out" / name) == rows(b / "out" / name) and len(rows(a / "out" / name)) == 16201
+    assert not (b / "rv").exists()                    # rank 0 removes the rendezvous file once everyone has joined
+    c = tmp_path / "dup"
+    c.mkdir()
+    procs = []
+    for rank in (0, 1):
+        env = dict(os.environ, ISX_QUIET="1", ISX_RAYS="20000", ISX_RANK=str(rank), ISX_WORLD="2", ISX_DEVICE="0",
+                   ISX_RENDEZVOUS=str(c / "rv"))
+        procs.append(subprocess.Popen([cli, *args], cwd=c, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    outs = [p.communicate(timeout=300) for p in procs]
+    for p, (_, err) in zip(procs, outs):
+        assert p.returncode != 0 and "isx_comm" in err
 
 
 @pytest.mark.gpu
