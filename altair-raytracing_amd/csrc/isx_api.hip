@@ -22,6 +22,7 @@ struct State {
   bool init = false;
   int device = -1;
   int cu_count = 0;
+  size_t lds_limit = 64 * 1024;   // per-workgroup LDS the device grants (160 KiB on gfx950)
   hipStream_t stream = nullptr;
   int last_hip = 0;
   // detector tables (device) + the config they were built for
@@ -272,6 +273,8 @@ int enqueue(int sink, const isx_config* c, uint64_t n, uint64_t seed, uint64_t f
     d.discs = d_discs; d.disc_r = disc_r; d.disc_h = disc_h;
     lds = (((size_t)d.nbins * 4 + 15) & ~(size_t)15) + 64 + sizeof(Geom) + sizeof(DetGrid);
   }
+  // the per-block histogram (+ tables) must fit the workgroup's LDS: a grid too fine for that is a configuration error
+  if (lds > S.lds_limit) return ISX_ERR_BAD_CONFIG;
   if (n == 0) return ISX_OK;
   Work wk;
   wk.seed = seed; wk.first = first; wk.n = n; wk.hist = d_hist; wk.stats = d_stats ? d_stats : S.d_stats;
@@ -384,6 +387,11 @@ int isx_init(int device) {
   hipDeviceProp_t prop;
   HIPCHK(hipGetDeviceProperties(&prop, device));
   S.cu_count = prop.multiProcessorCount;
+  {
+    int v = 0;
+    if (hipDeviceGetAttribute(&v, hipDeviceAttributeMaxSharedMemoryPerBlock, device) == hipSuccess && v > 0) S.lds_limit = (size_t)v;
+    if (prop.sharedMemPerBlock > S.lds_limit) S.lds_limit = prop.sharedMemPerBlock;
+  }
   HIPCHK(hipStreamCreateWithFlags(&S.stream, hipStreamNonBlocking));
   HIPCHK(hipMalloc(&S.d_stats, 8 * sizeof(unsigned long long)));
   HIPCHK(hipMemset(S.d_stats, 0, 8 * sizeof(unsigned long long)));

@@ -222,6 +222,22 @@ def test_bad_config_is_rejected(isx):
     c = isx.default_config(); c.dir[0] = 0.0
     with pytest.raises(isx.IsxError):
         isx.fluxmap(c, 10, 1)
+    # within the 36 000-bin limit but with a column table that cannot share the 160 KiB of LDS with the histogram
+    c = isx.default_config(); c.n_theta = 1; c.n_phi = 36000
+    with pytest.raises(isx.IsxError) as e:
+        isx.fluxmap(c, 10, 1)
+    assert "configuration" in str(e.value).lower() or "config" in str(e.value).lower()
+
+
+def test_largest_grid_bit_exact(isx, orc):
+    """36 000 bins (the LDS histogram limit): 200 x 180 with a 4 cm detector."""
+    cg, co = isx.default_config(), orc.default_config()
+    for c in (cg, co):
+        c.n_theta, c.n_phi, c.det_diameter = 200, 180, 4.0
+    gh, gst = isx.fluxmap(cg, 20000, 31)
+    oh, ost = orc.fluxmap(co, 20000, 31)
+    assert gh.shape == (200, 180) and np.array_equal(gh, oh) and gh.sum() > 0
+    _census_equal(gst, ost)
 
 
 def test_full_size_properties(isx, golden):
