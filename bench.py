@@ -23,6 +23,7 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s
 FP64_VALU_PEAK_TFLOPS = 78.6   # MI355X vector FP64 peak
+VALU_CLOCK_GHZ = 2.4           # MI355X peak engine clock (78.6 TFLOP/s = 256 CU x 4 SIMD x 16 lanes x 2 flop x 2.4 GHz)
 # Work model frozen in BASELINE.md §2 / DESIGN.md §5 (brute-force binning convention):
 F_BOUNCE, N_BOUNCE, P_EXIT, F_DISC = 200.0, 57.5, 0.4235, 40.0
 
@@ -179,11 +180,12 @@ def main():
         hbm_gbs = alg_bytes / (k_ms * 1e-3) / 1e9
         f_ray = N_BOUNCE * F_BOUNCE + P_EXIT * nb * F_DISC
         fp64_tflops = n * f_ray / (k_ms * 1e-3) / 1e12
-        traffic = None
+        traffic, valu_per_ray, pmc_tag = None, None, None
         pmc = os.path.join(ROOT, "profiles", "pmc_summary.json")
         if os.path.exists(pmc):
             try:
-                traffic = json.load(open(pmc)).get("hbm_bytes_per_launch")
+                pj = json.load(open(pmc))
+                traffic, valu_per_ray, pmc_tag = pj.get("hbm_bytes_per_launch"), pj.get("valu_wave_insts_per_ray"), pj.get("tag")
             except Exception:
                 traffic = None
         st = census[-1]
@@ -209,6 +211,15 @@ def main():
                               "note": "algorithmic FP64 flop of the reference algorithm (brute-force 16200 disc "
                                       "tests per exiting ray, BASELINE.md §2); the kernel culls, so executed flop "
                                       "are far fewer and frac may exceed what executed-op counters show"},
+            # the resource that actually binds: VALU issue slots.  One wave64 instruction occupies a SIMD's VALU for 4
+            # cycles, so a GPU issues at most n_simd * clock / 4 wave-instructions per second.
+            "roofline_valu": (None if not valu_per_ray else {
+                "bound": "valu_issue", "achieved": valu_per_ray * n / (k_ms * 1e-3) / 1e9,
+                "peak": cus * 4 * VALU_CLOCK_GHZ / 4.0, "unit": "G wave-instr/s",
+                "frac": valu_per_ray * n / (k_ms * 1e-3) / 1e9 / (cus * 4 * VALU_CLOCK_GHZ / 4.0),
+                "valu_wave_insts_per_ray": valu_per_ray,
+                "note": f"executed SQ_INSTS_VALU per ray from the committed PMC pass (profiles/pmc_summary.json, tag {pmc_tag}) "
+                        f"x rays / live kernel time; peak = {cus} CUs x 4 SIMDs x {VALU_CLOCK_GHZ} GHz / 4 cycles"}),
             "census_last_step": {"launched": st.launched, "counted_below_z": st.counted_below_z,
                                  "wall_hits": st.wall_hits, "bin_increments": st.bin_increments},
             "hist_sum_last_step": total_hits,
