@@ -87,6 +87,7 @@ int prepare_geom(const isx_config* c, Geom* g) {
     // (w + 0.5) * 2^-32 < rho  <=>  w < rho * 2^32 - 0.5 =: x (both scalings exact)  <=>  w < ceil(x) for integer w
     const double x = std::ldexp(c->reflectance, 32) - 0.5;
     g->rho_thr = !(x > 0.0) ? 0ull : (x >= 4294967296.0 ? 4294967296ull : (unsigned long long)std::ceil(x));
+    g->inv_thr = g->rho_thr ? 1.0 / (double)g->rho_thr : 0.0;
   }
   g->sigma = c->roughness_rad;
   g->lambertian = c->lambertian;

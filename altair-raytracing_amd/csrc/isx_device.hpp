@@ -33,19 +33,20 @@ struct Geom {
   int chord, pad2;          // ISX_TRACE_CHORD; sched_*: generic-search batching, flush when (iter & mask) == mask or >= min lanes parked
   double r_in;
   unsigned long long rho_thr;  // absorb test on the raw Philox word: (w + 0.5) 2^-32 < rho  <=>  w < rho_thr (exact, see prepare_geom)
+  double inv_thr;              // 1 / rho_thr: the surviving word, rescaled, is the azimuth's uniform
 };
 
 // The handful of constants the hot loop needs; kept in SGPRs.  Everything else of Geom is read
 // on demand from an LDS copy (a `const volatile Geom&`), so it never occupies scalar registers
 // across the loop (SGPR spills were >10 % of the issued instructions before this split).
 struct Hot {
-  double rin2, zcut_in, ninv_rin, r_in;
+  double rin2, zcut_in, ninv_rin, r_in, inv_thr;
   unsigned long long rho_thr;
   int lambertian, limit, source_model, surface_model, chord;
 };
 __device__ __forceinline__ Hot make_hot(const Geom& g) {
   Hot h;
-  h.rin2 = g.rin2; h.zcut_in = g.zcut_in; h.ninv_rin = g.ninv_rin; h.rho_thr = g.rho_thr;
+  h.rin2 = g.rin2; h.zcut_in = g.zcut_in; h.ninv_rin = g.ninv_rin; h.rho_thr = g.rho_thr; h.inv_thr = g.inv_thr;
   h.lambertian = g.lambertian; h.limit = g.limit; h.source_model = g.source_model; h.surface_model = g.surface_model;
   h.r_in = g.r_in; h.chord = g.chord;
   return h;
@@ -76,6 +77,35 @@ __device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t
 }
 __device__ __forceinline__ void draw_block(uint64_t seed, uint64_t ray, uint32_t block, uint32_t stream, uint32_t w[4]) {
   philox4x32_10((uint32_t)ray, (uint32_t)(ray >> 32), block, stream, (uint32_t)seed, (uint32_t)(seed >> 32), w);
+}
+// The two random words (a, b) of interaction j of a trace: block j/2 of the trace's stream serves two interactions,
+// words (0,1) the even one, (2,3) the odd one.  a -> polar angle; b -> absorption (survive iff b < rho_thr) and, rescaled,
+// the azimuth.  PH_DIRECT computes the block on the spot.  The persistent kernels run an even number of synchronous
+// bounce steps per loop trip and keep the last block in `cw`: on even steps (PH_EVEN) every lane computes the block its
+// NEXT even interaction needs, (j+1)/2 -- its current one if j is even, one ahead if j is odd, in which case words (2,3)
+// of the block it already holds serve this bounce; on odd steps (PH_ODD) nothing is computed.  A lane reaches an odd
+// step only from the even step before it, and re-enters (refill, generic-search flush, re-scatter) only on step 0, so
+// `cw` always holds block j/2 when it is read.  One Philox block per two bounces; which words a ray sees never depends
+// on the schedule.
+enum : int { PH_DIRECT = 0, PH_EVEN = 1, PH_ODD = 2 };
+template <int PH>
+__device__ __forceinline__ void bounce_words(uint64_t seed, uint64_t ray, uint32_t j, uint32_t stream, uint32_t (&cw)[4],
+                                             uint32_t& wa, uint32_t& wb) {
+  const bool odd = (j & 1u) != 0u;
+  if (PH == PH_ODD) {
+    wa = odd ? cw[2] : cw[0];
+    wb = odd ? cw[3] : cw[1];
+  } else if (PH == PH_EVEN) {
+    const uint32_t ha = cw[2], hb = cw[3];
+    draw_block(seed, ray, (j + 1u) >> 1, stream, cw);
+    wa = odd ? ha : cw[0];
+    wb = odd ? hb : cw[1];
+  } else {
+    uint32_t w[4];
+    draw_block(seed, ray, j >> 1, stream, w);
+    wa = odd ? w[2] : w[0];
+    wb = odd ? w[3] : w[1];
+  }
 }
 // (w + 0.5) * 2^-32: both operations are exact (33 significant bits), and both constants are inline operands
 __device__ __forceinline__ double u01(uint32_t w) { return ((double)w + 0.5) * 0x1.0p-32; }
@@ -413,15 +443,13 @@ __device__ __forceinline__ V3 surface_normal(const Hot& h, const G& g, int kind,
 // ISX_TRACE_CHORD: Lambertian bounce off the inner sphere via the integrating-sphere identity - for cosine-law
 // emission from a point of a sphere the far intersection is uniform over the sphere's area, so the next wall
 // point T is sampled directly: no direction, no orthonormal basis, no intersection.  Same Philox words as the
-// explicit bounce (w0,w1 -> point, w2 -> absorb).  Returns false if absorbed.
-__device__ __forceinline__ bool interact_chord(const Hot& h, V3& T, uint64_t seed, uint64_t ray, uint32_t j, uint32_t stream) {
-  uint32_t wl[4];
-  draw_block(seed, ray, 2u * j, stream, wl);
-  if (!((unsigned long long)wl[2] < h.rho_thr)) return false;   // u01(wl[2]) < rho, decided on the integer
-  const double zz = fma(-2.0, u01(wl[0]), 1.0);
+// explicit bounce (a -> z, b -> absorb + azimuth).  Returns false if absorbed.
+__device__ __forceinline__ bool interact_chord(const Hot& h, V3& T, uint32_t wa, uint32_t wb) {
+  if (!((unsigned long long)wb < h.rho_thr)) return false;   // u01(wb) < rho, decided on the integer
+  const double zz = fma(-2.0, u01(wa), 1.0);
   const double s2 = sqrt_unit(fma(-zz, zz, 1.0));   // 1 - zz^2 in [2^-32, 1]
   double sf, cf;
-  circle_point(u01(wl[1]), cf, sf);
+  circle_point(((double)wb + 0.5) * h.inv_thr, cf, sf);
   const double rxy = h.r_in * s2;
   T.x = rxy * cf; T.y = rxy * sf; T.z = h.r_in * zz;
   return true;
@@ -431,10 +459,8 @@ __device__ __forceinline__ bool interact_chord(const Hot& h, V3& T, uint64_t see
 // models are compiled out so their registers and code do not burden the hot kernel.
 template <bool LEAN, class G>
 __device__ __forceinline__ bool interact(const Hot& h, const G& g, int kind, const V3& q, V3& v, uint64_t seed,
-                                         uint64_t ray, uint32_t j, uint32_t stream) {
-  uint32_t wl[4];
-  draw_block(seed, ray, 2u * j, stream, wl);
-  if (!((unsigned long long)wl[2] < h.rho_thr)) return false;   // u01(wl[2]) < rho, decided on the integer
+                                         uint64_t ray, uint32_t j, uint32_t stream, uint32_t wa, uint32_t wb) {
+  if (!((unsigned long long)wb < h.rho_thr)) return false;   // u01(wb) < rho, decided on the integer
   const V3 n = surface_normal(h, g, kind, q);
   V3 w;
   if (!LEAN && h.surface_model == 1) {
@@ -442,7 +468,7 @@ __device__ __forceinline__ bool interact(const Hot& h, const G& g, int kind, con
   } else if (LEAN || h.lambertian) {
     // cosine-law re-emission about the geometric normal; roughness does not act on a
     // Lambertian border
-    const double u1 = u01(wl[0]), u2 = u01(wl[1]);
+    const double u1 = u01(wa), u2 = ((double)wb + 0.5) * h.inv_thr;
     const double r = sqrt_unit(u1);      // u1, 1-u1 in [2^-33, 1)
     const double z = sqrt_unit(1.0 - u1);
     double sf, cf;
@@ -465,7 +491,7 @@ __device__ __forceinline__ bool interact(const Hot& h, const G& g, int kind, con
       V3 A, Bv;
       onb(n, A, Bv);
       uint32_t wr[4];
-      draw_block(seed, ray, 2u * j + 1u, stream, wr);
+      draw_block(seed, ray, j, stream + 64u, wr);   // the roughness draws have their own stream
       const double u1 = u01(wr[0]), u2 = u01(wr[1]), u3 = u01(wr[2]);
       const double R = sqrt(-2.0 * log_pos(u1));
       double s2, c2;

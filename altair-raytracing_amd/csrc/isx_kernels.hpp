@@ -13,6 +13,7 @@
 //   * bins live in a per-block LDS histogram (u32[n_theta*n_phi] = 64.8 KB for 180x90),
 //     flushed once per block with global 64-bit atomics.
 #pragma once
+#include <type_traits>
 #include "isx_device.hpp"
 
 namespace isx {
@@ -355,6 +356,7 @@ struct Ray {
   int on;
   int phase;        // 0 primary, 2 scattered (source_model 1)
   bool tgt;         // ISX_TRACE_CHORD: v holds the next wall point T, not a direction
+  uint32_t cw[4];   // the Philox block this lane holds (bounce_words; unused with PH_DIRECT)
 };
 
 template <class G>
@@ -367,19 +369,21 @@ __device__ __forceinline__ void ray_start(const G& g, Ray& r, uint64_t id) {
 // Second half of a step, once the boundary (kind, q) is known: advance, interact.
 // CH: 0 explicit bounces only, 1 chord identity for every eligible bounce (compile time), 2 decided by h.chord.
 // Returns 0 while running, else the end status of the CURRENT trace.
-template <bool KEEP_PREV, bool LEAN, int CH, class G>
+template <bool KEEP_PREV, bool LEAN, int CH, int PH = PH_DIRECT, class G>
 __device__ __forceinline__ int ray_arrive(const Hot& h, const G& g, Ray& r, uint64_t seed, int kind, const V3& q) {
   if (KEEP_PREV) r.prev = r.p;
   r.p = q;
   if (kind == K_BOX) { r.on = K_BOX; return ST_EXITED; }
   r.on = kind;
   bool alive;
+  uint32_t wa, wb;
+  bounce_words<PH>(seed, r.id, r.j, (uint32_t)r.phase, r.cw, wa, wb);
   const bool eligible = (kind == K_INNER) && (LEAN || (h.lambertian && h.surface_model == 0));
   if (CH != 0 && eligible && (CH == 1 || h.chord)) {
-    alive = interact_chord(h, r.v, seed, r.id, r.j, (uint32_t)r.phase);
+    alive = interact_chord(h, r.v, wa, wb);
     r.tgt = alive;
   } else {
-    alive = interact<LEAN>(h, g, kind, q, r.v, seed, r.id, r.j, (uint32_t)r.phase);
+    alive = interact<LEAN>(h, g, kind, q, r.v, seed, r.id, r.j, (uint32_t)r.phase, wa, wb);
   }
   r.j++;
   if (!alive) return ST_ABSORBED;
@@ -464,6 +468,15 @@ __device__ __forceinline__ void bin_discs(const DG& dd, uint32_t* __restrict__ h
     bool hit = false;
     if (b < d.nbins) hit = segment_hits_tube(P0, V, tmax, d.discs + 6 * (size_t)b, d.disc_r, d.disc_h);
     if (hit) atomicAdd(&hist[b], 1u);
+  }
+}
+
+// compile-time loop: f(integral_constant<int, K>) for K = FIRST .. N-1 (the step index selects code, not just data)
+template <int FIRST, int N, class F>
+__device__ __forceinline__ void static_steps(F&& f) {
+  if constexpr (FIRST < N) {
+    f(std::integral_constant<int, FIRST>());
+    static_steps<FIRST + 1, N>(f);
   }
 }
 
@@ -557,8 +570,12 @@ __device__ __forceinline__ void persistent_body(const Geom& g_arg, const DetGrid
     bool bin_me = false;
     int pend = 0;     // end status of the ray this lane finished during the trip, 0 if none
     // what happens to a lane once its boundary (kind, q) is known
-    auto arrive = [&](int kind, const V3& q) {
-      const int st = ray_arrive<SINK == SINK_DISC, LEAN, CH>(h, g, r, seed, kind, q);
+    // Philox block shared by two bounces (bounce_words): the lean kernels alternate compute / reuse steps
+    constexpr bool kShare = LEAN;
+    static_assert(!kShare || (kStepsPerTrip % 2) == 0, "block sharing needs an even number of steps per trip");
+    auto arrive = [&](int kind, const V3& q, auto ph) {
+      constexpr int PH = kShare ? decltype(ph)::value : PH_DIRECT;
+      const int st = ray_arrive<SINK == SINK_DISC, LEAN, CH, PH>(h, g, r, seed, kind, q);
       if (st != 0) { alive = false; pend = st; }   // census / re-scatter once per trip (below), not per bounce
     };
     // hot boundary search of one lane: true if it arrived on the inner mirror patch, else the lane parks
@@ -585,19 +602,18 @@ __device__ __forceinline__ void persistent_body(const Geom& g_arg, const DetGrid
         }
       }
       iter++;
-      if (arrived) arrive(kind, q);
+      if (arrived) arrive(kind, q, std::integral_constant<int, PH_EVEN>());
     }
     // extra bounces per loop trip (hot search only): amortises refill / flush / exit bookkeeping
-#pragma unroll
-    for (int rep = 1; rep < kStepsPerTrip; ++rep) {
+    static_steps<1, kStepsPerTrip>([&](auto rep) {
       V3 q;
       bool arrived = false;
       if (alive && !parked) {
         if (hot_search(q)) arrived = true;
         else parked = true;
       }
-      if (arrived) arrive(K_INNER, q);
-    }
+      if (arrived) arrive(K_INNER, q, std::integral_constant<int, (decltype(rep)::value & 1) ? PH_ODD : PH_EVEN>());
+    });
     // ---- census of the rays that ended in this trip (a dead lane stays dead until the next refill, so each ended
     // ray is seen exactly once, with its final point and direction still in place)
     if (RESC && pend != 0 && h.source_model == 1 && r.phase == 0) {

@@ -65,8 +65,10 @@ void isxo_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t o
 
 /* RNG addressing: key = (seed_lo, seed_hi); counter = (ray_lo, ray_hi, block, stream).
  * stream 0: primary trace; 1: BRDF re-scatter draw; 2: scattered-ray trace.
- * For mirror interaction j (0-based) of a trace: block 2j = "L" (Lambert u1,u2, absorb, spare),
- * block 2j+1 = "R" (roughness: Box-Muller u1,u2, azimuth, spare). */
+ * Mirror interaction j (0-based) of a trace in stream s takes two words (a, b) from block j/2 of stream s -- words
+ * (0,1) if j is even, (2,3) if odd: a -> polar angle, b -> absorption (survive iff b < rho_thr) and, rescaled by
+ * 1/rho_thr, the azimuth.  The rough-specular branch draws block j of stream s+64 (Box-Muller u1,u2, azimuth);
+ * the cos^2-lobe rejection tries use streams 16+k. */
 static inline void draw_block(uint64_t seed, uint64_t ray, uint32_t block, uint32_t stream, uint32_t w[4]) {
   uint32_t ctr[4] = { (uint32_t)ray, (uint32_t)(ray >> 32), block, stream };
   uint32_t key[2] = { (uint32_t)seed, (uint32_t)(seed >> 32) };
@@ -183,6 +185,8 @@ typedef struct {
   double rin2, rout2, zcut_in, zcut_out, k2, ninv_rin, inv_rout, H, rho, sigma;
   int lambertian, limit, surface_model, chord;
   double r_in;
+  uint64_t rho_thr;   /* survive iff word < rho_thr  <=>  (word + 0.5) 2^-32 < rho */
+  double inv_thr;     /* 1 / rho_thr: the surviving word, rescaled, is the azimuth's uniform */
   v3 src, dir0;
 } geom;
 
@@ -203,6 +207,12 @@ static int prepare(const isxo_config* c, geom* g) {
   g->inv_rout = 1.0 / c->r_out;
   g->H = c->box_half;
   g->rho = c->reflectance;
+  {
+    /* (w + 0.5) * 2^-32 < rho  <=>  w < rho * 2^32 - 0.5 =: x (both scalings exact)  <=>  w < ceil(x) for integer w */
+    double x = ldexp(c->reflectance, 32) - 0.5;
+    g->rho_thr = !(x > 0.0) ? 0ull : (x >= 4294967296.0 ? 4294967296ull : (uint64_t)ceil(x));
+    g->inv_thr = g->rho_thr ? 1.0 / (double)g->rho_thr : 0.0;
+  }
   g->sigma = c->roughness_rad;
   g->lambertian = c->lambertian;
   g->limit = c->max_points;
@@ -372,9 +382,13 @@ static v3 lobe_sample(v3 normal, uint64_t seed, uint64_t ray, uint32_t j, uint32
 
 /* returns 0 if absorbed, 1 otherwise (v updated) */
 static int interact(const geom* g, int kind, v3 q, v3* v, uint64_t seed, uint64_t ray, uint32_t j, uint32_t stream) {
+  /* Random words of interaction j: block j/2 of the trace's stream serves two interactions, words
+   * (0,1) the even one, (2,3) the odd one.  Word a -> polar angle.  Word b -> absorption AND azimuth: the ray survives
+   * iff b < rho_thr, and a surviving b is uniform on [0, rho_thr), so (b + 1/2)/rho_thr is a fresh uniform. */
   uint32_t wl[4];
-  draw_block(seed, ray, 2u * j, stream, wl);
-  if (!(isxo_u01(wl[2]) < g->rho)) return 0;
+  draw_block(seed, ray, j >> 1, stream, wl);
+  const uint32_t wa = wl[2u * (j & 1u)], wb = wl[2u * (j & 1u) + 1u];
+  if (!((uint64_t)wb < g->rho_thr)) return 0;
   v3 n = surface_normal(g, kind, q);
   v3 w;
   if (g->surface_model == 1) {
@@ -384,7 +398,7 @@ static int interact(const geom* g, int kind, v3 q, v3* v, uint64_t seed, uint64_
      * roughness does not act on a Lambertian border: the reference's own sigma=0.5 map
      * (flux_at_observer/fluxmap_data.csv) is reproduced with the roughness ignored and is
      * missed by 9.5 % on axis with a roughness-tilted normal. */
-    double u1 = isxo_u01(wl[0]), u2 = isxo_u01(wl[1]);
+    double u1 = isxo_u01(wa), u2 = ((double)wb + 0.5) * g->inv_thr;
     double r = sqrt(u1);
     double z = sqrt(1.0 - u1);
     double sf, cf;
@@ -408,7 +422,7 @@ static int interact(const geom* g, int kind, v3 q, v3* v, uint64_t seed, uint64_
       v3 A, Bv;
       onb(n, &A, &Bv);
       uint32_t wr[4];
-      draw_block(seed, ray, 2u * j + 1u, stream, wr);
+      draw_block(seed, ray, j, stream + 64u, wr);   /* the roughness draws have their own stream */
       double u1 = isxo_u01(wr[0]), u2 = isxo_u01(wr[1]), u3 = isxo_u01(wr[2]);
       double R = sqrt(-2.0 * isxo_log(u1));
       double s2, c2;
@@ -441,16 +455,17 @@ typedef struct { int status, npts, on; v3 p, v, prev; uint64_t wall_hits; } ends
 /* ISX_TRACE_CHORD: Lambertian bounce off the inner sphere.  For cosine-law emission from a point of a
  * sphere the far intersection is uniformly distributed over the sphere (the integrating-sphere identity:
  * the form factor between two surface elements of a sphere does not depend on where they are), so the next
- * wall point T is sampled directly.  Same Philox words as the explicit bounce: w0,w1 -> point, w2 -> absorb.
+ * wall point T is sampled directly.  Same Philox words as the explicit bounce: a -> z, b -> absorb + azimuth.
  * Returns 0 if absorbed. */
 static int interact_chord(const geom* g, v3* T, uint64_t seed, uint64_t ray, uint32_t j, uint32_t stream) {
   uint32_t wl[4];
-  draw_block(seed, ray, 2u * j, stream, wl);
-  if (!(isxo_u01(wl[2]) < g->rho)) return 0;
-  double zz = fma(-2.0, isxo_u01(wl[0]), 1.0);
+  draw_block(seed, ray, j >> 1, stream, wl);
+  const uint32_t wa = wl[2u * (j & 1u)], wb = wl[2u * (j & 1u) + 1u];
+  if (!((uint64_t)wb < g->rho_thr)) return 0;
+  double zz = fma(-2.0, isxo_u01(wa), 1.0);
   double s2 = sqrt(fma(-zz, zz, 1.0));
   double sf, cf;
-  isxo_circle_point(isxo_u01(wl[1]), &cf, &sf);
+  isxo_circle_point(((double)wb + 0.5) * g->inv_thr, &cf, &sf);
   double rxy = g->r_in * s2;
   T->x = rxy * cf; T->y = rxy * sf; T->z = g->r_in * zz;
   return 1;
