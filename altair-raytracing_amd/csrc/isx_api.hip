@@ -276,6 +276,11 @@ int enqueue(int sink, const isx_config* c, uint64_t n, uint64_t seed, uint64_t f
   }
   // the per-block histogram (+ tables) must fit the workgroup's LDS: a grid too fine for that is a configuration error
   if (lds > S.lds_limit) return ISX_ERR_BAD_CONFIG;
+  if (sink == SINK_FLUX) {
+    // room for the per-lane exit-line records of the lean kernels (20 B per lane), if the grid leaves it
+    const size_t stage = 16 + (size_t)kBlock * 20;
+    if (lds + stage <= S.lds_limit) { lds += stage; d.rec_stage = 1; }
+  }
   if (n == 0) return ISX_OK;
   Work wk;
   wk.seed = seed; wk.first = first; wk.n = n; wk.hist = d_hist; wk.stats = d_stats ? d_stats : S.d_stats;

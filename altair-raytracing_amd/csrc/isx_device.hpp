@@ -515,7 +515,7 @@ __device__ __forceinline__ bool interact(const Hot& h, const G& g, int kind, con
   }
   // one Newton step towards unit length (keeps the |v| error at rounding level instead of letting it
   // random-walk multiplicatively through hit point -> normal -> new direction)
-  const double k = fma(-0.5, dot3(w, w), 1.5);
+  const double k = fma(-0.5, dot3(w, w), sconst(1.5));
   w.x *= k; w.y *= k; w.z *= k;
   v = w;
   return true;

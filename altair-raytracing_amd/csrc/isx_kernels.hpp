@@ -36,7 +36,8 @@ struct DetGrid {
   // against that group's detector(s) only.  fold 1: group g = bin g.  fold 2 ("twofold",
   // fluxAtObserverFast.C:336-408): group g -> bins (i,j) and (i,j+n_phi/2), i=g/(n_phi/2).
   uint64_t map_first, rays_per_group;
-  int fold, pad1;
+  int fold;
+  int rec_stage;                        // 1: the launch reserved LDS for the per-lane exit-line records (prep_record)
   // SINK_LOG: un-binned exit log (3dRayLog.txt): records {ray id, dx, dy, dz} = 32 B per counted ray,
   // the one sink with real HBM output.  log_count is the device-side cursor; records beyond log_cap are dropped
   // (the cursor still counts them, so the caller can tell).
@@ -233,6 +234,52 @@ __device__ __forceinline__ void walk_rows(const D& d, uint32_t* __restrict__ his
   }
 }
 
+// The wave-uniform part of bin_culled (line vs S(O,R), the lower piercing point, its cap, the row range) evaluated
+// PER LANE by the lanes whose rays just left: once per loop trip for all of them instead of once per exit line.  Covers
+// the normal case only -- cap construction valid, the upper piercing point's cap above every detector row; anything
+// else (mode 1) goes through bin_culled as before.  Same formulas, same margins as bin_culled.
+struct RecPre {
+  float Fz, AF, jf, ch2;
+  int rows;   // ilo | ihi << 16 (fast path: cap around the lower piercing point only), or -1: general path
+};
+struct GridConst { float Rf, rho, portz, inv_dphi, inv_dth; int n_theta; };   // wave-uniform, read once per trip
+__device__ __forceinline__ RecPre prep_record(const GridConst& k, const V3& P, const V3& V) {
+  RecPre o;
+  o.Fz = 0.f; o.AF = 0.f; o.jf = 0.f; o.ch2 = 0.f; o.rows = -1;
+  const double wz = P.z - (double)k.portz;
+  const double wv = fma(P.x, V.x, fma(P.y, V.y, wz * V.z));
+  const double hx = fma(-wv, V.x, P.x), hy = fma(-wv, V.y, P.y), hz = fma(-wv, V.z, wz);
+  const float dO2 = (float)fma(hx, hx, fma(hy, hy, hz * hz));
+  const float R2 = k.Rf * k.Rf;
+  const float dO = sqrt_cull(dO2);
+  const float a1 = dO + k.rho;
+  if (!(a1 < 0.999f * k.Rf)) return o;
+  const float sF = sqrt_cull(R2 - dO2);
+  const float smin = sqrt_cull(R2 - a1 * a1);
+  const float a0 = fmaxf(0.f, dO - k.rho);
+  const float smax = sqrt_cull(R2 - a0 * a0);
+  const float ext = fmaxf(sF - smin, smax - sF);
+  const float ch2 = fmaf(ext, ext, k.rho * k.rho) * 1.0001f + 1e-3f;
+  if (!(4.0f * (R2 - dO2) > 4.04f * ch2)) return o;
+  const float ch = sqrt_cull(ch2);
+  const float omega = ch * rcp_cull(k.Rf) * 1.01f + 2e-3f;
+  const double s0 = (double)sF - wv, s1 = -(double)sF - wv;
+  const float Fz0 = (float)fma(s0, V.z, P.z), Fz1 = (float)fma(s1, V.z, P.z);
+  // fast path: the cap of side 0 reaches detector rows, the cap of side 1 lies above all of them
+  if (Fz0 - ch > k.portz || !(Fz1 - ch > k.portz)) return o;
+  const float Fx = (float)fma(s0, V.x, P.x), Fy = (float)fma(s0, V.y, P.y);
+  const float AF2 = fmaf(Fx, Fx, Fy * Fy);
+  const float AF = sqrt_cull(AF2);
+  float phiF = atan2_cull(Fy, Fx);
+  if (phiF < 0.f) phiF += 6.28318530718f;
+  const float thF = atan2_cull(AF, k.portz - Fz0);
+  const int ilo = max((int)floorf((thF - omega) * k.inv_dth - 0.5f - 1e-3f), 0);
+  const int ihi = min((int)ceilf((thF + omega) * k.inv_dth - 0.5f + 1e-3f), k.n_theta - 1);
+  o.Fz = Fz0; o.AF = AF; o.jf = phiF * k.inv_dphi - 0.5f; o.ch2 = ch2;
+  if (ihi >= ilo && k.n_theta <= 32767) o.rows = ilo | (ihi << 16);
+  return o;
+}
+
 template <class DG>
 __device__ inline void bin_culled(const DG& dd, uint32_t* __restrict__ hist,
                                       const double* __restrict__ rowt, const ColX* __restrict__ colx,
@@ -351,7 +398,7 @@ __device__ __forceinline__ void hit_line_compat(V3& P, V3& V) {
 struct Ray {
   V3 p, v;
   V3 prev;          // start of the current segment (only kept for SINK_DISC)
-  uint64_t id;
+  uint32_t ido;     // ray index relative to the wave's (or launch's) first ray: id = id_base + ido
   uint32_t j;       // mirror interactions of the current trace; track points = j + 1 (+1 once it left the box)
   int on;
   int phase;        // 0 primary, 2 scattered (source_model 1)
@@ -360,8 +407,8 @@ struct Ray {
 };
 
 template <class G>
-__device__ __forceinline__ void ray_start(const G& g, Ray& r, uint64_t id) {
-  r.id = id; r.j = 0; r.on = K_NONE; r.phase = 0; r.tgt = false;
+__device__ __forceinline__ void ray_start(const G& g, Ray& r, uint32_t ido) {
+  r.ido = ido; r.j = 0; r.on = K_NONE; r.phase = 0; r.tgt = false;
   r.p.x = g.src[0]; r.p.y = g.src[1]; r.p.z = g.src[2];
   r.v.x = g.dir0[0]; r.v.y = g.dir0[1]; r.v.z = g.dir0[2];
 }
@@ -370,20 +417,21 @@ __device__ __forceinline__ void ray_start(const G& g, Ray& r, uint64_t id) {
 // CH: 0 explicit bounces only, 1 chord identity for every eligible bounce (compile time), 2 decided by h.chord.
 // Returns 0 while running, else the end status of the CURRENT trace.
 template <bool KEEP_PREV, bool LEAN, int CH, int PH = PH_DIRECT, class G>
-__device__ __forceinline__ int ray_arrive(const Hot& h, const G& g, Ray& r, uint64_t seed, int kind, const V3& q) {
+__device__ __forceinline__ int ray_arrive(const Hot& h, const G& g, Ray& r, uint64_t seed, uint64_t id_base, int kind, const V3& q) {
+  const uint64_t rid = id_base + (uint64_t)r.ido;
   if (KEEP_PREV) r.prev = r.p;
   r.p = q;
   if (kind == K_BOX) { r.on = K_BOX; return ST_EXITED; }
   r.on = kind;
   bool alive;
   uint32_t wa, wb;
-  bounce_words<PH>(seed, r.id, r.j, (uint32_t)r.phase, r.cw, wa, wb);
+  bounce_words<PH>(seed, rid, r.j, (uint32_t)r.phase, r.cw, wa, wb);
   const bool eligible = (kind == K_INNER) && (LEAN || (h.lambertian && h.surface_model == 0));
   if (CH != 0 && eligible && (CH == 1 || h.chord)) {
     alive = interact_chord(h, r.v, wa, wb);
     r.tgt = alive;
   } else {
-    alive = interact<LEAN>(h, g, kind, q, r.v, seed, r.id, r.j, (uint32_t)r.phase, wa, wb);
+    alive = interact<LEAN>(h, g, kind, q, r.v, seed, rid, r.j, (uint32_t)r.phase, wa, wb);
   }
   r.j++;
   if (!alive) return ST_ABSORBED;
@@ -406,20 +454,20 @@ __device__ __forceinline__ bool chord_arrive(const Hot& h, Ray& r, V3& q) {
 
 // One full step: next boundary + interaction (chord mode decided at run time).
 template <bool KEEP_PREV, class G>
-__device__ __forceinline__ int ray_step(const Hot& h, const G& g, Ray& r, uint64_t seed) {
+__device__ __forceinline__ int ray_step(const Hot& h, const G& g, Ray& r, uint64_t seed, uint64_t id_base) {
   V3 q;
   int kind;
   if (r.tgt && chord_arrive(h, r, q)) kind = K_INNER;
   else kind = next_hit(h, g, r.p, r.v, r.on, q);
-  return ray_arrive<KEEP_PREV, false, 2>(h, g, r, seed, kind, q);
+  return ray_arrive<KEEP_PREV, false, 2>(h, g, r, seed, id_base, kind, q);
 }
 
 // nonLambertianFlux.C:253-268: restart from the primary's last point along a BRDF-sampled direction
 template <class G>
-__device__ __forceinline__ void ray_rescatter(const G& g, Ray& r, uint64_t seed) {
+__device__ __forceinline__ void ray_rescatter(const G& g, Ray& r, uint64_t seed, uint64_t id_base) {
   V3 d0; d0.x = g.dir0[0]; d0.y = g.dir0[1]; d0.z = g.dir0[2];
   const V3 normal = tv_unit(r.p);
-  const V3 nd = brdf_sample(g, normal, d0, seed, r.id);
+  const V3 nd = brdf_sample(g, normal, d0, seed, id_base + (uint64_t)r.ido);
   const double mag = sqrt(nd.x * nd.x + nd.y * nd.y + nd.z * nd.z);
   r.v.x = nd.x / mag; r.v.y = nd.y / mag; r.v.z = nd.z / mag;
   r.on = (r.on == K_BOX) ? K_NONE : r.on;
@@ -521,6 +569,7 @@ __device__ __forceinline__ void persistent_body(const Geom& g_arg, const DetGrid
   const double portz = d_arg.portz;
   const int bin_mode = d_arg.bin_mode;
   const int hit_line_mode = d_arg.hit_line_mode;
+  const int rec_stage = d_arg.rec_stage;
   const int sched_mask = g_arg.sched_mask, sched_min = g_arg.sched_min;
   const uint64_t seed = wk.seed;
 
@@ -544,7 +593,8 @@ __device__ __forceinline__ void persistent_body(const Geom& g_arg, const DetGrid
   r.prev = r.p;
   bool alive = false, parked = false;
   uint32_t iter = 0;
-  uint32_t n_exited = 0, n_counted = 0, n_susp = 0, n_ended = 0, n_wall = 0;   // per lane
+  uint32_t n_wall = 0;                                                           // per lane: mirror interactions of its finished rays
+  uint32_t n_exited = 0, n_counted = 0, n_susp = 0, n_ended = 0;                 // per wave (ballot counts: scalar registers)
   unsigned long long n_inc = 0;                                                  // per wave (SINK_LOG; the histogram sinks count at flush)
 
   for (;;) {
@@ -556,7 +606,7 @@ __device__ __forceinline__ void persistent_body(const Geom& g_arg, const DetGrid
             __builtin_amdgcn_mbcnt_hi((uint32_t)(dead >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)dead, 0u));
         if (!alive) {
           const uint64_t id = next + rank;
-          if (id < end) { ray_start(g, r, id); alive = true; }
+          if (id < end) { ray_start(g, r, (uint32_t)(id - range_first)); alive = true; }
         }
         next += (uint64_t)__popcll(dead);
       }
@@ -575,7 +625,7 @@ __device__ __forceinline__ void persistent_body(const Geom& g_arg, const DetGrid
     static_assert(!kShare || (kStepsPerTrip % 2) == 0, "block sharing needs an even number of steps per trip");
     auto arrive = [&](int kind, const V3& q, auto ph) {
       constexpr int PH = kShare ? decltype(ph)::value : PH_DIRECT;
-      const int st = ray_arrive<SINK == SINK_DISC, LEAN, CH, PH>(h, g, r, seed, kind, q);
+      const int st = ray_arrive<SINK == SINK_DISC, LEAN, CH, PH>(h, g, r, seed, range_first, kind, q);
       if (st != 0) { alive = false; pend = st; }   // census / re-scatter once per trip (below), not per bounce
     };
     // hot boundary search of one lane: true if it arrived on the inner mirror patch, else the lane parks
@@ -620,20 +670,25 @@ __device__ __forceinline__ void persistent_body(const Geom& g_arg, const DetGrid
       // nonLambertianFlux.C:253-268: the primary trace is over (whatever its status); the ray restarts from its last
       // point along a BRDF-sampled direction.  One copy of this code per trip instead of one per bounce.
       n_wall += r.j;
-      ray_rescatter(g, r, seed);
+      ray_rescatter(g, r, seed, range_first);
       alive = true;
       pend = 0;
     }
-    if (pend != 0) {
-      n_ended++;
-      n_wall += r.j;
-      if (n_wall > 0x7fffffffu) { atomicAdd(&sstat[6], (unsigned long long)n_wall); n_wall = 0; }
-      if (pend == ST_EXITED) {
-        n_exited++;
-        const bool below = r.p.z < portz;  // isRayPassingThroughExitPort, fluxAtObserver.C:162-166
-        if (below) n_counted++;
-        bin_me = (SINK == SINK_DISC) ? true : below;
-      } else if (pend == ST_SUSPENDED) n_susp++;
+    {
+      const bool ended = pend != 0, exited = pend == ST_EXITED;
+      const bool below = exited && (r.p.z < portz);   // isRayPassingThroughExitPort, fluxAtObserver.C:162-166
+      if (ended) {
+        n_wall += r.j;
+        if (n_wall > 0x7fffffffu) { atomicAdd(&sstat[6], (unsigned long long)n_wall); n_wall = 0; }
+      }
+      bin_me = (SINK == SINK_DISC) ? exited : below;
+      const unsigned long long me = __ballot(ended);
+      if (me) {
+        n_ended += (uint32_t)__popcll(me);
+        n_exited += (uint32_t)__popcll(__ballot(exited));
+        n_counted += (uint32_t)__popcll(__ballot(below));
+        n_susp += (uint32_t)__popcll(__ballot(pend == ST_SUSPENDED));
+      }
     }
     if (SINK == SINK_LOG) {
       // wave-aggregated append: one atomic on the cursor per wave-step, 32-byte records
@@ -649,7 +704,7 @@ __device__ __forceinline__ void persistent_body(const Geom& g_arg, const DetGrid
           const unsigned long long slot = base + rank;
           if (slot < d_arg.log_cap) {
             double4 rec;
-            rec.x = __longlong_as_double((long long)r.id); rec.y = r.v.x; rec.z = r.v.y; rec.w = r.v.z;
+            rec.x = __longlong_as_double((long long)(range_first + (uint64_t)r.ido)); rec.y = r.v.x; rec.z = r.v.y; rec.w = r.v.z;
             reinterpret_cast<double4*>(d_arg.log_rec)[slot] = rec;
           }
         }
@@ -665,7 +720,7 @@ __device__ __forceinline__ void persistent_body(const Geom& g_arg, const DetGrid
         const double half_w2 = d.half_w2;
         V3 lp = r.p, lv = r.v;
         if (hit_line_mode == 1) hit_line_compat(lp, lv);
-        const uint64_t rel = r.id - map_first;
+        const uint64_t rel = (range_first + (uint64_t)r.ido) - map_first;
         uint64_t grp = (uint64_t)((double)rel / (double)rpg);
         if (grp * rpg > rel) grp--;
         else if ((grp + 1) * rpg <= rel) grp++;
@@ -693,8 +748,29 @@ __device__ __forceinline__ void persistent_body(const Geom& g_arg, const DetGrid
       }
       if (hit) atomicAdd(&hist[b], 1u);
     } else {
-      // ---- wave-cooperative binning of every line that left in this step
+      // ---- wave-cooperative binning of every line that left in this trip
       unsigned long long em = __ballot(bin_me);
+      constexpr bool kFast = (SINK == SINK_FLUX) && LEAN;   // lean kernels: hit line = last segment, no compat mode
+      const bool fast = kFast && rec_stage && bin_mode == 1;
+      // per-wave staging of the exit-line records in LDS (16 B + 4 B per lane, after the parameter blocks)
+      float4* rec4 = nullptr;
+      int* reci = nullptr;
+      if (fast && em) {
+        // (offsets from `smem`, not pointer-to-integer casts: the accesses must stay ds_read/ds_write with 32-bit addresses)
+        const uint32_t off_rec = ((uint32_t)(reinterpret_cast<unsigned char*>(d_lds + 1) - smem) + 15u) & ~15u;
+        float4* base = reinterpret_cast<float4*>(smem + off_rec);
+        rec4 = base + (tid >> 6) * 64;
+        reci = reinterpret_cast<int*>(base + kWavesPerBlock * 64) + (tid >> 6) * 64;
+        if (bin_me) {   // the exiting lanes prepare their own lines, all at once, and park the result in LDS
+          GridConst k;
+          k.Rf = (float)d.R; k.rho = (float)d.rho_d; k.portz = (float)portz; k.n_theta = d.n_theta;
+          k.inv_dphi = (float)d.n_phi * 0.15915494309f;
+          k.inv_dth = (float)k.n_theta * 0.63661977237f;
+          const RecPre pre = prep_record(k, r.p, r.v);
+          rec4[lane] = make_float4(pre.Fz, pre.AF, pre.jf, pre.ch2);
+          reci[lane] = pre.rows;
+        }
+      }
       while (em) {
         const int src = __builtin_ctzll(em);
         em &= em - 1ull;
@@ -708,7 +784,20 @@ __device__ __forceinline__ void persistent_body(const Geom& g_arg, const DetGrid
         } else {
           if (!LEAN && hit_line_mode == 1) hit_line_compat(P, V);
           if (bin_mode == 0) bin_brute(d, hist, P, V, lane);
-          else if (bin_mode == 1) bin_culled(d, hist, rowt, colx, P, V, lane);
+          else if (bin_mode == 1) {
+            const int rows = fast ? __builtin_amdgcn_readfirstlane(reci[src]) : -1;   // same address in every lane
+            if (rows >= 0) {
+              const float4 q4 = rec4[src];
+              struct { int n_phi; double half_w2; const double* table; } dfast;
+              dfast.n_phi = d.n_phi; dfast.half_w2 = d.half_w2; dfast.table = d.table;
+              CapWin wfast;
+              wfast.inv_dphi = (float)dfast.n_phi * 0.15915494309f;
+              wfast.Fz = q4.x; wfast.AF = q4.y; wfast.AF2 = q4.y * q4.y; wfast.jf = q4.z; wfast.ch2 = q4.w;
+              walk_rows<true>(dfast, hist, rowt, colx, P, V, lane, rows & 0xffff, rows >> 16, wfast);
+            } else {
+              bin_culled(d, hist, rowt, colx, P, V, lane);
+            }
+          }
           // bin_mode 2: diagnostic only (trace without binning; results are NOT a flux map)
         }
       }
@@ -716,12 +805,12 @@ __device__ __forceinline__ void persistent_body(const Geom& g_arg, const DetGrid
   }
 
   // ---- census + histogram flush
-  atomicAdd(&sstat[1], (unsigned long long)n_exited);
-  atomicAdd(&sstat[2], (unsigned long long)n_counted);
-  atomicAdd(&sstat[3], (unsigned long long)(n_ended - n_exited - n_susp));  // absorbed
-  atomicAdd(&sstat[4], (unsigned long long)n_susp);
   atomicAdd(&sstat[6], (unsigned long long)n_wall);
   if (lane == 0) {
+    atomicAdd(&sstat[1], (unsigned long long)n_exited);
+    atomicAdd(&sstat[2], (unsigned long long)n_counted);
+    atomicAdd(&sstat[3], (unsigned long long)(n_ended - n_exited - n_susp));  // absorbed
+    atomicAdd(&sstat[4], (unsigned long long)n_susp);
     atomicAdd(&sstat[0], (unsigned long long)(range_end - range_first));       // launched = this wave's range
     atomicAdd(&sstat[5], n_inc);
   }
@@ -767,11 +856,11 @@ isx_endstates_kernel(const Geom g, uint64_t seed, uint64_t first, uint64_t n, in
   if (i >= n) return;
   const Hot h = make_hot(g);
   Ray r;
-  ray_start(g, r, first + i);
+  ray_start(g, r, (uint32_t)i);
   int st;
   for (;;) {
-    st = ray_step<false>(h, g, r, seed);
-    if (st != 0 && h.source_model == 1 && r.phase == 0) { ray_rescatter(g, r, seed); st = 0; }
+    st = ray_step<false>(h, g, r, seed, first);
+    if (st != 0 && h.source_model == 1 && r.phase == 0) { ray_rescatter(g, r, seed, first); st = 0; }
     if (st != 0) break;
   }
   status[i] = st;
