@@ -845,6 +845,9 @@ extern "C" __global__ void ISX_KERNEL_ATTR
 isx_trace_disc_kernel(const Geom g, const DetGrid d, const Work wk) { persistent_body<SINK_DISC>(g, d, wk); }
 extern "C" __global__ void ISX_KERNEL_ATTR
 isx_trace_perpos_kernel(const Geom g, const DetGrid d, const Work wk) { persistent_body<SINK_PERPOS>(g, d, wk); }
+// the reference's main sweep (per-position maps) in the headline configuration: lean trace, one exact test per exiting ray
+extern "C" __global__ void ISX_KERNEL_ATTR
+isx_trace_perpos_lean_kernel(const Geom g, const DetGrid d, const Work wk) { persistent_body<SINK_PERPOS, true, 0>(g, d, wk); }
 extern "C" __global__ void ISX_KERNEL_ATTR
 isx_trace_log_kernel(const Geom g, const DetGrid d, const Work wk) { persistent_body<SINK_LOG>(g, d, wk); }
 
