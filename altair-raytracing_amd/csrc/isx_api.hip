@@ -297,7 +297,7 @@ int enqueue(int sink, const isx_config* c, uint64_t n, uint64_t seed, uint64_t f
                                         : lean ? (const void*)isx_trace_bin_kernel
                                         : brdf ? (const void*)isx_trace_bin_brdf_kernel : (const void*)isx_trace_bin_full_kernel)
                    : sink == SINK_DZ ? (const void*)isx_trace_dz_kernel
-                   : sink == SINK_DISC ? (const void*)isx_trace_disc_kernel
+                   : sink == SINK_DISC ? (lean && !chord ? (const void*)isx_trace_disc_lean_kernel : (const void*)isx_trace_disc_kernel)
                    : sink == SINK_PERPOS ? (lean && !chord ? (const void*)isx_trace_perpos_lean_kernel : (const void*)isx_trace_perpos_kernel)
                                          : (const void*)isx_trace_log_kernel;
   HIPCHK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -307,6 +307,7 @@ int enqueue(int sink, const isx_config* c, uint64_t n, uint64_t seed, uint64_t f
   else if (sink == SINK_FLUX && brdf) hipLaunchKernelGGL(isx_trace_bin_brdf_kernel, dim3(grid), dim3(kBlock), lds, S.stream, g, d, wk);
   else if (sink == SINK_FLUX) hipLaunchKernelGGL(isx_trace_bin_full_kernel, dim3(grid), dim3(kBlock), lds, S.stream, g, d, wk);
   else if (sink == SINK_DZ) hipLaunchKernelGGL(isx_trace_dz_kernel, dim3(grid), dim3(kBlock), lds, S.stream, g, d, wk);
+  else if (sink == SINK_DISC && lean && !chord) hipLaunchKernelGGL(isx_trace_disc_lean_kernel, dim3(grid), dim3(kBlock), lds, S.stream, g, d, wk);
   else if (sink == SINK_DISC) hipLaunchKernelGGL(isx_trace_disc_kernel, dim3(grid), dim3(kBlock), lds, S.stream, g, d, wk);
   else if (sink == SINK_PERPOS && lean && !chord) hipLaunchKernelGGL(isx_trace_perpos_lean_kernel, dim3(grid), dim3(kBlock), lds, S.stream, g, d, wk);
   else if (sink == SINK_PERPOS) hipLaunchKernelGGL(isx_trace_perpos_kernel, dim3(grid), dim3(kBlock), lds, S.stream, g, d, wk);
