@@ -363,6 +363,56 @@ def test_whole_row_fallback_equals_brute_force(isx):
     assert sb.bin_increments == sc.bin_increments == int(culled.sum()) and sc.bin_increments > 0
 
 
+def test_cull_is_conservative_on_random_geometries(isx, orc):
+    """The binning pre-selection rests on geometric bounds (caps on the sphere of detector centres, row/column windows,
+    whole-row fallback, far-line skip).  40 random configurations -- port angle, source, grid, detector size and
+    distance, port plane height, surface/source models -- culled == brute on the GPU for each, and == oracle for a few."""
+    rng = np.random.default_rng(20260101)
+    with_hits = 0
+    for k in range(40):
+        c = isx.default_config()
+        c.theta_max_deg = float(rng.uniform(150, 178))
+        c.reflectance = float(rng.choice([0.9, 0.97, 0.99, 1.0]))
+        c.max_points = 3000
+        c.src[0], c.src[1], c.src[2] = float(rng.uniform(-70, 70)), float(rng.uniform(-30, 30)), float(rng.uniform(-85, 40))
+        c.dir[0], c.dir[1], c.dir[2] = float(rng.uniform(1, 6)), float(rng.uniform(-3, 3)), float(rng.uniform(-2, 2))
+        c.n_theta, c.n_phi = int(rng.integers(1, 120)), int(rng.integers(1, 140))
+        c.det_diameter = float(rng.choice([1.0, 5.0, 20.0, 40.0, 90.0, 190.0]))
+        c.det_distance = float(rng.choice([30.0, 100.0, 180.0]))
+        c.exit_port_z = float(rng.choice([-100.0, -120.0, -99.0]))
+        c.box_half = float(rng.choice([200.0, 300.0]))
+        mode = k % 4
+        if mode == 1:
+            c.source_model = 1
+        elif mode == 2:
+            c.trace_mode = 1
+        elif mode == 3:
+            c.lambertian = 0; c.roughness_rad = 0.2; c.reflectance = 0.9
+        n = 20000
+        isx.set_option("bin_mode", 0)
+        try:
+            brute, sb = isx.fluxmap(c, n, 1000 + k)
+        finally:
+            isx.set_option("bin_mode", 1)
+        culled, sc = isx.fluxmap(c, n, 1000 + k)
+        assert np.array_equal(brute, culled), (k, [getattr(c, f) for f in ("theta_max_deg", "n_theta", "n_phi", "det_diameter", "det_distance", "exit_port_z")])
+        assert sb.bin_increments == sc.bin_increments == int(culled.sum())
+        with_hits += int(sc.bin_increments > 1000)
+        if k % 8 == 0:
+            co = orc.default_config()
+            for f, _ in c._fields_:
+                v = getattr(c, f)
+                if hasattr(v, "__len__"):
+                    for i in range(len(v)):
+                        getattr(co, f)[i] = v[i]
+                else:
+                    setattr(co, f, v)
+            oh, ost = orc.fluxmap(co, n, 1000 + k)
+            assert np.array_equal(culled, oh), k
+            _census_equal(sc, ost)
+    assert with_hits >= 30, with_hits
+
+
 def test_exit_direction_log_bit_exact(isx, orc):
     """Un-binned exit log (3dRayLog.txt): ids and directions equal the oracle's, in ray order; overflow is reported."""
     def mk(mod):
