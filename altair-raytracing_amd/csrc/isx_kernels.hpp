@@ -85,19 +85,6 @@ __device__ __forceinline__ double readlane_f64(double x, int lane) {
 __device__ __forceinline__ float rcp_cull(float x) { return __builtin_amdgcn_rcpf(x); }
 __device__ __forceinline__ float sqrt_cull(float x) { return __builtin_amdgcn_sqrtf(x); }
 
-// max over the 64 lanes with DPP row shifts + row broadcasts (7 instructions; a ds_bpermute butterfly costs ~40)
-__device__ __forceinline__ int wave_max_i32(int x) {
-#define ISX_DPP_MAX(ctrl, rmask) x = max(x, __builtin_amdgcn_update_dpp(x, x, ctrl, rmask, 0xf, false))
-  ISX_DPP_MAX(0x111, 0xf);  // row_shr:1
-  ISX_DPP_MAX(0x112, 0xf);  // row_shr:2
-  ISX_DPP_MAX(0x114, 0xf);  // row_shr:4
-  ISX_DPP_MAX(0x118, 0xf);  // row_shr:8  -> lane 15 of every row holds its row's max
-  ISX_DPP_MAX(0x142, 0xa);  // row_bcast:15 into rows 1 and 3
-  ISX_DPP_MAX(0x143, 0xc);  // row_bcast:31 into rows 2 and 3 -> lane 63 holds the wave's max
-#undef ISX_DPP_MAX
-  return __builtin_amdgcn_readlane(x, 63);
-}
-
 // atan2 in f32, |error| < 2e-5 rad (checked in tests/test_cull_math.py against numpy)
 __device__ __forceinline__ float atan2_cull(float y, float x) {
   const float ax = fabsf(x), ay = fabsf(y);
