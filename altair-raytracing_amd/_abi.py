@@ -27,7 +27,7 @@ RAY_EXITED, RAY_ABSORBED, RAY_SUSPENDED = 1, 2, 3
 
 # every symbol include/isx.h declares (tests check the .so exports exactly these)
 EXPORTS = [
-    "isx_default_config", "isx_init", "isx_shutdown", "isx_strerror", "isx_last_hip_error", "isx_abi_version",
+    "isx_default_config", "isx_init", "isx_shutdown", "isx_strerror", "isx_last_hip_error", "isx_abi_version", "isx_stream_version",
     "isx_device_info", "isx_fluxmap", "isx_fluxmap_device", "isx_sync", "isx_take_stats", "isx_stream",
     "isx_set_option", "isx_mathprobe", "isx_trace_endstates", "isx_disc_sweep", "isx_detector_table",
     "isx_exit_dz_hist", "isx_fluxmap_per_position", "isx_trace_rays_detector", "isx_exit_directions",

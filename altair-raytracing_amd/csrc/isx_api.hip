@@ -352,6 +352,7 @@ int collect_stats(isx_stats* out) {
 extern "C" {
 
 int isx_abi_version(void) { return ISX_ABI_VERSION; }
+int isx_stream_version(void) { return ISX_STREAM_VERSION; }
 
 void isx_default_config(isx_config* c) {
   if (!c) return;

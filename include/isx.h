@@ -31,6 +31,11 @@ extern "C" {
 #endif
 
 #define ISX_ABI_VERSION 2
+/* Results are a pure function of (configuration, seed, ray indices) AND of the random-number layout below; a build with
+ * another ISX_STREAM_VERSION gives different (equally valid) histograms for the same seed.
+ * 3: Philox4x32-10, counter (ray lo, ray hi, block, stream); interaction j takes words (2(j&1), 2(j&1)+1) of block j/2;
+ *    absorption and azimuth share one word; Householder cosine emission. */
+#define ISX_STREAM_VERSION 3
 
 typedef enum isx_status {
   ISX_OK = 0,
@@ -119,6 +124,7 @@ void isx_shutdown(void);
 const char* isx_strerror(int status);
 int isx_last_hip_error(void);
 int isx_abi_version(void);
+int isx_stream_version(void);
 /* Name/arch/CU count of the bound device (buf may be NULL). Returns CU count or <0. */
 int isx_device_info(char* buf, int buflen);
 

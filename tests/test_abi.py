@@ -34,6 +34,7 @@ def test_library_exports_every_declared_symbol(mod):
 
 def test_abi_version_and_struct_layout(mod):
     assert mod.load().isx_abi_version() == 2
+    assert mod.load().isx_stream_version() == 3
     # isx_config: 6 dbl, 2 i32, 6 dbl, 2 i32, 3 dbl, 2 i32, 3 dbl, 2 i32 ; isx_stats: 7 u64 + dbl
     assert C.sizeof(mod.Config) == 8 * 6 + 8 + 8 * 6 + 8 + 8 * 3 + 8 + 8 * 3 + 8
     assert C.sizeof(mod.Stats) == 64
