@@ -40,13 +40,13 @@ struct Geom {
 // on demand from an LDS copy (a `const volatile Geom&`), so it never occupies scalar registers
 // across the loop (SGPR spills were >10 % of the issued instructions before this split).
 struct Hot {
-  double rin2, zcut_in, ninv_rin, r_in, inv_thr;
+  double zcut_in, ninv_rin, r_in, inv_thr;
   unsigned long long rho_thr;
   int lambertian, limit, source_model, surface_model, chord;
 };
 __device__ __forceinline__ Hot make_hot(const Geom& g) {
   Hot h;
-  h.rin2 = g.rin2; h.zcut_in = g.zcut_in; h.ninv_rin = g.ninv_rin; h.rho_thr = g.rho_thr; h.inv_thr = g.inv_thr;
+  h.zcut_in = g.zcut_in; h.ninv_rin = g.ninv_rin; h.rho_thr = g.rho_thr; h.inv_thr = g.inv_thr;
   h.lambertian = g.lambertian; h.limit = g.limit; h.source_model = g.source_model; h.surface_model = g.surface_model;
   h.r_in = g.r_in; h.chord = g.chord;
   return h;
@@ -323,15 +323,19 @@ __device__ inline int next_hit_generic(const G& gg, const V3 p, const V3 v, cons
 // t^2 + 2bt = 0 since p is on the sphere and |v| = 1 to rounding - so the hot path needs no square root
 // (an IEEE f64 sqrt costs ~91 cycles per wave here).  If the generic search has to take over it re-derives
 // the same -2b first, so both routes always agree.
-__device__ __forceinline__ bool next_hit_s1(const Hot& g, const V3& p, const V3& v, const int on, V3& q_out) {
+// FIRST: also the first segment of a ray (on == K_NONE: starts inside the ball; needs rin2 and a square root).  The
+// persistent kernels pass FIRST only on step 0 of a loop trip -- rays start there -- and read rin2 from the LDS copy of
+// the geometry when they need it; a case this function does not take simply falls to the generic search.
+template <bool FIRST = true, class G>
+__device__ __forceinline__ bool next_hit_s1(const Hot& h, const G& g, const V3& p, const V3& v, const int on, V3& q_out) {
   const double b = dot3(p, v);
   if (on == K_INNER) {
     if (!(b < 0.0)) return false;
     const V3 q = axpy(-2.0 * b, v, p);
-    if (q.z >= g.zcut_in) { q_out = q; return true; }
+    if (q.z >= h.zcut_in) { q_out = q; return true; }
     return false;
   }
-  if (on != K_NONE) return false;
+  if (!FIRST || on != K_NONE) return false;
   const double pp = dot3(p, p);
   const double ci = pp - g.rin2;
   const double di = fma(b, b, -ci);
@@ -339,14 +343,14 @@ __device__ __forceinline__ bool next_hit_s1(const Hot& g, const V3& p, const V3&
   const double s = sqrt(di);
   const double tf = s - b;
   const V3 q = axpy(tf, v, p);
-  if (q.z >= g.zcut_in) { q_out = q; return true; }
+  if (q.z >= h.zcut_in) { q_out = q; return true; }
   return false;
 }
 
 // Rule S1 first (hot path); anything else falls to the generic search (which re-derives the same numbers).
 template <class G>
 __device__ __forceinline__ int next_hit(const Hot& h, const G& g, const V3& p, const V3& v, const int on, V3& q_out) {
-  if (next_hit_s1(h, p, v, on, q_out)) return K_INNER;
+  if (next_hit_s1<true>(h, g, p, v, on, q_out)) return K_INNER;
   return next_hit_generic(g, p, v, on, q_out);
 }
 // ---------------------------------------------------------------- TVector3 arithmetic in ROOT's own op order (no fma)

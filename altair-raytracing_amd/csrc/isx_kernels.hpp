@@ -561,10 +561,6 @@ __device__ __forceinline__ void persistent_body(const Geom& g_arg, const DetGrid
   const volatile LdsDetGrid& d = *(const volatile LdsDetGrid*)d_lds;
   const Hot h = make_hot(g_arg);
   const double portz = d_arg.portz;
-  const int bin_mode = d_arg.bin_mode;
-  const int hit_line_mode = d_arg.hit_line_mode;
-  const int rec_stage = d_arg.rec_stage;
-  const int sched_mask = g_arg.sched_mask, sched_min = g_arg.sched_min;
   const uint64_t seed = wk.seed;
 
   const int lane = tid & 63;
@@ -623,20 +619,21 @@ __device__ __forceinline__ void persistent_body(const Geom& g_arg, const DetGrid
       if (st != 0) { alive = false; pend = st; }   // census / re-scatter once per trip (below), not per bounce
     };
     // hot boundary search of one lane: true if it arrived on the inner mirror patch, else the lane parks
-    auto hot_search = [&](V3& q) -> bool {
+    auto hot_search = [&](V3& q, auto first) -> bool {
       if (CH != 0 && r.tgt) return chord_arrive(h, r, q);
-      return next_hit_s1(h, r.p, r.v, r.on, q);
+      return next_hit_s1<decltype(first)::value>(h, g, r.p, r.v, r.on, q);
     };
     {
       V3 q;
       int kind = K_NONE;
       bool arrived = false;
       if (alive && !parked) {
-        if (hot_search(q)) { kind = K_INNER; arrived = true; }
+        if (hot_search(q, std::true_type())) { kind = K_INNER; arrived = true; }
         else parked = true;
       }
       const unsigned long long pm = __ballot(parked);
       if (pm) {
+        const int sched_min = g.sched_min, sched_mask = g.sched_mask;   // rare: read from the LDS copy
         const bool flush = ((int)__popcll(pm) >= sched_min) || ((iter & (uint32_t)sched_mask) == (uint32_t)sched_mask) ||
                            (__ballot(alive && !parked) == 0ull);
         if (flush && parked) {
@@ -653,7 +650,7 @@ __device__ __forceinline__ void persistent_body(const Geom& g_arg, const DetGrid
       V3 q;
       bool arrived = false;
       if (alive && !parked) {
-        if (hot_search(q)) arrived = true;
+        if (hot_search(q, std::false_type())) arrived = true;
         else parked = true;
       }
       if (arrived) arrive(K_INNER, q, std::integral_constant<int, (decltype(rep)::value & 1) ? PH_ODD : PH_EVEN>());
@@ -713,7 +710,7 @@ __device__ __forceinline__ void persistent_body(const Geom& g_arg, const DetGrid
         const double* table = d.table;
         const double half_w2 = d.half_w2;
         V3 lp = r.p, lv = r.v;
-        if (hit_line_mode == 1) hit_line_compat(lp, lv);
+        if (d.hit_line_mode == 1) hit_line_compat(lp, lv);
         const uint64_t rel = (range_first + (uint64_t)r.ido) - map_first;
         uint64_t grp = (uint64_t)((double)rel / (double)rpg);
         if (grp * rpg > rel) grp--;
@@ -745,7 +742,9 @@ __device__ __forceinline__ void persistent_body(const Geom& g_arg, const DetGrid
       // ---- wave-cooperative binning of every line that left in this trip
       unsigned long long em = __ballot(bin_me);
       constexpr bool kFast = (SINK == SINK_FLUX) && LEAN;   // lean kernels: hit line = last segment, no compat mode
-      const bool fast = kFast && rec_stage && bin_mode == 1;
+      const int bin_mode = em ? d.bin_mode : 1;   // wave-uniform scalars of the binning: read from the LDS copy when needed
+      const int hit_line_mode = (!LEAN && em) ? d.hit_line_mode : 0;
+      const bool fast = kFast && em && d.rec_stage && bin_mode == 1;
       // per-wave staging of the exit-line records in LDS (16 B + 4 B per lane, after the parameter blocks)
       float4* rec4 = nullptr;
       int* reci = nullptr;
