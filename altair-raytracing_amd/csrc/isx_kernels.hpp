@@ -581,7 +581,9 @@ __device__ __forceinline__ void persistent_body(const Geom& g_arg, const DetGrid
   Ray r;
   ray_start(g, r, 0);
   r.prev = r.p;
-  bool alive = false, parked = false;
+  // lane state: `run` = has a ray that the hot path can advance; `parked` = has a ray that waits for the generic boundary
+  // search; neither = no ray (never had one, or its ray ended)
+  bool run = false, parked = false;
   uint32_t iter = 0;
   uint32_t n_wall = 0;                                                           // per lane: mirror interactions of its finished rays
   uint32_t n_exited = 0, n_counted = 0, n_susp = 0, n_ended = 0;                 // per wave (ballot counts: scalar registers)
@@ -589,18 +591,18 @@ __device__ __forceinline__ void persistent_body(const Geom& g_arg, const DetGrid
 
   for (;;) {
     // ---- refill dead lanes from this wave's range
-    const unsigned long long dead = __ballot(!alive);
+    const unsigned long long dead = __ballot(!(run || parked));
     if (dead) {
       if (next < end) {
         const uint32_t rank =
             __builtin_amdgcn_mbcnt_hi((uint32_t)(dead >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)dead, 0u));
-        if (!alive) {
+        if (!(run || parked)) {
           const uint64_t id = next + rank;
-          if (id < end) { ray_start(g, r, (uint32_t)(id - range_first)); alive = true; }
+          if (id < end) { ray_start(g, r, (uint32_t)(id - range_first)); run = true; }
         }
         next += (uint64_t)__popcll(dead);
       }
-      if (__ballot(alive) == 0ull) break;
+      if (__ballot(run || parked) == 0ull) break;
     }
     // ---- one boundary + interaction per live lane.  The hot boundary search (rule S1) runs every
     // iteration; the generic search (port transits, rim, box: ~0.75 % of lane-steps but ~40 % of
@@ -616,7 +618,7 @@ __device__ __forceinline__ void persistent_body(const Geom& g_arg, const DetGrid
     auto arrive = [&](int kind, const V3& q, auto ph) {
       constexpr int PH = kShare ? decltype(ph)::value : PH_DIRECT;
       const int st = ray_arrive<SINK == SINK_DISC, LEAN, CH, PH>(h, g, r, seed, range_first, kind, q);
-      if (st != 0) { alive = false; pend = st; }   // census / re-scatter once per trip (below), not per bounce
+      if (st != 0) { run = false; pend = st; }   // census / re-scatter once per trip (below), not per bounce
     };
     // hot boundary search of one lane: true if it arrived on the inner mirror patch, else the lane parks
     auto hot_search = [&](V3& q, auto first) -> bool {
@@ -627,19 +629,20 @@ __device__ __forceinline__ void persistent_body(const Geom& g_arg, const DetGrid
       V3 q;
       int kind = K_NONE;
       bool arrived = false;
-      if (alive && !parked) {
+      if (run) {
         if (hot_search(q, std::true_type())) { kind = K_INNER; arrived = true; }
-        else parked = true;
+        else { parked = true; run = false; }
       }
       const unsigned long long pm = __ballot(parked);
       if (pm) {
         const int sched_min = g.sched_min, sched_mask = g.sched_mask;   // rare: read from the LDS copy
         const bool flush = ((int)__popcll(pm) >= sched_min) || ((iter & (uint32_t)sched_mask) == (uint32_t)sched_mask) ||
-                           (__ballot(alive && !parked) == 0ull);
+                           (__ballot(run) == 0ull);
         if (flush && parked) {
           kind = next_hit_generic(g, r.p, r.v, r.on, q);
           arrived = true;
           parked = false;
+          run = true;
         }
       }
       iter++;
@@ -649,9 +652,9 @@ __device__ __forceinline__ void persistent_body(const Geom& g_arg, const DetGrid
     static_steps<1, kStepsPerTrip>([&](auto rep) {
       V3 q;
       bool arrived = false;
-      if (alive && !parked) {
+      if (run) {
         if (hot_search(q, std::false_type())) arrived = true;
-        else parked = true;
+        else { parked = true; run = false; }
       }
       if (arrived) arrive(K_INNER, q, std::integral_constant<int, (decltype(rep)::value & 1) ? PH_ODD : PH_EVEN>());
     });
@@ -662,7 +665,7 @@ __device__ __forceinline__ void persistent_body(const Geom& g_arg, const DetGrid
       // point along a BRDF-sampled direction.  One copy of this code per trip instead of one per bounce.
       n_wall += r.j;
       ray_rescatter(g, r, seed, range_first);
-      alive = true;
+      run = true;
       pend = 0;
     }
     {
