@@ -196,6 +196,21 @@ def test_partition_and_launch_shape_invariance(isx):
         finally:
             isx.set_option("grid_blocks", 0)
         assert np.array_equal(full, h), grid
+    # the generic-search batching decides WHEN a lane resumes (and with which parity of its interaction count it meets
+    # the compute / reuse steps of the shared Philox block): every schedule must give the same map, in every lean kernel
+    cb = isx.default_config(); cb.source_model = 1; cb.reflectance = 0.98
+    cc = isx.default_config(); cc.trace_mode = 1
+    cp = isx.default_config(); cp.theta_max_deg = 150.0          # large port: many more port transits and rim hits
+    for cfg in (c, cb, cc, cp):
+        ref, rst = isx.fluxmap(cfg, n, SEED)
+        for mask, mn in ((0, 1), (1, 64), (7, 3), (255, 64)):
+            isx.set_option("sched_mask", mask); isx.set_option("sched_min", mn)
+            try:
+                h, hst = isx.fluxmap(cfg, n, SEED)
+            finally:
+                isx.set_option("sched_mask", 3); isx.set_option("sched_min", 12)
+            assert np.array_equal(ref, h), (mask, mn)
+            assert (rst.wall_hits, rst.absorbed, rst.counted_below_z) == (hst.wall_hits, hst.absorbed, hst.counted_below_z)
     # different seed => different map
     other, _ = isx.fluxmap(c, n, SEED + 1)
     assert not np.array_equal(full, other)
