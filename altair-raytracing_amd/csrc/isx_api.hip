@@ -293,25 +293,20 @@ int enqueue(int sink, const isx_config* c, uint64_t n, uint64_t seed, uint64_t f
   const bool lean = lean_surface && c->source_model == ISX_SOURCE_PENCIL;
   const bool chord = lean && c->trace_mode == ISX_TRACE_CHORD;
   const bool brdf = lean_surface && c->source_model == ISX_SOURCE_BRDF && c->trace_mode != ISX_TRACE_CHORD;
-  const void* fn = sink == SINK_FLUX ? (chord ? (const void*)isx_trace_bin_chord_kernel
-                                        : lean ? (const void*)isx_trace_bin_kernel
-                                        : brdf ? (const void*)isx_trace_bin_brdf_kernel : (const void*)isx_trace_bin_full_kernel)
-                   : sink == SINK_DZ ? (const void*)isx_trace_dz_kernel
-                   : sink == SINK_DISC ? (lean && !chord ? (const void*)isx_trace_disc_lean_kernel : (const void*)isx_trace_disc_kernel)
-                   : sink == SINK_PERPOS ? (lean && !chord ? (const void*)isx_trace_perpos_lean_kernel : (const void*)isx_trace_perpos_kernel)
-                                         : (const void*)isx_trace_log_kernel;
-  HIPCHK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  // kernel variant: lean builds serve the headline surface/source configuration, the full builds everything else
+  typedef void (*KernelFn)(const Geom, const DetGrid, const Work);
+  const bool lean_explicit = lean && !chord;
+  KernelFn fn;
+  switch (sink) {
+    case SINK_FLUX: fn = chord ? isx_trace_bin_chord_kernel : lean ? isx_trace_bin_kernel : brdf ? isx_trace_bin_brdf_kernel : isx_trace_bin_full_kernel; break;
+    case SINK_DZ: fn = lean_explicit ? isx_trace_dz_lean_kernel : isx_trace_dz_kernel; break;
+    case SINK_DISC: fn = lean_explicit ? isx_trace_disc_lean_kernel : isx_trace_disc_kernel; break;
+    case SINK_PERPOS: fn = lean_explicit ? isx_trace_perpos_lean_kernel : isx_trace_perpos_kernel; break;
+    default: fn = lean_explicit ? isx_trace_log_lean_kernel : isx_trace_log_kernel; break;
+  }
+  HIPCHK(hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   HIPCHK(hipEventRecord(e0, S.stream));
-  if (sink == SINK_FLUX && chord) hipLaunchKernelGGL(isx_trace_bin_chord_kernel, dim3(grid), dim3(kBlock), lds, S.stream, g, d, wk);
-  else if (sink == SINK_FLUX && lean) hipLaunchKernelGGL(isx_trace_bin_kernel, dim3(grid), dim3(kBlock), lds, S.stream, g, d, wk);
-  else if (sink == SINK_FLUX && brdf) hipLaunchKernelGGL(isx_trace_bin_brdf_kernel, dim3(grid), dim3(kBlock), lds, S.stream, g, d, wk);
-  else if (sink == SINK_FLUX) hipLaunchKernelGGL(isx_trace_bin_full_kernel, dim3(grid), dim3(kBlock), lds, S.stream, g, d, wk);
-  else if (sink == SINK_DZ) hipLaunchKernelGGL(isx_trace_dz_kernel, dim3(grid), dim3(kBlock), lds, S.stream, g, d, wk);
-  else if (sink == SINK_DISC && lean && !chord) hipLaunchKernelGGL(isx_trace_disc_lean_kernel, dim3(grid), dim3(kBlock), lds, S.stream, g, d, wk);
-  else if (sink == SINK_DISC) hipLaunchKernelGGL(isx_trace_disc_kernel, dim3(grid), dim3(kBlock), lds, S.stream, g, d, wk);
-  else if (sink == SINK_PERPOS && lean && !chord) hipLaunchKernelGGL(isx_trace_perpos_lean_kernel, dim3(grid), dim3(kBlock), lds, S.stream, g, d, wk);
-  else if (sink == SINK_PERPOS) hipLaunchKernelGGL(isx_trace_perpos_kernel, dim3(grid), dim3(kBlock), lds, S.stream, g, d, wk);
-  else hipLaunchKernelGGL(isx_trace_log_kernel, dim3(grid), dim3(kBlock), lds, S.stream, g, d, wk);
+  hipLaunchKernelGGL(fn, dim3(grid), dim3(kBlock), lds, S.stream, g, d, wk);
   HIPCHK(hipGetLastError());
   HIPCHK(hipEventRecord(e1, S.stream));
   return ISX_OK;

@@ -838,6 +838,8 @@ isx_trace_bin_full_kernel(const Geom g, const DetGrid d, const Work wk) { persis
 extern "C" __global__ void ISX_KERNEL_ATTR
 isx_trace_dz_kernel(const Geom g, const DetGrid d, const Work wk) { persistent_body<SINK_DZ>(g, d, wk); }
 extern "C" __global__ void ISX_KERNEL_ATTR
+isx_trace_dz_lean_kernel(const Geom g, const DetGrid d, const Work wk) { persistent_body<SINK_DZ, true, 0>(g, d, wk); }
+extern "C" __global__ void ISX_KERNEL_ATTR
 isx_trace_disc_kernel(const Geom g, const DetGrid d, const Work wk) { persistent_body<SINK_DISC>(g, d, wk); }
 extern "C" __global__ void ISX_KERNEL_ATTR
 isx_trace_disc_lean_kernel(const Geom g, const DetGrid d, const Work wk) { persistent_body<SINK_DISC, true, 0>(g, d, wk); }
@@ -848,6 +850,8 @@ extern "C" __global__ void ISX_KERNEL_ATTR
 isx_trace_perpos_lean_kernel(const Geom g, const DetGrid d, const Work wk) { persistent_body<SINK_PERPOS, true, 0>(g, d, wk); }
 extern "C" __global__ void ISX_KERNEL_ATTR
 isx_trace_log_kernel(const Geom g, const DetGrid d, const Work wk) { persistent_body<SINK_LOG>(g, d, wk); }
+extern "C" __global__ void ISX_KERNEL_ATTR
+isx_trace_log_lean_kernel(const Geom g, const DetGrid d, const Work wk) { persistent_body<SINK_LOG, true, 0>(g, d, wk); }
 
 // ------------------------------------------------------------------ per-ray end states (parity tests)
 extern "C" __global__ void __launch_bounds__(256)
