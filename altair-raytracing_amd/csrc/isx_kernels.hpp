@@ -5,11 +5,14 @@
 //     indices and refills dead lanes from it (no atomics on the refill path), so lanes stay
 //     busy although the bounce count per ray is geometric (mean ~57, tail >> mean);
 //   * RNG is Philox4x32-10 keyed by (seed) and counted by (ray index, draw block, stream):
-//     a ray's history does not depend on which lane/wave/GPU traces it;
-//   * when a lane's ray leaves through the port, its line (last point, final direction)
-//     is broadcast with v_readlane and ALL 64 lanes of the wave test detector positions
-//     for it (one detector per lane per step) - no divergence in the binning, and the
-//     increments of one step go to 64 different bins;
+//     a ray's history does not depend on which lane/wave/GPU traces it; one block serves two
+//     bounces and is computed on the even steps of a loop trip only (bounce_words);
+//   * ISX_STEPS bounce steps per loop trip; refill, generic-search flush, census, BRDF re-scatter
+//     and the binning of the lines that left are paid once per trip;
+//   * the lanes whose rays left through the port prepare their lines themselves (prep_record:
+//     line vs the sphere of detector centres, cap, row range), then each line is broadcast and
+//     ALL 64 lanes of the wave bin it - lane = detector row, walking the row's phi-window
+//     (walk_rows); the cull never decides a result, the exact reference-order test does;
 //   * bins live in a per-block LDS histogram (u32[n_theta*n_phi] = 64.8 KB for 180x90),
 //     flushed once per block with global 64-bit atomics.
 #pragma once
@@ -607,7 +610,7 @@ __device__ __forceinline__ void persistent_body(const Geom& g_arg, const DetGrid
     // ---- one boundary + interaction per live lane.  The hot boundary search (rule S1) runs every
     // iteration; the generic search (port transits, rim, box: ~0.75 % of lane-steps but ~40 % of
     // wave-iterations if run eagerly) is BATCHED: a lane that needs it parks until several lanes
-    // need it, every 4th iteration, or nothing else is left to do.  Scheduling only - a ray's
+    // need it, every 4th loop trip, or nothing else is left to do.  Scheduling only - a ray's
     // history never depends on it.
     bool bin_me = false;
     int pend = 0;     // end status of the ray this lane finished during the trip, 0 if none
