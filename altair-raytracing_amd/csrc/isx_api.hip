@@ -285,6 +285,8 @@ int enqueue(int sink, const isx_config* c, uint64_t n, uint64_t seed, uint64_t f
   Work wk;
   wk.seed = seed; wk.first = first; wk.n = n; wk.hist = d_hist; wk.stats = d_stats ? d_stats : S.d_stats;
   const int grid = pick_grid(n);
+  // a block counts in 32-bit LDS bins and a wave addresses its rays by 32-bit offsets: at most 2^32-1 rays per block
+  if ((n + (uint64_t)grid - 1) / (uint64_t)grid > 0xffffffffull) return ISX_ERR_TOO_LARGE;
   hipEvent_t e0, e1;
   rc = get_event(&e0); if (rc) return rc;
   rc = get_event(&e1); if (rc) return rc;
