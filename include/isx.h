@@ -44,10 +44,11 @@ typedef enum isx_status {
   ISX_ERR_BAD_ARG = -3,     /* null pointer, zero size ... */
   ISX_ERR_HIP = -4,         /* a HIP call failed; isx_last_hip_error() has the code */
   ISX_ERR_NOT_INIT = -5,
-  ISX_ERR_TOO_LARGE = -6    /* n_rays per call above ISX_MAX_RAYS_PER_CALL */
+  ISX_ERR_TOO_LARGE = -6    /* n_rays per call above ISX_MAX_RAYS_PER_CALL, or above 2^32-1 per workgroup */
 } isx_status;
 
-/* One launch may trace at most this many rays (per-block 32-bit LDS bins). */
+/* One launch may trace at most this many rays, and at most 2^32-1 per workgroup (32-bit LDS bins, 32-bit ray offsets):
+ * with the default grid of one workgroup per CU that is ~1.1e12 rays on an MI355X.  Split larger jobs over calls. */
 #define ISX_MAX_RAYS_PER_CALL (1ull << 40)
 
 /* source_model */
