@@ -228,6 +228,7 @@ int enqueue(int sink, const isx_config* c, uint64_t n, uint64_t seed, uint64_t f
   int rc = prepare_geom(c, &g);
   if (rc) return rc;
   if (n > ISX_MAX_RAYS_PER_CALL) return ISX_ERR_TOO_LARGE;
+  if (first > UINT64_MAX - n) return ISX_ERR_BAD_ARG;   // first + n (the exclusive end of the index range) must be representable
   DetGrid d;
   std::memset(&d, 0, sizeof(d));
   d.portz = c->exit_port_z;

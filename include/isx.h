@@ -48,7 +48,8 @@ typedef enum isx_status {
 } isx_status;
 
 /* One launch may trace at most this many rays, and at most 2^32-1 per workgroup (32-bit LDS bins, 32-bit ray offsets):
- * with the default grid of one workgroup per CU that is ~1.1e12 rays on an MI355X.  Split larger jobs over calls. */
+ * with the default grid of one workgroup per CU that is ~1.1e12 rays on an MI355X.  Split larger jobs over calls.
+ * Ray indices are 64-bit; first_ray + n_rays must not exceed 2^64 - 1 (ISX_ERR_BAD_ARG). */
 #define ISX_MAX_RAYS_PER_CALL (1ull << 40)
 
 /* source_model */

@@ -244,6 +244,22 @@ def test_bad_config_is_rejected(isx):
     assert "configuration" in str(e.value).lower() or "config" in str(e.value).lower()
 
 
+def test_large_ray_indices_bit_exact(isx, orc):
+    """Ray indices are 64-bit Philox counter words: far-out index ranges behave like any other, up to the very last
+    index; a range that would wrap at 2^64 is refused."""
+    for first in (1 << 40, (1 << 63) + 12345, (1 << 64) - 20001):
+        gh, gst = isx.fluxmap(isx.default_config(), 20000, SEED, first)
+        oh, ost = orc.fluxmap(orc.default_config(), 20000, SEED, first)
+        assert np.array_equal(gh, oh), hex(first)
+        _census_equal(gst, ost)
+    gs, gn, gp, gd = isx.trace_endstates(isx.default_config(), 5000, SEED, (1 << 64) - 5001)
+    os_, on, op, od = orc.trace_endstates(orc.default_config(), 5000, SEED, (1 << 64) - 5001)
+    assert np.array_equal(gs, os_) and np.array_equal(gn, on) and np.array_equal(_bits(gp), _bits(op)) and np.array_equal(_bits(gd), _bits(od))
+    with pytest.raises(isx.IsxError) as e:
+        isx.fluxmap(isx.default_config(), 20000, SEED, (1 << 64) - 3000)
+    assert e.value.status == isx.abi.ERR_BAD_ARG
+
+
 def test_too_many_rays_per_call_is_refused(isx):
     c = isx.default_config()
     with pytest.raises(isx.IsxError) as e:
