@@ -2,8 +2,12 @@
 
 Bar: bit-exact for every integer output (hit counts, census) and for the per-ray end
 states (binary64 compared as bit patterns)."""
+import os
+
 import numpy as np
 import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 pytestmark = pytest.mark.gpu
 
@@ -242,6 +246,41 @@ def test_bad_config_is_rejected(isx):
     with pytest.raises(isx.IsxError) as e:
         isx.fluxmap(c, 10, 1)
     assert "configuration" in str(e.value).lower() or "config" in str(e.value).lower()
+
+
+def test_device_resident_accumulation():
+    """isx_fluxmap_device: several launches queued on the library stream accumulate (+=) into ONE caller-owned device
+    histogram (the form bench.py hands to the RCCL all-reduce); isx_take_stats sums their census.  Own process: torch's
+    bundled HIP runtime has to come up before libisx's (the order bench.py uses), which a shared pytest process cannot promise."""
+    import subprocess
+    import sys
+    code = r"""
+import sys, numpy as np, torch
+sys.path.insert(0, %r)
+torch.cuda.init(); torch.zeros(1, device="cuda:0")
+import altair_raytracing_amd as isx
+isx.load(); isx.init(0)
+SEED = 12345
+c = isx.default_config()
+nb = c.n_theta * c.n_phi
+d = torch.zeros(nb, dtype=torch.int64, device="cuda:0")
+torch.cuda.synchronize()
+isx.fluxmap_device(c, 30000, SEED, 0, d.data_ptr())
+isx.fluxmap_device(c, 20000, SEED, 30000, d.data_ptr())
+isx.sync()
+st = isx.take_stats()
+want, wst = isx.fluxmap(c, 50000, SEED, 0)
+torch.cuda.synchronize()
+got = d.cpu().numpy().astype(np.uint64).reshape(c.n_theta, c.n_phi)
+assert np.array_equal(got, want)
+assert (st.launched, st.counted_below_z, st.wall_hits, st.bin_increments) == (50000, wst.counted_below_z, wst.wall_hits, wst.bin_increments)
+isx.fluxmap_device(c, 50000, SEED, 0, d.data_ptr())      # a third launch keeps adding
+isx.sync(); isx.take_stats(); torch.cuda.synchronize()
+assert np.array_equal(d.cpu().numpy().astype(np.uint64).reshape(c.n_theta, c.n_phi), 2 * want)
+print("ok", int(want.sum()))
+""" % ROOT
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and r.stdout.startswith("ok"), r.stderr[-2000:]
 
 
 def test_large_ray_indices_bit_exact(isx, orc):
