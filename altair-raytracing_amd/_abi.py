@@ -46,6 +46,7 @@ class Config(C.Structure):
     """isx_config (include/isx.h)."""
 
     _fields_ = [
+        ("struct_size", C.c_uint32), ("reserved0", C.c_uint32),
         ("r_in", C.c_double), ("r_out", C.c_double), ("theta_max_deg", C.c_double),
         ("reflectance", C.c_double), ("roughness_rad", C.c_double), ("box_half", C.c_double),
         ("lambertian", C.c_int32), ("max_points", C.c_int32),

@@ -65,7 +65,11 @@ struct DevBuf {
     }                                                \
   } while (0)
 
+// ABI v3: the caller's struct must be the library's (isx.h: struct_size)
+bool config_abi_ok(const isx_config* c) { return c->struct_size == (uint32_t)sizeof(isx_config); }
+
 int prepare_geom(const isx_config* c, Geom* g) {
+  if (!config_abi_ok(c)) return ISX_ERR_BAD_CONFIG;
   if (!(c->r_in > 0) || !(c->r_out > c->r_in)) return ISX_ERR_BAD_CONFIG;
   if (!(c->theta_max_deg > 90.0) || !(c->theta_max_deg < 180.0)) return ISX_ERR_BAD_CONFIG;
   if (!(c->box_half > c->r_out)) return ISX_ERR_BAD_CONFIG;
@@ -132,6 +136,7 @@ void det_set_position(double theta, double phi, double radius, double portz, dou
 }
 
 int check_grid(const isx_config* c) {
+  if (!config_abi_ok(c)) return ISX_ERR_BAD_CONFIG;
   if (c->n_theta < 1 || c->n_phi < 1) return ISX_ERR_BAD_CONFIG;
   if ((long long)c->n_theta * c->n_phi > 36000) return ISX_ERR_BAD_CONFIG;  // LDS histogram: 4 B/bin
   if (!(c->det_diameter > 0) || !(c->det_distance > 0)) return ISX_ERR_BAD_CONFIG;
@@ -355,6 +360,7 @@ int isx_stream_version(void) { return ISX_STREAM_VERSION; }
 void isx_default_config(isx_config* c) {
   if (!c) return;
   std::memset(c, 0, sizeof(*c));
+  c->struct_size = (uint32_t)sizeof(isx_config);
   // fluxAtObserverOptimize.C:33-41 and sweepSeries() :892-896
   c->r_in = 100.1; c->r_out = 101.0; c->theta_max_deg = 170.0;
   c->reflectance = 0.99; c->roughness_rad = 0.01; c->box_half = 300.0;
@@ -406,7 +412,10 @@ int isx_init(int device) {
   S.device = device;
   S.init = true;
   S.have_tab = false;
-  if (const char* m = std::getenv("ISX_BIN_MODE")) S.bin_mode = std::atoi(m) != 0;
+  if (const char* m = std::getenv("ISX_BIN_MODE")) {
+    const int v = std::atoi(m);
+    if (v >= 0 && v <= 2) S.bin_mode = v;   // same domain as isx_set_option("bin_mode")
+  }
   return ISX_OK;
 }
 
@@ -530,7 +539,7 @@ int isx_mathprobe(int op, const double* a, const double* b, const double* c, dou
 
 int isx_detector_table(const isx_config* cfg, double* out) {
   if (!cfg || !out) return ISX_ERR_BAD_ARG;
-  if (cfg->n_theta < 1 || cfg->n_phi < 1) return ISX_ERR_BAD_CONFIG;
+  if (!config_abi_ok(cfg) || cfg->n_theta < 1 || cfg->n_phi < 1) return ISX_ERR_BAD_CONFIG;
   for (int i = 0; i < cfg->n_theta; ++i) {
     const double theta = (i + 0.5) * 90.0 / cfg->n_theta;
     for (int j = 0; j < cfg->n_phi; ++j) {

@@ -597,13 +597,17 @@ __device__ __forceinline__ void persistent_body(const Geom& g_arg, const DetGrid
     const unsigned long long dead = __ballot(!(run || parked));
     if (dead) {
       if (next < end) {
+        // `left` rays remain in [next, end); only differences are formed, so a range that ends at 2^64-1 cannot wrap
+        // the cursor (next never passes end)
+        const uint64_t left = end - next;
         const uint32_t rank =
             __builtin_amdgcn_mbcnt_hi((uint32_t)(dead >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)dead, 0u));
-        if (!(run || parked)) {
-          const uint64_t id = next + rank;
-          if (id < end) { ray_start(g, r, (uint32_t)(id - range_first)); run = true; }
+        if (!(run || parked) && (uint64_t)rank < left) {
+          ray_start(g, r, (uint32_t)(next - range_first) + rank);
+          run = true;
         }
-        next += (uint64_t)__popcll(dead);
+        const uint64_t take = (uint64_t)__popcll(dead);
+        next += take < left ? take : left;
       }
       if (__ballot(run || parked) == 0ull) break;
     }

@@ -20,6 +20,10 @@
  * function returns 0 or a negative isx_status.  There is NO CPU fallback: if no
  * gfx950 device (or the HIP runtime) is available every compute entry point
  * returns ISX_ERR_NO_DEVICE.
+ *
+ * Process model: the library is a process-wide singleton bound to ONE device by isx_init()
+ * (one process per GPU, as the reference is one process per run); it is not re-entrant and
+ * not thread-safe.  isx_init() with another device ordinal shuts the first binding down.
  */
 #ifndef ISX_H
 #define ISX_H
@@ -30,7 +34,9 @@
 extern "C" {
 #endif
 
-#define ISX_ABI_VERSION 2
+/* 3: isx_config starts with struct_size (a config whose size is not the library's is refused, so a field added by a
+ *    later ABI can never be mis-read silently). */
+#define ISX_ABI_VERSION 3
 /* Results are a pure function of (configuration, seed, ray indices) AND of the random-number layout below; a build with
  * another ISX_STREAM_VERSION gives different (equally valid) histograms for the same seed.
  * 3: Philox4x32-10, counter (ray lo, ray hi, block, stream); interaction j takes words (2(j&1), 2(j&1)+1) of block j/2;
@@ -82,6 +88,9 @@ typedef enum isx_status {
  * Lengths in cm (AOpticsManager::cm() == 1).
  */
 typedef struct isx_config {
+  uint32_t struct_size;  /* sizeof(isx_config) of the caller's ABI; set by isx_default_config().  Every entry
+                            point refuses (ISX_ERR_BAD_CONFIG) a config whose size is not the library's.  */
+  uint32_t reserved0;    /* 0 */
   double r_in;           /* TGeoSphere rmin (100.1)                                   */
   double r_out;          /* TGeoSphere rmax (101)                                     */
   double theta_max_deg;  /* TGeoSphere theta2: shell spans polar angle [0,theta_max]  */

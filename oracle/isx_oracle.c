@@ -661,6 +661,7 @@ int isxo_check_intersection(const double det[6], double width, const double last
 /* ------------------------------------------------------------------------- */
 void isxo_default_config(isxo_config* c) {
   memset(c, 0, sizeof(*c));
+  c->struct_size = (uint32_t)sizeof(*c);
   c->r_in = 100.1; c->r_out = 101.0; c->theta_max_deg = 170.0;
   c->reflectance = 0.99; c->roughness_rad = 0.01; c->box_half = 300.0;
   c->lambertian = 1; c->max_points = 50000;

@@ -25,6 +25,7 @@ extern "C" {
 #endif
 
 typedef struct isxo_config {
+  uint32_t struct_size, reserved0;   /* layout twin of isx_config (ABI v3); not interpreted by the oracle */
   double r_in, r_out, theta_max_deg, reflectance, roughness_rad, box_half;
   int32_t lambertian, max_points;
   double src[3], dir[3];

@@ -33,11 +33,24 @@ def test_library_exports_every_declared_symbol(mod):
 
 
 def test_abi_version_and_struct_layout(mod):
-    assert mod.load().isx_abi_version() == 2
+    assert mod.load().isx_abi_version() == 3
     assert mod.load().isx_stream_version() == 3
-    # isx_config: 6 dbl, 2 i32, 6 dbl, 2 i32, 3 dbl, 2 i32, 3 dbl, 2 i32 ; isx_stats: 7 u64 + dbl
-    assert C.sizeof(mod.Config) == 8 * 6 + 8 + 8 * 6 + 8 + 8 * 3 + 8 + 8 * 3 + 8
+    # isx_config: 2 u32, 6 dbl, 2 i32, 6 dbl, 2 i32, 3 dbl, 2 i32, 3 dbl, 2 i32 ; isx_stats: 7 u64 + dbl
+    assert C.sizeof(mod.Config) == 8 + 8 * 6 + 8 + 8 * 6 + 8 + 8 * 3 + 8 + 8 * 3 + 8
+    assert mod.Config.struct_size.offset == 0
+    assert mod.default_config().struct_size == C.sizeof(mod.Config)
     assert C.sizeof(mod.Stats) == 64
+
+
+def test_config_of_another_abi_is_refused(mod):
+    # ABI v3: a struct whose struct_size is not the library's is refused before anything reads its fields
+    # (no GPU needed: isx_detector_table is host code)
+    c = mod.default_config()
+    out = np.zeros(c.n_theta * c.n_phi * 6)
+    for bad in (0, C.sizeof(mod.Config) - 8, C.sizeof(mod.Config) + 8):
+        c.struct_size = bad
+        rc = mod.load().isx_detector_table(C.byref(c), out.ctypes.data_as(C.POINTER(C.c_double)))
+        assert rc == -2, (bad, rc)
 
 
 def test_default_config_matches_reference_constants(mod, orc):
