@@ -35,6 +35,8 @@ struct State {
   unsigned long long* d_hist = nullptr;
   size_t cap_hist = 0;
   unsigned long long* d_stats = nullptr;  // [8]
+  double* d_aux = nullptr;                // caller-supplied detector / disc lists of the current call (grown, never shrunk)
+  size_t cap_aux = 0;
   // options
   int bin_mode = 1;
   int blocks_per_cu = 1;   // 1024-thread blocks: 16 waves/CU, 4 per SIMD
@@ -269,6 +271,12 @@ int enqueue(int sink, const isx_config* c, uint64_t n, uint64_t seed, uint64_t f
     }
     d.map_first = pp->map_first; d.rays_per_group = pp->rays_per_group; d.fold = pp->fold;
     lds = (((size_t)d.nbins * 4 + 15) & ~(size_t)15) + 64 + sizeof(Geom) + sizeof(DetGrid);
+  } else if (sink == SINK_DISCPOS) {
+    if (!pp || pp->rays_per_group < 1 || nbins_override < 1 || nbins_override > 36000) return ISX_ERR_BAD_ARG;
+    d.nbins = nbins_override;
+    d.discs = d_discs; d.disc_r = disc_r; d.disc_h = disc_h;
+    d.map_first = pp->map_first; d.rays_per_group = pp->rays_per_group; d.fold = 1;
+    lds = (((size_t)d.nbins * 4 + 15) & ~(size_t)15) + 64 + sizeof(Geom) + sizeof(DetGrid);
   } else if (sink == SINK_LOG) {
     if (!lg || !lg->rec || !lg->count) return ISX_ERR_BAD_ARG;
     d.nbins = 1;
@@ -291,11 +299,12 @@ int enqueue(int sink, const isx_config* c, uint64_t n, uint64_t seed, uint64_t f
   Work wk;
   wk.seed = seed; wk.first = first; wk.n = n; wk.hist = d_hist; wk.stats = d_stats ? d_stats : S.d_stats;
   const int grid = pick_grid(n);
-  // a block counts in 32-bit LDS bins and a wave addresses its rays by 32-bit offsets: at most 2^32-1 rays per block
+  // a block counts in 32-bit LDS bins: at most 2^32-1 rays per block; a wave addresses its rays by 31-bit offsets
   if ((n + (uint64_t)grid - 1) / (uint64_t)grid > 0xffffffffull) return ISX_ERR_TOO_LARGE;
+  if (n / ((uint64_t)grid * kWavesPerBlock) >= 0x7fffffffull) return ISX_ERR_TOO_LARGE;
   hipEvent_t e0, e1;
   rc = get_event(&e0); if (rc) return rc;
-  rc = get_event(&e1); if (rc) return rc;
+  rc = get_event(&e1); if (rc) { S.ev_used--; return rc; }   // events are consumed in pairs
   // the lean kernel serves the headline configuration; anything else takes the full-featured variant
   const bool lean_surface = c->lambertian && c->surface_model == ISX_SURFACE_ROBAST && c->hit_line_mode == ISX_HITLINE_LAST_SEGMENT;
   const bool lean = lean_surface && c->source_model == ISX_SOURCE_PENCIL;
@@ -310,6 +319,7 @@ int enqueue(int sink, const isx_config* c, uint64_t n, uint64_t seed, uint64_t f
     case SINK_DZ: fn = lean_explicit ? isx_trace_dz_lean_kernel : isx_trace_dz_kernel; break;
     case SINK_DISC: fn = lean_explicit ? isx_trace_disc_lean_kernel : isx_trace_disc_kernel; break;
     case SINK_PERPOS: fn = lean_explicit ? isx_trace_perpos_lean_kernel : isx_trace_perpos_kernel; break;
+    case SINK_DISCPOS: fn = lean_explicit ? isx_trace_discpos_lean_kernel : isx_trace_discpos_kernel; break;
     default: fn = lean_explicit ? isx_trace_log_lean_kernel : isx_trace_log_kernel; break;
   }
   HIPCHK(hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -317,6 +327,21 @@ int enqueue(int sink, const isx_config* c, uint64_t n, uint64_t seed, uint64_t f
   hipLaunchKernelGGL(fn, dim3(grid), dim3(kBlock), lds, S.stream, g, d, wk);
   HIPCHK(hipGetLastError());
   HIPCHK(hipEventRecord(e1, S.stream));
+  return ISX_OK;
+}
+
+// device copy of a caller's detector / disc list in the pooled buffer (no hipMalloc/hipFree per call)
+int upload_aux(const double* host, size_t n_doubles) {
+  if (n_doubles > S.cap_aux) {
+    HIPCHK(hipStreamSynchronize(S.stream));
+    if (S.d_aux) HIPCHK(hipFree(S.d_aux));
+    S.d_aux = nullptr; S.cap_aux = 0;
+    const size_t cap = n_doubles < 4096 ? 4096 : n_doubles;
+    HIPCHK(hipMalloc(&S.d_aux, cap * sizeof(double)));
+    S.cap_aux = cap;
+  }
+  HIPCHK(hipMemcpyAsync(S.d_aux, host, n_doubles * sizeof(double), hipMemcpyHostToDevice, S.stream));
+  HIPCHK(hipStreamSynchronize(S.stream));   // `host` may be a temporary of the caller
   return ISX_OK;
 }
 
@@ -406,12 +431,14 @@ int isx_init(int device) {
     if (hipDeviceGetAttribute(&v, hipDeviceAttributeMaxSharedMemoryPerBlock, device) == hipSuccess && v > 0) S.lds_limit = (size_t)v;
     if (prop.sharedMemPerBlock > S.lds_limit) S.lds_limit = prop.sharedMemPerBlock;
   }
-  HIPCHK(hipStreamCreateWithFlags(&S.stream, hipStreamNonBlocking));
-  HIPCHK(hipMalloc(&S.d_stats, 8 * sizeof(unsigned long long)));
-  HIPCHK(hipMemset(S.d_stats, 0, 8 * sizeof(unsigned long long)));
+  // from here on a failure releases what was created (isx_shutdown() works on a partially built state)
   S.device = device;
   S.init = true;
   S.have_tab = false;
+  e = hipStreamCreateWithFlags(&S.stream, hipStreamNonBlocking);
+  if (e == hipSuccess) e = hipMalloc(&S.d_stats, 8 * sizeof(unsigned long long));
+  if (e == hipSuccess) e = hipMemset(S.d_stats, 0, 8 * sizeof(unsigned long long));
+  if (e != hipSuccess) { isx_shutdown(); S.last_hip = (int)e; return ISX_ERR_HIP; }
   if (const char* m = std::getenv("ISX_BIN_MODE")) {
     const int v = std::atoi(m);
     if (v >= 0 && v <= 2) S.bin_mode = v;   // same domain as isx_set_option("bin_mode")
@@ -421,7 +448,7 @@ int isx_init(int device) {
 
 void isx_shutdown(void) {
   if (!S.init) return;
-  (void)hipStreamSynchronize(S.stream);
+  if (S.stream) (void)hipStreamSynchronize(S.stream);
   for (hipEvent_t e : S.ev_pool) (void)hipEventDestroy(e);
   S.ev_pool.clear();
   S.ev_used = 0;
@@ -430,10 +457,12 @@ void isx_shutdown(void) {
   if (S.d_coltab) (void)hipFree(S.d_coltab);
   if (S.d_hist) (void)hipFree(S.d_hist);
   if (S.d_stats) (void)hipFree(S.d_stats);
+  if (S.d_aux) (void)hipFree(S.d_aux);
+  S.d_aux = nullptr; S.cap_aux = 0;
   S.d_table = S.d_rowtab = S.d_coltab = nullptr;
   S.d_hist = S.d_stats = nullptr;
   S.cap_bins = S.cap_rows = S.cap_cols = S.cap_hist = 0;
-  (void)hipStreamDestroy(S.stream);
+  if (S.stream) (void)hipStreamDestroy(S.stream);
   S.stream = nullptr;
   S.init = false;
   S.have_tab = false;
@@ -560,18 +589,42 @@ int isx_disc_sweep(const isx_config* cfg, const double* centers_axes, int32_t n_
   if (rc) return rc;
   rc = collect_stats(nullptr);
   if (rc) return rc;
-  double* d_discs = nullptr;
-  HIPCHK(hipMalloc(&d_discs, (size_t)n_disc * 6 * sizeof(double)));
-  hipError_t e = hipMemcpy(d_discs, centers_axes, (size_t)n_disc * 6 * sizeof(double), hipMemcpyHostToDevice);
-  if (e == hipSuccess) e = hipMemsetAsync(S.d_hist, 0, (size_t)n_disc * sizeof(unsigned long long), S.stream);
-  if (e != hipSuccess) { (void)hipFree(d_discs); S.last_hip = (int)e; return ISX_ERR_HIP; }
-  rc = enqueue(SINK_DISC, cfg, n_rays, seed, first_ray, S.d_hist, n_disc, d_discs, radius, half_thick);
+  rc = upload_aux(centers_axes, (size_t)n_disc * 6);
+  if (rc) return rc;
+  HIPCHK(hipMemsetAsync(S.d_hist, 0, (size_t)n_disc * sizeof(unsigned long long), S.stream));
+  rc = enqueue(SINK_DISC, cfg, n_rays, seed, first_ray, S.d_hist, n_disc, S.d_aux, radius, half_thick);
   if (rc == ISX_OK) {
-    e = hipMemcpyAsync(hits, S.d_hist, (size_t)n_disc * sizeof(unsigned long long), hipMemcpyDeviceToHost, S.stream);
+    const hipError_t e = hipMemcpyAsync(hits, S.d_hist, (size_t)n_disc * sizeof(unsigned long long), hipMemcpyDeviceToHost, S.stream);
     if (e != hipSuccess) { S.last_hip = (int)e; rc = ISX_ERR_HIP; }
   }
   const int rc2 = collect_stats(stats);
-  (void)hipFree(d_discs);
+  return rc ? rc : rc2;
+}
+
+int isx_disc_sweep_per_position(const isx_config* cfg, const double* centers_axes, int32_t n_disc, double radius,
+                                double half_thick, uint64_t rays_per_position, uint64_t seed, uint64_t first_ray,
+                                uint64_t* hits, isx_stats* stats) {
+  if (!S.init) return ISX_ERR_NOT_INIT;
+  if (!cfg || !centers_axes || !hits || n_disc < 1 || rays_per_position < 1) return ISX_ERR_BAD_ARG;
+  if (cfg->source_model != ISX_SOURCE_PENCIL) return ISX_ERR_BAD_CONFIG;
+  if (!(radius > 0) || !(half_thick > 0)) return ISX_ERR_BAD_ARG;
+  if ((uint64_t)n_disc > ISX_MAX_RAYS_PER_CALL / rays_per_position) return ISX_ERR_TOO_LARGE;
+  int rc = ensure_hist((size_t)n_disc);
+  if (rc) return rc;
+  rc = collect_stats(nullptr);
+  if (rc) return rc;
+  rc = upload_aux(centers_axes, (size_t)n_disc * 6);
+  if (rc) return rc;
+  HIPCHK(hipMemsetAsync(S.d_hist, 0, (size_t)n_disc * sizeof(unsigned long long), S.stream));
+  PerPos pp;
+  pp.map_first = first_ray; pp.rays_per_group = rays_per_position; pp.fold = 1;
+  rc = enqueue(SINK_DISCPOS, cfg, (uint64_t)n_disc * rays_per_position, seed, first_ray, S.d_hist, n_disc, S.d_aux, radius,
+               half_thick, &pp);
+  if (rc == ISX_OK) {
+    const hipError_t e = hipMemcpyAsync(hits, S.d_hist, (size_t)n_disc * sizeof(unsigned long long), hipMemcpyDeviceToHost, S.stream);
+    if (e != hipSuccess) { S.last_hip = (int)e; rc = ISX_ERR_HIP; }
+  }
+  const int rc2 = collect_stats(stats);
   return rc ? rc : rc2;
 }
 
@@ -608,21 +661,18 @@ int isx_trace_rays_detector(const isx_config* cfg, const double* detector, doubl
   if (rc) return rc;
   rc = collect_stats(nullptr);
   if (rc) return rc;
-  double* d_det = nullptr;
-  HIPCHK(hipMalloc(&d_det, 6 * sizeof(double)));
-  hipError_t e = hipMemcpy(d_det, detector, 6 * sizeof(double), hipMemcpyHostToDevice);
-  if (e == hipSuccess) e = hipMemsetAsync(S.d_hist, 0, sizeof(unsigned long long), S.stream);
-  if (e != hipSuccess) { (void)hipFree(d_det); S.last_hip = (int)e; return ISX_ERR_HIP; }
+  rc = upload_aux(detector, 6);
+  if (rc) return rc;
+  HIPCHK(hipMemsetAsync(S.d_hist, 0, sizeof(unsigned long long), S.stream));
   PerPos pp;
-  pp.map_first = first_ray; pp.rays_per_group = n_rays > 0 ? n_rays : 1; pp.fold = 1; pp.d_table = d_det; pp.width = width;
+  pp.map_first = first_ray; pp.rays_per_group = n_rays > 0 ? n_rays : 1; pp.fold = 1; pp.d_table = S.d_aux; pp.width = width;
   rc = enqueue(SINK_PERPOS, cfg, n_rays, seed, first_ray, S.d_hist, 1, nullptr, 0, 0, &pp);
   unsigned long long h = 0;
   if (rc == ISX_OK) {
-    e = hipMemcpyAsync(&h, S.d_hist, sizeof(h), hipMemcpyDeviceToHost, S.stream);
+    const hipError_t e = hipMemcpyAsync(&h, S.d_hist, sizeof(h), hipMemcpyDeviceToHost, S.stream);
     if (e != hipSuccess) { S.last_hip = (int)e; rc = ISX_ERR_HIP; }
   }
   const int rc2 = collect_stats(stats);
-  (void)hipFree(d_det);
   *hit_count = h;
   return rc ? rc : rc2;
 }
@@ -631,6 +681,9 @@ int isx_exit_directions(const isx_config* cfg, uint64_t n_rays, uint64_t seed, u
                         uint64_t* ray_ids, double* directions, uint64_t* count, isx_stats* stats) {
   if (!S.init) return ISX_ERR_NOT_INIT;
   if (!cfg || !ray_ids || !directions || !count || capacity < 1) return ISX_ERR_BAD_ARG;
+  // no more records than rays, and the 32-byte records of one call must stay addressable (ISX_MAX_LOG_RECORDS)
+  if (capacity > n_rays && n_rays > 0) capacity = n_rays;
+  if (capacity > ISX_MAX_LOG_RECORDS) return ISX_ERR_TOO_LARGE;
   int rc = ensure_hist(1);
   if (rc) return rc;
   rc = collect_stats(nullptr);
@@ -656,12 +709,12 @@ int isx_exit_directions(const isx_config* cfg, uint64_t n_rays, uint64_t seed, u
     if (e != hipSuccess) { S.last_hip = (int)e; rc = ISX_ERR_HIP; }
     else {
       // slots are handed out in completion order: sort by ray index so the log is reproducible
-      std::vector<uint32_t> order(kept);
-      for (uint64_t k = 0; k < kept; ++k) order[k] = (uint32_t)k;
-      auto id_of = [&](uint32_t k) { uint64_t v; std::memcpy(&v, &rec[4 * (size_t)k], 8); return v; };
-      std::sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return id_of(a) < id_of(b); });
-      for (uint64_t k = 0; k < kept; ++k) {
-        const uint32_t o = order[k];
+      std::vector<size_t> order(kept);
+      for (size_t k = 0; k < kept; ++k) order[k] = k;
+      auto id_of = [&](size_t k) { uint64_t v; std::memcpy(&v, &rec[4 * k], 8); return v; };
+      std::sort(order.begin(), order.end(), [&](size_t a, size_t b) { return id_of(a) < id_of(b); });
+      for (size_t k = 0; k < kept; ++k) {
+        const size_t o = order[k];
         ray_ids[k] = id_of(o);
         directions[3 * k] = rec[4 * (size_t)o + 1]; directions[3 * k + 1] = rec[4 * (size_t)o + 2]; directions[3 * k + 2] = rec[4 * (size_t)o + 3];
       }

@@ -197,19 +197,21 @@ __device__ __forceinline__ void circle_point(double u, double& c, double& s) {
   s = fma(c2, s2, c2 * s2);
 }
 __device__ __forceinline__ void sincos_cw(double x, double& s, double& c) {
-  const double INVPIO2 = 6.36619772367581382433e-01;
-  const double PIO2_1 = 1.57079632673412561417e+00;
-  const double PIO2_1T = 6.07710050650619224932e-11;
+  const double INVPIO2 = sconst(6.36619772367581382433e-01);
+  const double PIO2_1 = sconst(1.57079632673412561417e+00);
+  const double PIO2_1T = sconst(6.07710050650619224932e-11);
   const double kd = floor(fma(x, INVPIO2, 0.5));
   double r = fma(-kd, PIO2_1, x);
   r = fma(-kd, PIO2_1T, r);
   quadrant((int)kd, kern_sin(r), kern_cos(r), s, c);
 }
 __device__ __forceinline__ double log_pos(double x) {
-  const double LN2_HI = 6.93147180369123816490e-01, LN2_LO = 1.90821492927058770002e-10;
-  const double Lg1 = 6.666666666666735130e-01, Lg2 = 3.999999999940941908e-01, Lg3 = 2.857142874366239149e-01,
-               Lg4 = 2.222219843214978396e-01, Lg5 = 1.818357216161805012e-01, Lg6 = 1.531383769920937332e-01,
-               Lg7 = 1.479819860511658591e-01;
+  // (sconst: see above -- un-pinned, these 9 literals were hoisted into 18 VGPRs across the whole trace loop of every
+  //  kernel that can reach a Gaussian draw, and the BRDF / full kernels spilled to scratch because of it)
+  const double LN2_HI = sconst(6.93147180369123816490e-01), LN2_LO = sconst(1.90821492927058770002e-10);
+  const double Lg1 = sconst(6.666666666666735130e-01), Lg2 = sconst(3.999999999940941908e-01), Lg3 = sconst(2.857142874366239149e-01),
+               Lg4 = sconst(2.222219843214978396e-01), Lg5 = sconst(1.818357216161805012e-01), Lg6 = sconst(1.531383769920937332e-01),
+               Lg7 = sconst(1.479819860511658591e-01);
   const uint64_t bits = (uint64_t)__double_as_longlong(x);
   int e = (int)(bits >> 52) - 1023;
   const uint64_t mant = bits & 0x000FFFFFFFFFFFFFull;

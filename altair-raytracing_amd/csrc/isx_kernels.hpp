@@ -34,6 +34,8 @@ struct DetGrid {
   // SINK_DISC: physical discs (integratingSphereDetectorSweep.C:145-172); nbins == n_disc
   const double* discs;                  // [n_disc][6] centre, unit axis
   double disc_r, disc_h;
+  // SINK_DISCPOS: the reference's physical-disc loop as it is written (integratingSphereDetectorSweep.C:54-77): disc g
+  // sees only its own rays [map_first + g*rays_per_group, +rays_per_group) -- one launch for all positions.
   // SINK_PERPOS: the reference's per-position maps (fluxAtObserverOptimize.C:542-579): rays
   // [map_first + g*rays_per_group, +rays_per_group) belong to detector group g and are tested
   // against that group's detector(s) only.  fold 1: group g = bin g.  fold 2 ("twofold",
@@ -49,7 +51,7 @@ struct DetGrid {
   uint64_t log_cap;
 };
 
-enum : int { SINK_FLUX = 0, SINK_DZ = 1, SINK_DISC = 2, SINK_PERPOS = 3, SINK_LOG = 4 };
+enum : int { SINK_FLUX = 0, SINK_DZ = 1, SINK_DISC = 2, SINK_PERPOS = 3, SINK_LOG = 4, SINK_DISCPOS = 5 };
 
 struct Work {
   uint64_t seed, first, n;
@@ -388,17 +390,21 @@ __device__ __forceinline__ void hit_line_compat(V3& P, V3& V) {
 struct Ray {
   V3 p, v;
   V3 prev;          // start of the current segment (only kept for SINK_DISC)
-  uint32_t ido;     // ray index relative to the wave's (or launch's) first ray: id = id_base + ido
+  uint32_t ido;     // bits 0..30: ray index relative to the wave's (or launch's) first ray, id = id_base + offset();
+                    // bit 31: set once the ray has been re-scattered (source_model 1) -- Philox stream 2 instead of 0.
+                    // (one register for both: the BRDF kernel sits exactly at the 128-VGPR limit of a 1024-thread block)
   uint32_t j;       // mirror interactions of the current trace; track points = j + 1 (+1 once it left the box)
   int on;
-  int phase;        // 0 primary, 2 scattered (source_model 1)
   bool tgt;         // ISX_TRACE_CHORD: v holds the next wall point T, not a direction
   uint32_t cw[4];   // the Philox block this lane holds (bounce_words; unused with PH_DIRECT)
+  __device__ __forceinline__ uint32_t offset() const { return ido & 0x7fffffffu; }
+  __device__ __forceinline__ uint32_t stream() const { return (ido >> 31) << 1; }   // 0 primary, 2 scattered
+  __device__ __forceinline__ bool scattered() const { return (ido >> 31) != 0u; }
 };
 
 template <class G>
 __device__ __forceinline__ void ray_start(const G& g, Ray& r, uint32_t ido) {
-  r.ido = ido; r.j = 0; r.on = K_NONE; r.phase = 0; r.tgt = false;
+  r.ido = ido; r.j = 0; r.on = K_NONE; r.tgt = false;
   r.p.x = g.src[0]; r.p.y = g.src[1]; r.p.z = g.src[2];
   r.v.x = g.dir0[0]; r.v.y = g.dir0[1]; r.v.z = g.dir0[2];
 }
@@ -408,20 +414,20 @@ __device__ __forceinline__ void ray_start(const G& g, Ray& r, uint32_t ido) {
 // Returns 0 while running, else the end status of the CURRENT trace.
 template <bool KEEP_PREV, bool LEAN, int CH, int PH = PH_DIRECT, class G>
 __device__ __forceinline__ int ray_arrive(const Hot& h, const G& g, Ray& r, uint64_t seed, uint64_t id_base, int kind, const V3& q) {
-  const uint64_t rid = id_base + (uint64_t)r.ido;
+  const uint64_t rid = id_base + (uint64_t)r.offset();
   if (KEEP_PREV) r.prev = r.p;
   r.p = q;
   if (kind == K_BOX) { r.on = K_BOX; return ST_EXITED; }
   r.on = kind;
   bool alive;
   uint32_t wa, wb;
-  bounce_words<PH>(seed, rid, r.j, (uint32_t)r.phase, r.cw, wa, wb);
+  bounce_words<PH>(seed, rid, r.j, r.stream(), r.cw, wa, wb);
   const bool eligible = (kind == K_INNER) && (LEAN || (h.lambertian && h.surface_model == 0));
   if (CH != 0 && eligible && (CH == 1 || h.chord)) {
     alive = interact_chord(h, r.v, wa, wb);
     r.tgt = alive;
   } else {
-    alive = interact<LEAN>(h, g, kind, q, r.v, seed, rid, r.j, (uint32_t)r.phase, wa, wb);
+    alive = interact<LEAN>(h, g, kind, q, r.v, seed, rid, r.j, r.stream(), wa, wb);
   }
   r.j++;
   if (!alive) return ST_ABSORBED;
@@ -455,13 +461,16 @@ __device__ __forceinline__ int ray_step(const Hot& h, const G& g, Ray& r, uint64
 // nonLambertianFlux.C:253-268: restart from the primary's last point along a BRDF-sampled direction
 template <class G>
 __device__ __forceinline__ void ray_rescatter(const G& g, Ray& r, uint64_t seed, uint64_t id_base) {
+  // the held Philox block belongs to the finished primary trace: dead from here on (the scattered trace starts at j = 0,
+  // whose even step draws its own block); saying so frees four VGPRs across brdf_sample
+  r.cw[0] = r.cw[1] = r.cw[2] = r.cw[3] = 0u;
   V3 d0; d0.x = g.dir0[0]; d0.y = g.dir0[1]; d0.z = g.dir0[2];
   const V3 normal = tv_unit(r.p);
-  const V3 nd = brdf_sample(g, normal, d0, seed, id_base + (uint64_t)r.ido);
+  const V3 nd = brdf_sample(g, normal, d0, seed, id_base + (uint64_t)r.offset());
   const double mag = sqrt(nd.x * nd.x + nd.y * nd.y + nd.z * nd.z);
   r.v.x = nd.x / mag; r.v.y = nd.y / mag; r.v.z = nd.z / mag;
   r.on = (r.on == K_BOX) ? K_NONE : r.on;
-  r.j = 0; r.phase = 2; r.tgt = false;
+  r.j = 0; r.ido |= 0x80000000u; r.tgt = false;
 }
 
 // ------------------------------------------------------------------ physical disc test (SINK_DISC)
@@ -624,7 +633,7 @@ __device__ __forceinline__ void persistent_body(const Geom& g_arg, const DetGrid
     static_assert(!kShare || (kStepsPerTrip % 2) == 0, "block sharing needs an even number of steps per trip");
     auto arrive = [&](int kind, const V3& q, auto ph) {
       constexpr int PH = kShare ? decltype(ph)::value : PH_DIRECT;
-      const int st = ray_arrive<SINK == SINK_DISC, LEAN, CH, PH>(h, g, r, seed, range_first, kind, q);
+      const int st = ray_arrive<SINK == SINK_DISC || SINK == SINK_DISCPOS, LEAN, CH, PH>(h, g, r, seed, range_first, kind, q);
       if (st != 0) { run = false; pend = st; }   // census / re-scatter once per trip (below), not per bounce
     };
     // hot boundary search of one lane: true if it arrived on the inner mirror patch, else the lane parks
@@ -667,7 +676,7 @@ __device__ __forceinline__ void persistent_body(const Geom& g_arg, const DetGrid
     });
     // ---- census of the rays that ended in this trip (a dead lane stays dead until the next refill, so each ended
     // ray is seen exactly once, with its final point and direction still in place)
-    if (RESC && pend != 0 && h.source_model == 1 && r.phase == 0) {
+    if (RESC && pend != 0 && h.source_model == 1 && !r.scattered()) {
       // nonLambertianFlux.C:253-268: the primary trace is over (whatever its status); the ray restarts from its last
       // point along a BRDF-sampled direction.  One copy of this code per trip instead of one per bounce.
       n_wall += r.j;
@@ -682,7 +691,7 @@ __device__ __forceinline__ void persistent_body(const Geom& g_arg, const DetGrid
         n_wall += r.j;
         if (n_wall > 0x7fffffffu) { atomicAdd(&sstat[6], (unsigned long long)n_wall); n_wall = 0; }
       }
-      bin_me = (SINK == SINK_DISC) ? exited : below;
+      bin_me = (SINK == SINK_DISC || SINK == SINK_DISCPOS) ? exited : below;
       const unsigned long long me = __ballot(ended);
       if (me) {
         n_ended += (uint32_t)__popcll(me);
@@ -705,7 +714,7 @@ __device__ __forceinline__ void persistent_body(const Geom& g_arg, const DetGrid
           const unsigned long long slot = base + rank;
           if (slot < d_arg.log_cap) {
             double4 rec;
-            rec.x = __longlong_as_double((long long)(range_first + (uint64_t)r.ido)); rec.y = r.v.x; rec.z = r.v.y; rec.w = r.v.z;
+            rec.x = __longlong_as_double((long long)(range_first + (uint64_t)r.offset())); rec.y = r.v.x; rec.z = r.v.y; rec.w = r.v.z;
             reinterpret_cast<double4*>(d_arg.log_rec)[slot] = rec;
           }
         }
@@ -721,7 +730,7 @@ __device__ __forceinline__ void persistent_body(const Geom& g_arg, const DetGrid
         const double half_w2 = d.half_w2;
         V3 lp = r.p, lv = r.v;
         if (d.hit_line_mode == 1) hit_line_compat(lp, lv);
-        const uint64_t rel = (range_first + (uint64_t)r.ido) - map_first;
+        const uint64_t rel = (range_first + (uint64_t)r.offset()) - map_first;
         uint64_t grp = (uint64_t)((double)rel / (double)rpg);
         if (grp * rpg > rel) grp--;
         else if ((grp + 1) * rpg <= rel) grp++;
@@ -738,6 +747,22 @@ __device__ __forceinline__ void persistent_body(const Geom& g_arg, const DetGrid
       }
       if (hit0) atomicAdd(&hist[b0], 1u);
       if (hit1) atomicAdd(&hist[b1], 1u);
+    } else if (SINK == SINK_DISCPOS) {
+      // per-lane: the forward exit segment against the ray's own disc only
+      bool hit = false;
+      int b = 0;
+      if (bin_me) {
+        const uint64_t map_first = d.map_first, rpg = d.rays_per_group;
+        const uint64_t rel = (range_first + (uint64_t)r.offset()) - map_first;
+        uint64_t grp = (uint64_t)((double)rel / (double)rpg);
+        if (grp * rpg > rel) grp--;
+        else if ((grp + 1) * rpg <= rel) grp++;
+        b = (int)grp;
+        V3 dl; dl.x = r.p.x - r.prev.x; dl.y = r.p.y - r.prev.y; dl.z = r.p.z - r.prev.z;
+        const double tmax = dot3(dl, r.v);
+        hit = segment_hits_tube(r.prev, r.v, tmax, d.discs + 6 * (size_t)b, d.disc_r, d.disc_h);
+      }
+      if (hit) atomicAdd(&hist[b], 1u);
     } else if (SINK == SINK_DZ) {
       // per-lane: TH1D(nbins,-1,1)->Fill(dz)
       bool hit = false;
@@ -762,11 +787,15 @@ __device__ __forceinline__ void persistent_body(const Geom& g_arg, const DetGrid
         // (offsets from `smem`, not pointer-to-integer casts: the accesses must stay ds_read/ds_write with 32-bit addresses)
         const uint32_t off_rec = ((uint32_t)(reinterpret_cast<unsigned char*>(d_lds + 1) - smem) + 15u) & ~15u;
         float4* base = reinterpret_cast<float4*>(smem + off_rec);
-        rec4 = base + (tid >> 6) * 64;
-        reci = reinterpret_cast<int*>(base + kWavesPerBlock * 64) + (tid >> 6) * 64;
+        // (the wave's slot is re-derived here, behind a compiler barrier, and portz re-read from the LDS copy: hoisted out of
+        //  the trace loop these two loop invariants cost the BRDF kernel two VGPRs it does not have -> 12 B/lane of scratch)
+        uint32_t wslot = (uint32_t)tid >> 6;
+        asm volatile("" : "+v"(wslot));
+        rec4 = base + wslot * 64u;
+        reci = reinterpret_cast<int*>(base + kWavesPerBlock * 64) + wslot * 64u;
         if (bin_me) {   // the exiting lanes prepare their own lines, all at once, and park the result in LDS
           GridConst k;
-          k.Rf = (float)d.R; k.rho = (float)d.rho_d; k.portz = (float)portz; k.n_theta = d.n_theta;
+          k.Rf = (float)d.R; k.rho = (float)d.rho_d; k.portz = (float)d.portz; k.n_theta = d.n_theta;
           k.inv_dphi = (float)d.n_phi * 0.15915494309f;
           k.inv_dth = (float)k.n_theta * 0.63661977237f;
           const RecPre pre = prep_record(k, r.p, r.v);
@@ -851,6 +880,10 @@ isx_trace_disc_kernel(const Geom g, const DetGrid d, const Work wk) { persistent
 extern "C" __global__ void ISX_KERNEL_ATTR
 isx_trace_disc_lean_kernel(const Geom g, const DetGrid d, const Work wk) { persistent_body<SINK_DISC, true, 0>(g, d, wk); }
 extern "C" __global__ void ISX_KERNEL_ATTR
+isx_trace_discpos_kernel(const Geom g, const DetGrid d, const Work wk) { persistent_body<SINK_DISCPOS>(g, d, wk); }
+extern "C" __global__ void ISX_KERNEL_ATTR
+isx_trace_discpos_lean_kernel(const Geom g, const DetGrid d, const Work wk) { persistent_body<SINK_DISCPOS, true, 0>(g, d, wk); }
+extern "C" __global__ void ISX_KERNEL_ATTR
 isx_trace_perpos_kernel(const Geom g, const DetGrid d, const Work wk) { persistent_body<SINK_PERPOS>(g, d, wk); }
 // the reference's main sweep (per-position maps) in the headline configuration: lean trace, one exact test per exiting ray
 extern "C" __global__ void ISX_KERNEL_ATTR
@@ -872,7 +905,7 @@ isx_endstates_kernel(const Geom g, uint64_t seed, uint64_t first, uint64_t n, in
   int st;
   for (;;) {
     st = ray_step<false>(h, g, r, seed, first);
-    if (st != 0 && h.source_model == 1 && r.phase == 0) { ray_rescatter(g, r, seed, first); st = 0; }
+    if (st != 0 && h.source_model == 1 && !r.scattered()) { ray_rescatter(g, r, seed, first); st = 0; }
     if (st != 0) break;
   }
   status[i] = st;

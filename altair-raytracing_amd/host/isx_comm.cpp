@@ -1,6 +1,8 @@
-// isx_comm.cpp — see isx_comm.hpp.  RCCL (librccl, the ROCm build of NCCL) + a file rendezvous for the unique id.
+// isx_comm.cpp — see isx_comm.hpp.  RCCL (librccl, the ROCm build of NCCL) + a per-job rendezvous directory.
 #include "isx_comm.hpp"
 
+#include <dirent.h>
+#include <fcntl.h>
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h>
 #include <sys/stat.h>
@@ -27,21 +29,6 @@ int env_int(std::initializer_list<const char*> names, int dflt) {
   return dflt;
 }
 
-struct Rccl {
-  bool ready = false, failed = false;
-  ncclComm_t comm = nullptr;
-  hipStream_t stream = nullptr;
-  unsigned long long* d_buf = nullptr;
-  size_t cap = 0;
-} R;
-
-std::string rendezvous_path() {
-  if (const char* s = std::getenv("ISX_RENDEZVOUS")) return s;
-  std::string tag = "default";
-  if (const char* s = std::getenv("MASTER_PORT")) tag = s;
-  return "/tmp/isx_rccl_" + tag + "_" + std::to_string((long)getuid());
-}
-
 #define ISX_HIP_OK(call)                                                                                        \
   do {                                                                                                          \
     const hipError_t e_ = (call);                                                                               \
@@ -59,56 +46,214 @@ std::string rendezvous_path() {
     }                                                                                                           \
   } while (0)
 
+// ------------------------------------------------------------------------------------------------ rendezvous
+// One directory per job, private to the user: <ISX_RENDEZVOUS | $XDG_RUNTIME_DIR | $TMPDIR | /tmp>/isx_rdzv_<uid>_<job>.
+// <job> is the per-launch nonce: ISX_JOB_ID, else torchrun's TORCHELASTIC_RUN_ID + MASTER_PORT.  A multi-rank launch
+// without any of them is refused (two jobs would share one directory).  Files: `id` = magic | job tag | ncclUniqueId,
+// created with O_EXCL, mode 0600, published by rename; `ready.<rank>` / `fail.<rank>` = the pre-flight of rccl_init().
+constexpr char kMagic[8] = {'I', 'S', 'X', 'R', 'D', 'Z', 'V', '2'};
+constexpr size_t kTagLen = 96;
+constexpr int kWaitSeconds = 120;
+
+bool job_tag(std::string& tag) {
+  if (const char* s = std::getenv("ISX_JOB_ID")) { tag = s; return !tag.empty(); }
+  std::string t;
+  if (const char* s = std::getenv("TORCHELASTIC_RUN_ID")) t += s;
+  if (const char* s = std::getenv("MASTER_PORT")) t += std::string("_") + s;
+  tag = t;
+  return !tag.empty();
+}
+
+std::string sanitize(std::string s) {
+  for (char& ch : s)
+    if (!((ch >= 'a' && ch <= 'z') || (ch >= 'A' && ch <= 'Z') || (ch >= '0' && ch <= '9') || ch == '-' || ch == '.')) ch = '_';
+  if (s.size() > 64) s.resize(64);
+  return s;
+}
+
+bool rendezvous_dir(const Comm& c, std::string& dir, std::string& tag) {
+  if (!job_tag(tag)) {
+    if (c.world > 1) {
+      std::cerr << "Error: isx_comm: a multi-rank launch needs a per-job nonce: set ISX_JOB_ID (or launch through torchrun, "
+                   "which exports TORCHELASTIC_RUN_ID / MASTER_PORT)" << std::endl;
+      return false;
+    }
+    tag = "single_" + std::to_string((long)getpid());
+  }
+  std::string base;
+  if (const char* s = std::getenv("ISX_RENDEZVOUS")) base = s;
+  else if (const char* s = std::getenv("XDG_RUNTIME_DIR")) base = s;
+  else if (const char* s = std::getenv("TMPDIR")) base = s;
+  else base = "/tmp";
+  dir = base + "/isx_rdzv_" + std::to_string((long)getuid()) + "_" + sanitize(tag);
+  if (mkdir(dir.c_str(), 0700) != 0 && errno != EEXIST) {
+    std::cerr << "Error: isx_comm: cannot create rendezvous directory " << dir << std::endl;
+    return false;
+  }
+  struct stat sb;
+  if (lstat(dir.c_str(), &sb) != 0 || !S_ISDIR(sb.st_mode) || sb.st_uid != getuid() || (sb.st_mode & 077) != 0) {
+    std::cerr << "Error: isx_comm: rendezvous directory " << dir << " is not a private directory of this user" << std::endl;
+    return false;
+  }
+  return true;
+}
+
+// publish `bytes` as dir/name atomically (O_EXCL temp file, mode 0600, rename)
+bool publish(const std::string& dir, const std::string& name, const void* bytes, size_t n) {
+  const std::string tmp = dir + "/." + name + ".tmp." + std::to_string((long)getpid());
+  (void)unlink(tmp.c_str());
+  const int fd = open(tmp.c_str(), O_WRONLY | O_CREAT | O_EXCL, 0600);
+  if (fd < 0) return false;
+  const bool ok = n == 0 || write(fd, bytes, n) == (ssize_t)n;
+  close(fd);
+  if (!ok || std::rename(tmp.c_str(), (dir + "/" + name).c_str()) != 0) { (void)unlink(tmp.c_str()); return false; }
+  return true;
+}
+
+// a file of THIS launch: owned by us and not older than the launch skew we tolerate
+bool fresh(const std::string& path, std::time_t started, struct stat* sb) {
+  return stat(path.c_str(), sb) == 0 && sb->st_uid == getuid() && sb->st_mtime + kWaitSeconds >= started;
+}
+
+struct Rccl {
+  bool ready = false, failed = false;
+  ncclComm_t comm = nullptr;
+  hipStream_t stream = nullptr;
+  unsigned long long* d_buf = nullptr;
+  size_t cap = 0;
+} R;
+
 bool rccl_init(const Comm& c) {
   if (R.ready) return true;
   if (R.failed) return false;
   R.failed = true;  // until proven otherwise
-  if (!ensure_device()) return false;   // libisx has bound this process to its GPU (same HIP runtime)
-  ncclUniqueId id;
-  const std::string path = rendezvous_path();
+  std::string dir, tag;
+  if (!rendezvous_dir(c, dir, tag)) return false;
   const std::time_t started = std::time(nullptr);
+  // ---- pre-flight: a rank whose GPU cannot be bound says so in the directory, so that nobody enters
+  // ncclCommInitRank (which has no time-out) for a job that cannot start
+  const bool dev_ok = ensure_device();   // libisx has bound this process to its GPU (same HIP runtime)
+  const std::string me = std::to_string(c.rank);
+  if (!publish(dir, (dev_ok ? "ready." : "fail.") + me, nullptr, 0)) {
+    std::cerr << "Error: isx_comm: cannot write into " << dir << std::endl;
+    return false;
+  }
+  bool all_ready = false, someone_failed = !dev_ok;
+  for (int tries = 0; tries < kWaitSeconds * 20 && !all_ready && !someone_failed; ++tries) {
+    int n_ready = 0;
+    for (int r = 0; r < c.world; ++r) {
+      struct stat sb;
+      if (fresh(dir + "/fail." + std::to_string(r), started, &sb)) someone_failed = true;
+      else if (fresh(dir + "/ready." + std::to_string(r), started, &sb)) n_ready++;
+    }
+    all_ready = n_ready == c.world;
+    if (!all_ready && !someone_failed) std::this_thread::sleep_for(std::chrono::milliseconds(50));
+  }
+  if (!all_ready) {
+    std::cerr << "Error: isx_comm: rank " << c.rank << ": " << (someone_failed ? "a rank could not bind its GPU" : "not every rank showed up")
+              << " (rendezvous " << dir << "); not starting the job" << std::endl;
+    return false;
+  }
+  // ---- the ncclUniqueId
+  ncclUniqueId id;
+  unsigned char blob[sizeof(kMagic) + kTagLen + sizeof(id)];
   if (c.rank == 0) {
     ISX_NCCL_OK(ncclGetUniqueId(&id));
-    const std::string tmp = path + ".tmp." + std::to_string((long)getpid());
-    FILE* f = std::fopen(tmp.c_str(), "wb");
-    if (!f || std::fwrite(&id, 1, sizeof(id), f) != sizeof(id)) {
-      std::cerr << "Error: isx_comm: cannot write rendezvous file " << tmp << std::endl;
-      if (f) std::fclose(f);
-      return false;
-    }
-    std::fclose(f);
-    if (std::rename(tmp.c_str(), path.c_str()) != 0) {
-      std::cerr << "Error: isx_comm: cannot publish rendezvous file " << path << std::endl;
+    std::memset(blob, 0, sizeof(blob));
+    std::memcpy(blob, kMagic, sizeof(kMagic));
+    std::strncpy((char*)blob + sizeof(kMagic), tag.c_str(), kTagLen - 1);
+    std::memcpy(blob + sizeof(kMagic) + kTagLen, &id, sizeof(id));
+    (void)unlink((dir + "/id").c_str());   // nothing of an earlier launch survives
+    if (!publish(dir, "id", blob, sizeof(blob))) {
+      std::cerr << "Error: isx_comm: cannot publish " << dir << "/id" << std::endl;
       return false;
     }
   } else {
     bool got = false;
-    for (int tries = 0; tries < 2400 && !got; ++tries) {   // 120 s
+    for (int tries = 0; tries < kWaitSeconds * 20 && !got; ++tries) {
       struct stat sb;
-      // a file left behind by an earlier job is older than this process by more than the launch skew we tolerate
-      if (stat(path.c_str(), &sb) == 0 && sb.st_size == (off_t)sizeof(id) && sb.st_mtime + 120 >= started) {
-        FILE* f = std::fopen(path.c_str(), "rb");
+      if (fresh(dir + "/id", started, &sb) && sb.st_size == (off_t)sizeof(blob)) {
+        FILE* f = std::fopen((dir + "/id").c_str(), "rb");
         if (f) {
-          got = std::fread(&id, 1, sizeof(id), f) == sizeof(id);
+          got = std::fread(blob, 1, sizeof(blob), f) == sizeof(blob) && std::memcmp(blob, kMagic, sizeof(kMagic)) == 0 &&
+                std::strncmp((const char*)blob + sizeof(kMagic), tag.c_str(), kTagLen - 1) == 0;
           std::fclose(f);
         }
       }
       if (!got) std::this_thread::sleep_for(std::chrono::milliseconds(50));
     }
     if (!got) {
-      std::cerr << "Error: isx_comm: rank " << c.rank << " found no rendezvous file " << path << " within 120 s" << std::endl;
+      std::cerr << "Error: isx_comm: rank " << c.rank << " found no id of job '" << tag << "' in " << dir << " within " << kWaitSeconds
+                << " s" << std::endl;
       return false;
     }
+    std::memcpy(&id, blob + sizeof(kMagic) + kTagLen, sizeof(id));
   }
   ISX_NCCL_OK(ncclCommInitRank(&R.comm, c.world, id, c.rank));   // returns once every rank has joined
-  if (c.rank == 0) std::remove(path.c_str());
+  (void)unlink((dir + "/ready." + me).c_str());
+  if (c.rank == 0) { (void)unlink((dir + "/id").c_str()); (void)rmdir(dir.c_str()); }   // rmdir succeeds once the last rank has cleaned up
+  else (void)rmdir(dir.c_str());
   ISX_HIP_OK(hipStreamCreateWithFlags(&R.stream, hipStreamNonBlocking));
   R.failed = false;
   R.ready = true;
   return true;
 }
 
+// RCCL transport: one staging buffer on the device, three in-place all-reduces on one stream, one synchronisation
+struct RcclTransport : Transport {
+  bool exchange(unsigned long long* buf, size_t n_sum, size_t n_max, size_t n_min) override {
+    const size_t total = n_sum + n_max + n_min;
+    if (total > R.cap) {
+      if (R.d_buf) ISX_HIP_OK(hipFree(R.d_buf));
+      R.d_buf = nullptr; R.cap = 0;
+      ISX_HIP_OK(hipMalloc(&R.d_buf, total * sizeof(unsigned long long)));
+      R.cap = total;
+    }
+    ISX_HIP_OK(hipMemcpyAsync(R.d_buf, buf, total * sizeof(unsigned long long), hipMemcpyHostToDevice, R.stream));
+    if (n_sum) ISX_NCCL_OK(ncclAllReduce(R.d_buf, R.d_buf, n_sum, ncclUint64, ncclSum, R.comm, R.stream));
+    if (n_max) ISX_NCCL_OK(ncclAllReduce(R.d_buf + n_sum, R.d_buf + n_sum, n_max, ncclUint64, ncclMax, R.comm, R.stream));
+    if (n_min) ISX_NCCL_OK(ncclAllReduce(R.d_buf + n_sum + n_max, R.d_buf + n_sum + n_max, n_min, ncclInt64, ncclMin, R.comm, R.stream));
+    ISX_HIP_OK(hipMemcpyAsync(buf, R.d_buf, total * sizeof(unsigned long long), hipMemcpyDeviceToHost, R.stream));
+    ISX_HIP_OK(hipStreamSynchronize(R.stream));
+    return true;
+  }
+} g_rccl;
+
+Transport* g_transport_override = nullptr;
+
 }  // namespace
+
+// ------------------------------------------------------------------------------------------------ the collective
+// Every rank calls this exactly once per trace call, WHATEVER its local status: the status travels with the data
+// (MIN over ranks: ISX_OK = 0, errors are negative), so either every rank gets the reduced result or every rank gets
+// the same error -- no rank is left waiting in a collective the others never enter.
+int reduce_collective(Transport& t, int local_rc, uint64_t* hits, size_t count, isx_stats* st, int n_stats) {
+  const size_t ns = st ? (size_t)n_stats : 0;
+  const size_t n_sum = count + 7 * ns, n_max = ns, n_min = 1;
+  std::vector<unsigned long long> h(n_sum + n_max + n_min, 0ull);
+  if (local_rc == ISX_OK) {
+    std::memcpy(h.data(), hits, count * sizeof(uint64_t));
+    for (size_t k = 0; k < ns; ++k) {
+      unsigned long long* c = h.data() + count + 7 * k;
+      c[0] = st[k].launched; c[1] = st[k].exited; c[2] = st[k].counted_below_z; c[3] = st[k].absorbed;
+      c[4] = st[k].suspended; c[5] = st[k].bin_increments; c[6] = st[k].wall_hits;
+      h[n_sum + k] = (unsigned long long)(st[k].t_kernel_ms * 1e3 + 0.5);
+    }
+  }
+  long long status = (long long)local_rc;
+  std::memcpy(&h[n_sum + n_max], &status, sizeof(status));
+  if (!t.exchange(h.data(), n_sum, n_max, n_min)) return local_rc != ISX_OK ? local_rc : ISX_ERR_HIP;
+  std::memcpy(&status, &h[n_sum + n_max], sizeof(status));
+  if (status != ISX_OK) return (int)status;
+  std::memcpy(hits, h.data(), count * sizeof(uint64_t));
+  for (size_t k = 0; k < ns; ++k) {
+    const unsigned long long* c = h.data() + count + 7 * k;
+    st[k].launched = c[0]; st[k].exited = c[1]; st[k].counted_below_z = c[2]; st[k].absorbed = c[3];
+    st[k].suspended = c[4]; st[k].bin_increments = c[5]; st[k].wall_hits = c[6];
+    st[k].t_kernel_ms = (double)h[n_sum + k] * 1e-3;
+  }
+  return ISX_OK;
+}
 
 Comm& comm() {
   static Comm c = [] {
@@ -134,38 +279,19 @@ void Comm::shard(uint64_t n, uint64_t& first, uint64_t& count) const {
   count = q + (k < r ? 1 : 0);
 }
 
-bool Comm::reduce(uint64_t* hits, size_t count, isx_stats* st, int n_stats) {
-  if (!active()) return true;
-  if (!rccl_init(*this)) return false;
-  const size_t ns = st ? (size_t)n_stats : 0;
-  const size_t words = count + 7 * ns, total = words + ns;   // [hits | 7 census words per stats | kernel microseconds per stats]
-  if (total > R.cap) {
-    if (R.d_buf) ISX_HIP_OK(hipFree(R.d_buf));
-    R.d_buf = nullptr; R.cap = 0;
-    ISX_HIP_OK(hipMalloc(&R.d_buf, total * sizeof(unsigned long long)));
-    R.cap = total;
-  }
-  std::vector<unsigned long long> h(total);
-  std::memcpy(h.data(), hits, count * sizeof(uint64_t));
-  for (size_t k = 0; k < ns; ++k) {
-    unsigned long long* c = h.data() + count + 7 * k;
-    c[0] = st[k].launched; c[1] = st[k].exited; c[2] = st[k].counted_below_z; c[3] = st[k].absorbed;
-    c[4] = st[k].suspended; c[5] = st[k].bin_increments; c[6] = st[k].wall_hits;
-    h[words + k] = (unsigned long long)(st[k].t_kernel_ms * 1e3 + 0.5);
-  }
-  ISX_HIP_OK(hipMemcpyAsync(R.d_buf, h.data(), total * sizeof(unsigned long long), hipMemcpyHostToDevice, R.stream));
-  ISX_NCCL_OK(ncclAllReduce(R.d_buf, R.d_buf, words, ncclUint64, ncclSum, R.comm, R.stream));
-  if (ns) ISX_NCCL_OK(ncclAllReduce(R.d_buf + words, R.d_buf + words, ns, ncclUint64, ncclMax, R.comm, R.stream));
-  ISX_HIP_OK(hipMemcpyAsync(h.data(), R.d_buf, total * sizeof(unsigned long long), hipMemcpyDeviceToHost, R.stream));
-  ISX_HIP_OK(hipStreamSynchronize(R.stream));
-  std::memcpy(hits, h.data(), count * sizeof(uint64_t));
-  for (size_t k = 0; k < ns; ++k) {
-    const unsigned long long* c = h.data() + count + 7 * k;
-    st[k].launched = c[0]; st[k].exited = c[1]; st[k].counted_below_z = c[2]; st[k].absorbed = c[3];
-    st[k].suspended = c[4]; st[k].bin_increments = c[5]; st[k].wall_hits = c[6];
-    st[k].t_kernel_ms = (double)h[words + k] * 1e-3;
-  }
-  return true;
+void Comm::set_transport_for_tests(Transport* t) { g_transport_override = t; }
+
+int Comm::reduce(int local_rc, uint64_t* hits, size_t count, isx_stats* st, int n_stats) {
+  if (!active()) return local_rc;
+  if (g_transport_override) return reduce_collective(*g_transport_override, local_rc, hits, count, st, n_stats);
+  if (!rccl_init(*this)) return local_rc != ISX_OK ? local_rc : ISX_ERR_HIP;
+  return reduce_collective(g_rccl, local_rc, hits, count, st, n_stats);
+}
+
+bool Comm::agree(bool local_ok) {
+  if (!active()) return local_ok;
+  uint64_t none = 0;
+  return reduce(local_ok ? ISX_OK : ISX_ERR_BAD_ARG, &none, 0, nullptr, 0) == ISX_OK;
 }
 
 void Comm::finalize() {
@@ -181,17 +307,17 @@ void Comm::finalize() {
 std::string outputPath(const std::string& base) { return comm().writer() ? getUniqueFilename(base) : std::string("/dev/null"); }
 
 // ---------------------------------------------------------------------------------------------
+// Sharded equivalents of the ABI calls: this rank's share, then ONE collective that also carries the status.
 int fluxmap_all(const isx_config* cfg, uint64_t n_rays, uint64_t seed, uint64_t first_ray, uint64_t* hits, isx_stats* st) {
   Comm& c = comm();
   if (!c.active()) return isx_fluxmap(cfg, n_rays, seed, first_ray, hits, st);
   uint64_t f, cnt;
   c.shard(n_rays, f, cnt);
-  isx_stats local;
-  const int rc = isx_fluxmap(cfg, cnt, seed, first_ray + f, hits, &local);
-  if (rc != ISX_OK) return rc;
-  if (!c.reduce(hits, (size_t)cfg->n_theta * cfg->n_phi, &local)) return ISX_ERR_HIP;
-  if (st) *st = local;
-  return ISX_OK;
+  isx_stats local{};
+  int rc = isx_fluxmap(cfg, cnt, seed, first_ray + f, hits, &local);
+  rc = c.reduce(rc, hits, (size_t)cfg->n_theta * cfg->n_phi, &local);
+  if (rc == ISX_OK && st) *st = local;
+  return rc;
 }
 
 int fluxmap_per_position_all(const isx_config* cfg, uint64_t rays_per_position, int32_t fold, uint64_t n_groups, uint64_t seed,
@@ -200,30 +326,28 @@ int fluxmap_per_position_all(const isx_config* cfg, uint64_t rays_per_position, 
   if (!c.active()) return isx_fluxmap_per_position(cfg, rays_per_position, fold, 0, n_groups, seed, first_ray, hits, st);
   uint64_t g0, ng;
   c.shard(n_groups, g0, ng);   // whole detector groups per rank: group g keeps its rays [first_ray + g*rays_per_position, ...)
-  isx_stats local;
-  const int rc = isx_fluxmap_per_position(cfg, rays_per_position, fold, g0, ng, seed, first_ray, hits, &local);
-  if (rc != ISX_OK) return rc;
-  if (!c.reduce(hits, (size_t)cfg->n_theta * cfg->n_phi, &local)) return ISX_ERR_HIP;
-  if (st) *st = local;
-  return ISX_OK;
+  isx_stats local{};
+  int rc = isx_fluxmap_per_position(cfg, rays_per_position, fold, g0, ng, seed, first_ray, hits, &local);
+  rc = c.reduce(rc, hits, (size_t)cfg->n_theta * cfg->n_phi, &local);
+  if (rc == ISX_OK && st) *st = local;
+  return rc;
 }
 
 int fluxmap_series_all(const isx_config* cfgs, int32_t n_cfg, uint64_t n_rays, uint64_t seed, uint64_t first_ray, uint64_t* hits,
                        isx_stats* st) {
   Comm& c = comm();
   if (!c.active()) return isx_fluxmap_series(cfgs, n_cfg, n_rays, seed, first_ray, hits, st);
-  if (n_cfg < 1) return ISX_ERR_BAD_ARG;
+  if (n_cfg < 1) return ISX_ERR_BAD_ARG;   // the same on every rank: no collective needed
   const size_t nb = (size_t)cfgs[0].n_theta * cfgs[0].n_phi;
   uint64_t f, cnt;
   c.shard(n_rays, f, cnt);
   std::vector<isx_stats> local((size_t)n_cfg);
-  for (int32_t k = 0; k < n_cfg; ++k) {   // configuration k owns the ray indices [first_ray + k*n_rays, +n_rays)
-    const int rc = isx_fluxmap(&cfgs[k], cnt, seed, first_ray + (uint64_t)k * n_rays + f, hits + (size_t)k * nb, &local[(size_t)k]);
-    if (rc != ISX_OK) return rc;
-  }
-  if (!c.reduce(hits, nb * (size_t)n_cfg, local.data(), n_cfg)) return ISX_ERR_HIP;
-  if (st) for (int32_t k = 0; k < n_cfg; ++k) st[k] = local[(size_t)k];
-  return ISX_OK;
+  int rc = ISX_OK;
+  for (int32_t k = 0; k < n_cfg && rc == ISX_OK; ++k)   // configuration k owns the ray indices [first_ray + k*n_rays, +n_rays)
+    rc = isx_fluxmap(&cfgs[k], cnt, seed, first_ray + (uint64_t)k * n_rays + f, hits + (size_t)k * nb, &local[(size_t)k]);
+  rc = c.reduce(rc, hits, nb * (size_t)n_cfg, local.data(), n_cfg);
+  if (rc == ISX_OK && st) for (int32_t k = 0; k < n_cfg; ++k) st[k] = local[(size_t)k];
+  return rc;
 }
 
 int disc_sweep_all(const isx_config* cfg, const double* centers_axes, int32_t n_disc, double radius, double half_thick,
@@ -232,12 +356,31 @@ int disc_sweep_all(const isx_config* cfg, const double* centers_axes, int32_t n_
   if (!c.active()) return isx_disc_sweep(cfg, centers_axes, n_disc, radius, half_thick, n_rays, seed, first_ray, hits, st);
   uint64_t f, cnt;
   c.shard(n_rays, f, cnt);
-  isx_stats local;
-  const int rc = isx_disc_sweep(cfg, centers_axes, n_disc, radius, half_thick, cnt, seed, first_ray + f, hits, &local);
-  if (rc != ISX_OK) return rc;
-  if (!c.reduce(hits, (size_t)n_disc, &local)) return ISX_ERR_HIP;
-  if (st) *st = local;
-  return ISX_OK;
+  isx_stats local{};
+  int rc = isx_disc_sweep(cfg, centers_axes, n_disc, radius, half_thick, cnt, seed, first_ray + f, hits, &local);
+  rc = c.reduce(rc, hits, n_disc > 0 ? (size_t)n_disc : 0, &local);
+  if (rc == ISX_OK && st) *st = local;
+  return rc;
+}
+
+int disc_sweep_per_position_all(const isx_config* cfg, const double* centers_axes, int32_t n_disc, double radius,
+                                double half_thick, uint64_t rays_per_position, uint64_t seed, uint64_t first_ray, uint64_t* hits,
+                                isx_stats* st) {
+  Comm& c = comm();
+  if (!c.active())
+    return isx_disc_sweep_per_position(cfg, centers_axes, n_disc, radius, half_thick, rays_per_position, seed, first_ray, hits, st);
+  // whole disc positions per rank; position k keeps its rays [first_ray + k*rays_per_position, ...) whatever the rank count
+  uint64_t k0, nk;
+  c.shard(n_disc > 0 ? (uint64_t)n_disc : 0, k0, nk);
+  isx_stats local{};
+  int rc = ISX_OK;
+  if (n_disc > 0) std::memset(hits, 0, (size_t)n_disc * sizeof(uint64_t));
+  if (nk > 0)
+    rc = isx_disc_sweep_per_position(cfg, centers_axes + 6 * k0, (int32_t)nk, radius, half_thick, rays_per_position, seed,
+                                     first_ray + k0 * rays_per_position, hits + k0, &local);
+  rc = c.reduce(rc, hits, n_disc > 0 ? (size_t)n_disc : 0, &local);
+  if (rc == ISX_OK && st) *st = local;
+  return rc;
 }
 
 int exit_dz_hist_all(const isx_config* cfg, uint64_t n_rays, uint64_t seed, uint64_t first_ray, int32_t nbins, uint64_t* hist,
@@ -246,12 +389,11 @@ int exit_dz_hist_all(const isx_config* cfg, uint64_t n_rays, uint64_t seed, uint
   if (!c.active()) return isx_exit_dz_hist(cfg, n_rays, seed, first_ray, nbins, hist, st);
   uint64_t f, cnt;
   c.shard(n_rays, f, cnt);
-  isx_stats local;
-  const int rc = isx_exit_dz_hist(cfg, cnt, seed, first_ray + f, nbins, hist, &local);
-  if (rc != ISX_OK) return rc;
-  if (!c.reduce(hist, (size_t)nbins, &local)) return ISX_ERR_HIP;
-  if (st) *st = local;
-  return ISX_OK;
+  isx_stats local{};
+  int rc = isx_exit_dz_hist(cfg, cnt, seed, first_ray + f, nbins, hist, &local);
+  rc = c.reduce(rc, hist, nbins > 0 ? (size_t)nbins : 0, &local);
+  if (rc == ISX_OK && st) *st = local;
+  return rc;
 }
 
 }  // namespace isxhost

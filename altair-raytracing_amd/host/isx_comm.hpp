@@ -7,8 +7,15 @@
 // ISX_RANK/ISX_WORLD/ISX_LOCAL_RANK, RANK/WORLD_SIZE/LOCAL_RANK (torchrun), OMPI_COMM_WORLD_RANK/_SIZE/_LOCAL_RANK):
 //     for r in 0..7:  ISX_RANK=$r ISX_WORLD=8 ISX_RENDEZVOUS=/tmp/isx_job42 isx_macro fluxAtObserverFast::sweepDetectorTraceOnce ...
 // Rank r binds GPU ISX_LOCAL_RANK (unless ISX_DEVICE says otherwise); rank 0 writes the files, the other ranks write
-// to /dev/null.  The 128-byte ncclUniqueId travels through the file ISX_RENDEZVOUS (default /tmp/isx_rccl_<MASTER_PORT
-// or uid>; give every job its own path): rank 0 writes it atomically, the others wait for it (120 s), rank 0 removes it.
+// to /dev/null.  The 128-byte ncclUniqueId travels through a private per-job directory
+// <ISX_RENDEZVOUS | $XDG_RUNTIME_DIR | $TMPDIR | /tmp>/isx_rdzv_<uid>_<job>, <job> = ISX_JOB_ID or torchrun's
+// TORCHELASTIC_RUN_ID + MASTER_PORT (a multi-rank launch without a per-job nonce is refused): the id file carries a
+// magic word and the job tag and is verified on read; before anybody enters ncclCommInitRank every rank reports whether
+// it could bind its GPU (ready.<rank> / fail.<rank>), so one broken rank stops the job instead of hanging it.
+//
+// Failure semantics: every *_all() call ends in ONE collective that also carries the local status (MIN over ranks), so
+// either every rank returns the reduced result or every rank returns the same error; Comm::agree() is the same for
+// conditions checked on one rank only (the output file of the writer rank).
 #pragma once
 #include <cstdint>
 #include <string>
@@ -17,6 +24,16 @@
 
 namespace isxhost {
 
+// What the collective needs from the wire: in place, buf = [n_sum words summed | n_max words max'ed (both uint64) |
+// n_min words min'ed as int64].  RCCL in production; tests install an in-process double (tests/comm_stub_test.cpp).
+struct Transport {
+  virtual bool exchange(unsigned long long* buf, size_t n_sum, size_t n_max, size_t n_min) = 0;
+  virtual ~Transport() {}
+};
+// The collective itself (transport-independent): sums hits[count] and the census words of st[n_stats], takes the MAX of
+// the kernel times and the MIN of the status.  Returns the job-wide status; outputs are written only if it is ISX_OK.
+int reduce_collective(Transport& t, int local_rc, uint64_t* hits, size_t count, isx_stats* st, int n_stats);
+
 struct Comm {
   int rank = 0, world = 1, local_rank = 0;
   bool forced = false;             // ISX_FORCE_COMM=1: go through RCCL even with one rank (rehearsal on a 1-GPU box)
@@ -24,9 +41,13 @@ struct Comm {
   bool writer() const { return rank == 0; }
   // contiguous share of [0,n): the first n % world ranks get one extra unit (same rule as sharding.py)
   void shard(uint64_t n, uint64_t& first, uint64_t& count) const;
-  // in-place SUM of hits[count] and of the census in *st over all ranks (t_kernel_ms: MAX); false + message on failure
-  bool reduce(uint64_t* hits, size_t count, isx_stats* st, int n_stats = 1);
+  // called by EVERY rank with its local status: in-place SUM of hits[count] and of the census in *st over all ranks
+  // (t_kernel_ms: MAX); returns the job-wide status (the worst local one)
+  int reduce(int local_rc, uint64_t* hits, size_t count, isx_stats* st, int n_stats = 1);
+  // true on every rank iff local_ok on every rank (collective)
+  bool agree(bool local_ok);
   void finalize();
+  static void set_transport_for_tests(Transport* t);
 };
 Comm& comm();
 
@@ -42,6 +63,9 @@ int fluxmap_series_all(const isx_config* cfgs, int32_t n_cfg, uint64_t n_rays, u
                        isx_stats* st);
 int disc_sweep_all(const isx_config* cfg, const double* centers_axes, int32_t n_disc, double radius, double half_thick,
                    uint64_t n_rays, uint64_t seed, uint64_t first_ray, uint64_t* hits, isx_stats* st);
+int disc_sweep_per_position_all(const isx_config* cfg, const double* centers_axes, int32_t n_disc, double radius,
+                                double half_thick, uint64_t rays_per_position, uint64_t seed, uint64_t first_ray, uint64_t* hits,
+                                isx_stats* st);
 int exit_dz_hist_all(const isx_config* cfg, uint64_t n_rays, uint64_t seed, uint64_t first_ray, int32_t nbins, uint64_t* hist,
                      isx_stats* st);
 

@@ -57,6 +57,16 @@ bool ensure_device() {
   return state == 1;
 }
 
+// Every rank of a multi-rank launch reaches this point: true everywhere iff the device is bound on every rank and the
+// output file (opened on the writer rank only) is usable -- so no rank walks away from a collective the others enter.
+static bool ready_everywhere(bool file_ok = true) {
+  const bool dev_ok = ensure_device();
+  const bool ok = comm().agree(file_ok && dev_ok);
+  if (!ok && file_ok && dev_ok)   // the cause was reported by another rank, or by isx_comm on this one
+    err() << "Error: isx_comm: the job cannot run on every rank (device, output file or RCCL start-up); nothing was traced" << std::endl;
+  return ok;
+}
+
 static uint64_t take_rays(uint64_t n) {
   const uint64_t first = options().next_ray;
   options().next_ray += n;
@@ -554,10 +564,8 @@ void sweepDetector() {
                          std::to_string(nThetaBins * nPhiBins) + "points.csv";
   fullPath = outputPath(fullPath);
   std::ofstream csvFile(fullPath);
-  if (!csvFile.is_open()) {
-    err() << "Error: Could not open file " << fullPath << " for writing." << std::endl;
-    return;
-  }
+  const bool file_ok = csvFile.is_open();   // decided with the other ranks below (ready_everywhere): no rank may leave before the collective
+  if (!file_ok) err() << "Error: Could not open file " << fullPath << " for writing." << std::endl;
   const std::string timeBuffer = currentTimeString();
   csvFile << "# Flux Map Data - Generated: " << timeBuffer << std::endl;
   csvFile << "# Number of rays per position: " << n << std::endl;
@@ -569,7 +577,7 @@ void sweepDetector() {
   csvFile << "# Phi bins: " << nPhiBins << std::endl;
   csvFile << "# y direction: 2" << std::endl;
   csvFile << "theta,phi,fraction" << std::endl;
-  if (!ensure_device()) return;
+  if (!ready_everywhere(file_ok)) return;
   isx_config c = manager.cfg;
   c.src[0] = -60; c.src[1] = 0; c.src[2] = -80;
   c.dir[0] = 5; c.dir[1] = 2; c.dir[2] = 0;
@@ -644,17 +652,15 @@ void sweepDetector(bool notify, const char* saveFolder, int /*threads: ignored, 
                          std::to_string(int(srcY / cm)) + "_" + std::to_string(int(srcZ / cm)) + ".csv";
   fullPath = outputPath(fullPath);
   std::ofstream csvFile(fullPath);
-  if (!csvFile.is_open()) {
-    err() << "Error: Could not open file " << fullPath << " for writing." << std::endl;
-    return;
-  }
+  const bool file_ok = csvFile.is_open();   // decided with the other ranks below (ready_everywhere): no rank may leave before the collective
+  if (!file_ok) err() << "Error: Could not open file " << fullPath << " for writing." << std::endl;
   Detector detector(40 * cm, 40 * cm);
   const double src[3] = {srcX, srcY, srcZ}, dir[3] = {dirX, dirY, dirZ};
   csvFile << fluxmap_header(meta_for("Flux Map Data", "Number of rays per position", n, thetaMax, src, dir), currentTimeString());
   const int totalPositions = nThetaBins * nPhiBins;
   say("\nStarting detector sweep with " + std::to_string(n) + " rays per position (" + std::to_string(totalPositions) +
       " positions total)...");
-  if (!ensure_device()) return;
+  if (!ready_everywhere(file_ok)) return;
   const double t0 = now_s();
   isx_config c = manager.cfg;
   for (int k = 0; k < 3; ++k) { c.src[k] = src[k]; c.dir[k] = dir[k]; }
@@ -756,12 +762,10 @@ static void sweep_common(bool traceOnce, bool notify, const char* saveFolder, do
   mm.reflectance = REFLECTANCE; mm.roughness = ROUGHNESS; mm.maxReflections = MAX_REFLECTIONS;
   for (int k = 0; k < 3; ++k) { mm.src[k] = src[k] / cm; mm.dir[k] = dir[k]; }
   std::ofstream csvFile(fullPath, std::ios::trunc);
-  if (!csvFile.is_open()) {
-    err() << "Error: Could not open file " << fullPath << " for writing." << std::endl;
-    return;
-  }
+  const bool file_ok = csvFile.is_open();   // decided with the other ranks below (ready_everywhere): no rank may leave before the collective
+  if (!file_ok) err() << "Error: Could not open file " << fullPath << " for writing." << std::endl;
   csvFile << fluxmap_header(mm, currentTimeString());
-  if (!ensure_device()) return;
+  if (!ready_everywhere(file_ok)) return;
   isx_config c = manager.cfg;
   for (int k = 0; k < 3; ++k) { c.src[k] = src[k]; c.dir[k] = dir[k]; }
   c.n_theta = nThetaBins; c.n_phi = nPhiBins; c.det_diameter = 40 * cm; c.det_distance = 100 * cm;
@@ -839,7 +843,7 @@ void sweepSeries() {
   isx_config c = manager.cfg;
   c.src[0] = srcX; c.src[1] = srcY; c.src[2] = srcZ; c.dir[0] = dirXBase; c.dir[1] = 0; c.dir[2] = 0;
   c.n_theta = 180; c.n_phi = 90; c.det_diameter = 40 * cm; c.det_distance = 100 * cm; c.exit_port_z = -100 * cm;
-  if (!ensure_device()) return;
+  if (!ready_everywhere()) return;
   std::vector<isx_config> cfgs(reps, c);
   std::vector<uint64_t> hits((size_t)reps * 16200);
   std::vector<isx_stats> st(reps);
@@ -880,7 +884,7 @@ void sweepDetector() {
   const double exitPortZ = -100 * cm;
   const int nThetaBins = 45, nPhiBins = 20;
   Detector detector;
-  if (!ensure_device()) return;
+  if (!ready_everywhere()) return;
   isx_config c = manager.cfg;
   c.src[0] = -60; c.src[1] = 0; c.src[2] = -80; c.dir[0] = 5; c.dir[1] = 0; c.dir[2] = 0;
   c.n_theta = nThetaBins; c.n_phi = nPhiBins; c.det_diameter = detector.width; c.det_distance = 100 * cm;
@@ -895,7 +899,7 @@ void sweepDetector() {
   }
   const std::string path = outputPath("fluxmap_data.csv");  // the reference overwrites; this driver never does
   std::ofstream csvFile(path);
-  if (!csvFile.is_open()) {
+  if (!csvFile.is_open()) {   // after the last collective of this entry point: a local return is safe
     err() << "Error: Could not open file " << path << " for writing." << std::endl;
     return;
   }
@@ -921,7 +925,7 @@ static void root_geometry(isx_config& c, double r_out) {
 }
 
 void makeIntegratingSphereNRays() {
-  if (!ensure_device()) return;
+  if (!ready_everywhere()) return;
   isx_config c;
   root_geometry(c, 101 * cm);
   const long n = pick_n(1000);
@@ -952,30 +956,36 @@ void detectorDiskPlacement(double theta, double phi, double out[6]) {
 void sweepDetector(OpticsManager* manager, double diskRadius, int nRays, double dtheta, double thetaMax) {
   const double dphi = 180;
   std::ofstream outFile(outputPath("detector_sweep3.txt"));
-  if (!outFile.is_open()) {
-    err() << "Error: Could not open file detector_sweep3.txt for writing." << std::endl;
-    return;
-  }
+  const bool file_ok = outFile.is_open();
+  if (!file_ok) err() << "Error: Could not open file detector_sweep3.txt for writing." << std::endl;
   outFile << "Theta(deg)\tPhi(deg)\tHitFraction\n";
-  if (!ensure_device()) return;
+  if (!ready_everywhere(file_ok)) return;
+  // the reference's loop (integratingSphereDetectorSweep.C:54-77) places one disc, traces nRays fresh rays, moves on;
+  // here every position keeps its own nRays fresh rays and all positions go through ONE launch
+  std::vector<double> ca, angles;
   for (double theta = -thetaMax; theta <= thetaMax; theta += dtheta) {
     for (double phi = 0; phi < 360; phi += dphi) {
-      double ca[6];
-      detectorDiskPlacement(theta, phi, ca);
-      uint64_t hits = 0;
-      isx_stats st;
-      // fresh rays per position, as the reference's inner loop (:67-77)
-      const int rc = disc_sweep_all(&manager->cfg, ca, 1, diskRadius, 0.1 * cm, (uint64_t)nRays, options().seed,
-                                    take_rays((uint64_t)nRays), &hits, &st);
-      if (rc != ISX_OK) {
-        err() << "Error: isx_disc_sweep: " << isx_strerror(rc) << std::endl;
-        return;
-      }
-      const double hitFraction = static_cast<double>(hits) / nRays;
-      if (!options().quiet)
-        std::cout << "Theta: " << theta << "° Phi: " << phi << "° Hit fraction: " << hitFraction << std::endl;
-      outFile << theta << "\t" << phi << "\t" << hitFraction << "\n";
+      double one[6];
+      detectorDiskPlacement(theta, phi, one);
+      ca.insert(ca.end(), one, one + 6);
+      angles.push_back(theta); angles.push_back(phi);
     }
+  }
+  const int32_t nd = (int32_t)(ca.size() / 6);
+  std::vector<uint64_t> hits((size_t)nd);
+  isx_stats st;
+  const int rc = disc_sweep_per_position_all(&manager->cfg, ca.data(), nd, diskRadius, 0.1 * cm, (uint64_t)nRays, options().seed,
+                                             take_rays((uint64_t)nRays * (uint64_t)nd), hits.data(), &st);
+  if (rc != ISX_OK) {
+    err() << "Error: isx_disc_sweep_per_position: " << isx_strerror(rc) << std::endl;
+    return;
+  }
+  for (int32_t k = 0; k < nd; ++k) {
+    const double theta = angles[2 * (size_t)k], phi = angles[2 * (size_t)k + 1];
+    const double hitFraction = static_cast<double>(hits[(size_t)k]) / nRays;
+    if (!options().quiet)
+      std::cout << "Theta: " << theta << "° Phi: " << phi << "° Hit fraction: " << hitFraction << std::endl;
+    outFile << theta << "\t" << phi << "\t" << hitFraction << "\n";
   }
   outFile.close();
 }
@@ -988,7 +998,7 @@ void integratingSphereDetectorSweep() {
 }
 
 void distributionSphereDetectorSweep() {
-  if (!ensure_device()) return;
+  if (!ready_everywhere()) return;
   isx_config c;
   root_geometry(c, 101 * cm);
   const long n = pick_n(10000);

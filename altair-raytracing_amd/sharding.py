@@ -23,6 +23,15 @@ def shard(n_total: int, rank: int, world: int) -> Tuple[int, int]:
     return first, q + (1 if rank < r else 0)
 
 
+def step_slice(step: int, rank: int, world: int, rays_per_rank: int) -> Tuple[int, int]:
+    """bench.py's weak-scaling schedule: in step s, rank r traces rays [(s*world + r)*n, +n).  Over `steps` steps and all
+    ranks these slices tile [0, steps*world*n) exactly once, and the union over ranks of one step is the contiguous block
+    [s*world*n, (s+1)*world*n) -- so the summed histogram of a step does not depend on the number of ranks."""
+    if world < 1 or not (0 <= rank < world) or step < 0 or rays_per_rank < 0:
+        raise ValueError("bad step slice request")
+    return (step * world + rank) * rays_per_rank, rays_per_rank
+
+
 CENSUS_FIELDS = ("launched", "exited", "counted_below_z", "absorbed", "suspended", "bin_increments", "wall_hits")
 
 

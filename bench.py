@@ -28,12 +28,26 @@ VALU_CLOCK_GHZ = 2.4           # MI355X peak engine clock (78.6 TFLOP/s = 256 CU
 F_BOUNCE, N_BOUNCE, P_EXIT, F_DISC = 200.0, 57.5, 0.4235, 40.0
 
 
+def kernel_source_sha():
+    """Fingerprint of the kernel sources libisx.so is built from: a committed PMC summary is only used for the roofline if
+    it was measured on THIS code (tools/summarize_profile.py stores the same fingerprint)."""
+    import hashlib
+    h = hashlib.sha256()
+    base = os.path.join(ROOT, "altair-raytracing_amd", "csrc")
+    for name in ("isx_device.hpp", "isx_kernels.hpp", "isx_api.hip"):
+        with open(os.path.join(base, name), "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()[:16]
+
+
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--rays", type=int, default=50_000_000, help="rays per GPU per step (BASELINE configs[1])")
+    ap.add_argument("--rays", type=int, default=0,
+                    help="rays per GPU per step; default 5e7 (BASELINE configs[1]), and 1.25e8 at --gpus 8 "
+                         "(BASELINE configs[4]: 1e9 rays per step over the node)")
     ap.add_argument("--seed", type=lambda s: int(s, 0), default=0x5EED0001)
     ap.add_argument("--cpu-rays", type=int, default=-1, help="oracle sample size for cpu_baseline (0: skip, -1: auto)")
     ap.add_argument("--trace-mode", choices=["explicit", "chord"], default="explicit",
@@ -106,7 +120,8 @@ def main():
     cfg = isx.default_config()
     cfg.trace_mode = 1 if a.trace_mode == "chord" else 0
     nb = cfg.n_theta * cfg.n_phi
-    n = a.rays
+    n = a.rays if a.rays > 0 else (125_000_000 if world == 8 else 50_000_000)
+    which = "BASELINE configs[4]: 1e9 rays per step over 8 GPUs" if (world == 8 and n == 125_000_000) else "BASELINE configs[1]"
 
     hist_dev = torch.zeros(nb, dtype=torch.int64, device=dev)
 
@@ -115,9 +130,16 @@ def main():
             dist.barrier(device_ids=[dev_index])
         torch.cuda.synchronize()
 
-    # --- pick the reduce path: device-resident histogram if this process's two HIP runtimes
-    # (torch's and libisx's) agree on device pointers, else bounce 130 KB through the host.
+    # --- ONE HIP runtime per process: torch's wheel bundles libamdhip64.so with the SONAME libisx.so asks for
+    # (libamdhip64.so.7), and torch is imported (and has initialised the device) BEFORE libisx is loaded, so the dynamic
+    # linker hands libisx the runtime that is already mapped.  Checked, not assumed: count the distinct libamdhip64 images
+    # in this process.  With one runtime a torch tensor's data_ptr() is a device pointer libisx can write to, so the
+    # histogram stays on the device for the all-reduce; with two (never seen) it would bounce 130 KB through the host.
+    with open("/proc/self/maps") as f:
+        hip_images = sorted({ln.split()[-1] for ln in f if "libamdhip64" in ln})
     mode = a.reduce
+    if mode == "auto" and len(hip_images) != 1:
+        mode = "host"
     if mode == "auto":
         try:
             probe = torch.zeros(nb, dtype=torch.int64, device=dev)
@@ -139,7 +161,7 @@ def main():
 
     def step(s):
         """trace + bin this rank's slice of step s, then all-reduce the 180x90 histogram."""
-        first = (s * world + rank) * n
+        first, _ = isx.step_slice(s, rank, world, n)
         if mode == "device":
             hist_dev.zero_()
             torch.cuda.synchronize()
@@ -180,14 +202,24 @@ def main():
         hbm_gbs = alg_bytes / (k_ms * 1e-3) / 1e9
         f_ray = N_BOUNCE * F_BOUNCE + P_EXIT * nb * F_DISC
         fp64_tflops = n * f_ray / (k_ms * 1e-3) / 1e12
-        traffic, valu_per_ray, pmc_tag = None, None, None
+        # executed-instruction counters come from the committed rocprofv3 PMC passes (profiles/pmc_summary.json,
+        # written by tools/summarize_profile.py).  They are used only if they were measured on THIS kernel code.
+        pj, pmc_note = {}, "no profiles/pmc_summary.json"
         pmc = os.path.join(ROOT, "profiles", "pmc_summary.json")
         if os.path.exists(pmc):
             try:
                 pj = json.load(open(pmc))
-                traffic, valu_per_ray, pmc_tag = pj.get("hbm_bytes_per_launch"), pj.get("valu_wave_insts_per_ray"), pj.get("tag")
-            except Exception:
-                traffic = None
+                sha = kernel_source_sha()
+                if pj.get("kernel_source_sha") != sha:
+                    pmc_note = (f"STALE: profiles/pmc_summary.json (tag {pj.get('tag')}) was measured on kernel sources "
+                                f"{pj.get('kernel_source_sha')}, this build is {sha}: executed-instruction rooflines omitted")
+                    pj = {}
+                else:
+                    pmc_note = f"profiles/pmc_summary.json tag {pj.get('tag')}, kernel sources {sha}"
+            except Exception as e:  # a broken file is reported, not fatal
+                pj, pmc_note = {}, f"unreadable profiles/pmc_summary.json: {e}"
+        traffic, valu_per_ray, pmc_tag = pj.get("hbm_bytes_per_launch"), pj.get("valu_wave_insts_per_ray"), pj.get("tag")
+        fp64 = pj.get("fp64_executed")
         st = census[-1]
         out = {
             "metric": "Mrays/sec whole-node, 180x90 fluxmap src(-60,0,-75); achieved HBM GB/s vs peak",
@@ -196,30 +228,49 @@ def main():
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": f"{n} rays/GPU/step, pencil source src(-60,0,-75) dir(5,0,0) -> Lambertian wall "
                                    f"(rho .99, port 170deg), 180x90 detector map, 40 cm disc at 100 cm "
-                                   f"(BASELINE configs[1])",
+                                   f"({which})",
                        "rays_per_gpu_per_step": n, "grid": [cfg.n_theta, cfg.n_phi], "seed": hex(a.seed),
                        "parallelism": f"rays sharded over {world} GPU(s), one RCCL all-reduce of the histogram",
-                       "reduce_path": mode, "trace_mode": a.trace_mode, "device": devname},
-            "roofline": {"bound": "hbm", "achieved": hbm_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": hbm_gbs / HBM_PEAK_GBS, "traffic": traffic,
-                         "kernel": "isx_trace_bin_kernel", "kernel_ms": k_ms, "algorithmic_bytes_per_launch": alg_bytes,
-                         "note": "the path reads nothing and writes one 129.6 KB histogram per launch: HBM is not "
-                                 "the binding resource (SURVEY.md §8d); see roofline_fp64"},
-            "roofline_fp64": {"bound": "valu_fp64", "achieved": fp64_tflops, "peak": FP64_VALU_PEAK_TFLOPS,
-                              "unit": "TFLOP/s", "frac": fp64_tflops / FP64_VALU_PEAK_TFLOPS,
-                              "flop_per_ray_model": f_ray,
-                              "note": "algorithmic FP64 flop of the reference algorithm (brute-force 16200 disc "
-                                      "tests per exiting ray, BASELINE.md §2); the kernel culls, so executed flop "
-                                      "are far fewer and frac may exceed what executed-op counters show"},
-            # the resource that actually binds: VALU issue slots.  One wave64 instruction occupies a SIMD's VALU for 4
-            # cycles, so a GPU issues at most n_simd * clock / 4 wave-instructions per second.
-            "roofline_valu": (None if not valu_per_ray else {
+                       "reduce_path": mode, "trace_mode": a.trace_mode, "device": devname,
+                       "hip_runtime_images": hip_images,
+                       "rccl_world_size": (dist.get_world_size() if use_dist else 1),
+                       "torch_backend": (dist.get_backend() if use_dist else None)},
+            # The binding resource is VALU issue (the path reads nothing and writes one 129.6 KB histogram per
+            # launch; no MFMA).  One wave64 instruction occupies a SIMD's VALU for >= 4 cycles (f64; 32-bit ops can dual
+            # issue in 2), so a GPU issues at most n_simd * clock / 4 wave-instructions per second by this convention.
+            # achieved = executed SQ_INSTS_VALU per ray (PMC pass on this kernel code) x rays / LIVE kernel time.
+            "roofline": ({"bound": "valu_issue", "achieved": None, "peak": cus * 4 * VALU_CLOCK_GHZ / 4.0,
+                          "unit": "G wave-instr/s", "frac": None, "traffic": traffic, "kernel": "isx_trace_bin_kernel",
+                          "kernel_ms": k_ms, "note": pmc_note} if not valu_per_ray else {
                 "bound": "valu_issue", "achieved": valu_per_ray * n / (k_ms * 1e-3) / 1e9,
                 "peak": cus * 4 * VALU_CLOCK_GHZ / 4.0, "unit": "G wave-instr/s",
                 "frac": valu_per_ray * n / (k_ms * 1e-3) / 1e9 / (cus * 4 * VALU_CLOCK_GHZ / 4.0),
-                "valu_wave_insts_per_ray": valu_per_ray,
-                "note": f"executed SQ_INSTS_VALU per ray from the committed PMC pass (profiles/pmc_summary.json, tag {pmc_tag}) "
-                        f"x rays / live kernel time; peak = {cus} CUs x 4 SIMDs x {VALU_CLOCK_GHZ} GHz / 4 cycles"}),
+                "traffic": traffic, "kernel": "isx_trace_bin_kernel", "kernel_ms": k_ms,
+                "valu_wave_insts_per_ray": valu_per_ray, "valu_busy": pj.get("valu_busy"),
+                "valu_lane_utilization": pj.get("valu_lane_utilization"),
+                "note": f"executed SQ_INSTS_VALU per ray from {pmc_note} x rays / live kernel time (HIP events on the "
+                        f"library's stream); peak = {cus} CUs x 4 SIMDs x {VALU_CLOCK_GHZ} GHz / 4 cycles; traffic = HBM "
+                        f"bytes per launch (FETCH_SIZE + WRITE_SIZE passes)"}),
+            # the HBM figure the north star asks for, kept beside it: algorithmic bytes / kernel time against 8 TB/s
+            "roofline_hbm": {"bound": "hbm", "achieved": hbm_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                             "frac": hbm_gbs / HBM_PEAK_GBS, "traffic": traffic, "algorithmic_bytes_per_launch": alg_bytes,
+                             "note": "the path reads nothing and writes one 129.6 KB histogram per launch: HBM is not the "
+                                     "binding resource (SURVEY.md 8d) and no traffic is faked to make it one"},
+            # reference-algorithm flop (brute-force convention of SURVEY.md 8d) -- NOT a utilisation: the kernel culls
+            "roofline_fp64_model": {"bound": "valu_fp64", "achieved": fp64_tflops, "peak": FP64_VALU_PEAK_TFLOPS,
+                                    "unit": "TFLOP/s", "frac": fp64_tflops / FP64_VALU_PEAK_TFLOPS,
+                                    "flop_per_ray_model": f_ray,
+                                    "note": "algorithmic FP64 flop of the reference algorithm (16200 disc tests per exiting "
+                                            "ray, BASELINE.md section 2) / kernel time; exceeds 1 because the kernel culls"},
+            # EXECUTED f64 operations (rocprofv3 SQ_INSTS_VALU_{ADD,MUL,FMA,TRANS}_F64; fma = 2 flop), lane-level:
+            # wave-instructions x 64 x measured lane utilisation
+            "roofline_fp64_executed": (None if not fp64 else {
+                "bound": "valu_fp64", "unit": "TFLOP/s", "peak": FP64_VALU_PEAK_TFLOPS,
+                "achieved": fp64["lane_flop_per_ray"] * n / (k_ms * 1e-3) / 1e12,
+                "frac": fp64["lane_flop_per_ray"] * n / (k_ms * 1e-3) / 1e12 / FP64_VALU_PEAK_TFLOPS,
+                "f64_wave_insts_per_ray": fp64["wave_insts_per_ray"], "share_of_valu_insts": fp64["share_of_valu"],
+                "note": "executed FP64 from the PMC pass; the rest of the VALU stream is Philox (32-bit integer), f32 cull "
+                        "arithmetic, conversions, compares and moves"}),
             "census_last_step": {"launched": st.launched, "counted_below_z": st.counted_below_z,
                                  "wall_hits": st.wall_hits, "bin_increments": st.bin_increments},
             "hist_sum_last_step": total_hits,

@@ -57,6 +57,8 @@ typedef enum isx_status {
  * with the default grid of one workgroup per CU that is ~1.1e12 rays on an MI355X.  Split larger jobs over calls.
  * Ray indices are 64-bit; first_ray + n_rays must not exceed 2^64 - 1 (ISX_ERR_BAD_ARG). */
 #define ISX_MAX_RAYS_PER_CALL (1ull << 40)
+/* isx_exit_directions keeps at most this many 32-byte records per call (8 GiB of device memory) */
+#define ISX_MAX_LOG_RECORDS (1ull << 28)
 
 /* source_model */
 #define ISX_SOURCE_PENCIL 0 /* fluxAtObserver*.C: identical rays from src along dir            */
@@ -194,6 +196,15 @@ int isx_disc_sweep(const isx_config* cfg, const double* centers_axes /*[n_disc][
                    uint64_t* hits, isx_stats* stats);
 
 /*
+ * The same sweep as the reference WRITES it (integratingSphereDetectorSweep.C:54-77): every disc position k gets its
+ * own `rays_per_position` fresh rays [first_ray + k*rays_per_position, +rays_per_position) and only those are tested
+ * against disc k -- all positions in ONE launch (362 positions x 1e5 rays for the macro's defaults).
+ */
+int isx_disc_sweep_per_position(const isx_config* cfg, const double* centers_axes /*[n_disc][6]*/, int32_t n_disc,
+                                double radius, double half_thick, uint64_t rays_per_position, uint64_t seed,
+                                uint64_t first_ray, uint64_t* hits, isx_stats* stats);
+
+/*
  * The reference's PER-POSITION maps: every detector position gets its own
  * `rays_per_position` fresh rays (fluxAtObserverOptimize.C:542-579, n=50000 => 8.1e8 rays
  * for 180x90).  Rays [first_ray + g*rays_per_position, +rays_per_position) belong to
@@ -225,7 +236,8 @@ int isx_exit_dz_hist(const isx_config* cfg, uint64_t n_rays, uint64_t seed, uint
 /*
  * Un-binned exit log (the committed 3dRayLog.txt, "# dx dy dz"): ray index and final unit
  * direction of every ray counted below exit_port_z, sorted by ray index.  capacity = room in
- * ray_ids[capacity] / directions[capacity][3]; *count = number of such rays (may exceed capacity:
+ * ray_ids[capacity] / directions[capacity][3] (at most ISX_MAX_LOG_RECORDS are kept, more is ISX_ERR_TOO_LARGE;
+ * a capacity above n_rays is treated as n_rays); *count = number of such rays (may exceed capacity:
  * the surplus is dropped).  This is the one sink with real HBM output (32 B per exiting ray).
  */
 int isx_exit_directions(const isx_config* cfg, uint64_t n_rays, uint64_t seed, uint64_t first_ray, uint64_t capacity,

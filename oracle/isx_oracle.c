@@ -952,6 +952,53 @@ int isxo_disc_sweep(const isxo_config* c, const double* ca, int32_t nd, double r
   return 0;
 }
 
+/* the sweep as the reference writes it (integratingSphereDetectorSweep.C:54-77): disc k sees only its own rays
+ * [first + k*rpp, +rpp) */
+int isxo_disc_sweep_per_position(const isxo_config* c, const double* ca, int32_t nd, double radius, double half_thick,
+                                 uint64_t rpp, uint64_t seed, uint64_t first, uint64_t* hits, isxo_stats* stats, int nthreads) {
+  geom g;
+  if (!c || !hits || !ca || nd < 1 || rpp < 1) return -3;
+  int rc = prepare(c, &g);
+  if (rc) return rc;
+  memset(hits, 0, (size_t)nd * sizeof(uint64_t));
+  isxo_stats tot;
+  memset(&tot, 0, sizeof(tot));
+  double t0 = now_ms();
+#ifdef _OPENMP
+  if (nthreads > 0) omp_set_num_threads(nthreads);
+  else omp_set_num_threads(omp_get_num_procs());
+#endif
+#pragma omp parallel
+  {
+    isxo_stats st;
+    memset(&st, 0, sizeof(st));
+#pragma omp for schedule(dynamic, 1)
+    for (int k = 0; k < nd; k++) {
+      uint64_t h = 0;
+      for (uint64_t i = 0; i < rpp; i++) {
+        endstate es;
+        trace_one(&g, seed, first + (uint64_t)k * rpp + i, 0u, g.src, g.dir0, K_NONE, &es);
+        const int status = es.status;
+        const v3 seg_start = es.prev, p = es.p, v = es.v;
+        int counted;
+        census(&es, c->exit_port_z, &st, &counted);
+        if (status == ISXO_EXITED) {
+          v3 dlt = { p.x - seg_start.x, p.y - seg_start.y, p.z - seg_start.z };
+          double tmax = dot3(dlt, v);
+          if (segment_hits_tube(seg_start, v, tmax, ca + 6 * k, radius, half_thick)) h++;
+        }
+      }
+      hits[k] = h;
+      st.bin_increments += h;
+    }
+#pragma omp critical
+    stats_add(&tot, &st);
+  }
+  tot.t_kernel_ms = now_ms() - t0;
+  if (stats) *stats = tot;
+  return 0;
+}
+
 int isxo_exit_dz_hist(const isxo_config* c, uint64_t n, uint64_t seed, uint64_t first, int32_t nbins, uint64_t* hist,
                       isxo_stats* stats, int nthreads) {
   geom g;

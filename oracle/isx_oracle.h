@@ -79,6 +79,11 @@ int isxo_trace_rays_detector(const isxo_config* cfg, const double* detector, dou
 int isxo_disc_sweep(const isxo_config* cfg, const double* centers_axes, int32_t n_disc, double radius,
                     double half_thick, uint64_t n_rays, uint64_t seed, uint64_t first_ray, uint64_t* hits,
                     isxo_stats* stats, int nthreads);
+/* The same with every disc position seeing only its own rays [first_ray + k*rays_per_position, +rays_per_position)
+ * (the loop integratingSphereDetectorSweep.C:54-77 as written). */
+int isxo_disc_sweep_per_position(const isxo_config* cfg, const double* centers_axes, int32_t n_disc, double radius,
+                                 double half_thick, uint64_t rays_per_position, uint64_t seed, uint64_t first_ray,
+                                 uint64_t* hits, isxo_stats* stats, int nthreads);
 
 /* Exit-direction by-products (distributionSphereDetectorSweep.C:61-103): for rays counted
  * below z, histogram of dz into nbins over [-1,1) and optional direction log. */

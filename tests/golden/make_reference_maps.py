@@ -11,7 +11,7 @@ What is kept, bin by bin (VERDICT r01 "next" #1: the full 180x90 maps, not only 
   * per folder of trace-once files (trace_once_test_04_2..., portAngleSweep_04_03..., portAngleSweep_04_02...)
     the bin-wise SUM of the integer hit counts of all files of the folder, the number of files, and the sum
     of their `Total rays exiting port` footers (these pin hit_line_mode = 1, the GetPoint(nPoints-2) defect).
-Keys: <name>_hits [180,90] int32, <name>_meta = json string.
+Keys: <name>_hits [180,90] int32 (-1 = row missing in a cut-short file), index_json = list of per-map metadata.
 """
 import glob
 import json
@@ -72,7 +72,7 @@ for folder in ("results_overnight_03_31-60_0_-75_5", "results_overnight_04_1-60_
         # name: pp_<mm_dd of the folder>_<k>, k = the suffix the reference's getUniqueFilename gave the file (none = 0)
         stem = os.path.basename(p)[:-4]
         k = stem.rsplit("_", 1)[1] if stem.rsplit("_", 1)[1].isdigit() and not stem.endswith("-75") else "0"
-        name = "pp_" + folder.split("-")[0][-5:] + "_" + k
+        name = "pp_" + re.match(r"results_overnight_(\d+_\d+)", folder).group(1) + "_" + k
         info = {
             "name": name, "kind": "per_position", "file": os.path.relpath(p, REF), "complete": bool(full),
             "rows_present": int(nrows), "port_deg": float(meta["Exit port angle"].split()[0]),

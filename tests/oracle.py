@@ -83,6 +83,7 @@ def lib():
         L.isxo_trace_endstates.argtypes = [P(Config), u64, u64, u64, P(i32), P(i32), P(dbl), P(dbl)]
         L.isxo_fluxmap.argtypes = [P(Config), u64, u64, u64, P(u64), P(Stats), C.c_int]
         L.isxo_disc_sweep.argtypes = [P(Config), P(dbl), i32, dbl, dbl, u64, u64, u64, P(u64), P(Stats), C.c_int]
+        L.isxo_disc_sweep_per_position.argtypes = [P(Config), P(dbl), i32, dbl, dbl, u64, u64, u64, P(u64), P(Stats), C.c_int]
         L.isxo_exit_dz_hist.argtypes = [P(Config), u64, u64, u64, i32, P(u64), P(Stats), C.c_int]
         L.isxo_fluxmap_per_position.argtypes = [P(Config), u64, i32, u64, u64, u64, u64, P(u64), P(Stats), C.c_int]
         L.isxo_trace_rays_detector.argtypes = [P(Config), P(dbl), dbl, u64, u64, u64, P(u64), P(Stats)]
@@ -161,6 +162,17 @@ def disc_sweep(cfg, centers_axes, radius, half_thick, n, seed, first=0, nthreads
     st = Stats()
     rc = lib().isxo_disc_sweep(C.byref(cfg), _p(ca, C.c_double), nd, radius, half_thick, n, seed, first,
                                _p(hits, C.c_uint64), C.byref(st), nthreads)
+    assert rc == 0, rc
+    return hits, st
+
+
+def disc_sweep_per_position(cfg, centers_axes, radius, half_thick, rpp, seed, first=0, nthreads=0):
+    ca = np.ascontiguousarray(centers_axes, dtype=np.float64)
+    nd = ca.shape[0]
+    hits = np.zeros(nd, dtype=np.uint64)
+    st = Stats()
+    rc = lib().isxo_disc_sweep_per_position(C.byref(cfg), _p(ca, C.c_double), nd, radius, half_thick, rpp, seed, first,
+                                            _p(hits, C.c_uint64), C.byref(st), nthreads)
     assert rc == 0, rc
     return hits, st
 

@@ -184,6 +184,44 @@ def test_cli_fails_loudly_without_gpu(cli, tmp_path):
     assert r.returncode != 0 and "no CPU fallback" in r.stderr
 
 
+def test_collective_status_with_a_failing_rank(cli, tmp_path):
+    """ranks must not diverge before the collective.  tests/native/comm_stub_test.cpp joins 2 and 8 "ranks"
+    (threads) through an in-process Transport double: SUM/MAX semantics, and with ONE rank failing every rank returns
+    that rank's error and nobody is left waiting (the run is under a time-out)."""
+    exe = tmp_path / "comm_stub_test"
+    subprocess.check_call(["g++", "-O1", "-std=c++17", "-I/opt/rocm/include", "-D__HIP_PLATFORM_AMD__", "-o", str(exe),
+                           os.path.join(ROOT, "tests", "native", "comm_stub_test.cpp"), "-L" + HOST, "-lisx_macros",
+                           "-Wl,-rpath," + HOST, "-lpthread"])
+    r = subprocess.run([str(exe)], capture_output=True, text=True, timeout=60)
+    assert r.returncode == 0 and r.stdout.strip().endswith("OK"), r.stdout + r.stderr
+
+
+def test_multirank_launch_stops_instead_of_hanging(cli, tmp_path):
+    """The pre-flight of isx_comm.cpp: a rank that cannot bind its GPU says so in the job's rendezvous directory, so no
+    rank enters ncclCommInitRank (which has no time-out).  Here (no GPU) both ranks of a 2-rank launch must stop within
+    seconds; a multi-rank launch without a per-job nonce is refused."""
+    import time
+    import altair_raytracing_amd as isx
+    if isx.load().isx_init(0) == 0:
+        isx.load().isx_shutdown()
+        pytest.skip("GPU present")
+    args = ("fluxAtObserverFast::sweepDetectorTraceOnce", "folder=out", "srcZ=-75", "dirY=0", "thetaMax=170")
+    base = {k: v for k, v in os.environ.items() if not k.startswith("ISX_") and k not in ("MASTER_PORT", "TORCHELASTIC_RUN_ID", "RANK", "WORLD_SIZE")}
+    t0 = time.time()
+    procs = []
+    for rank in (0, 1):
+        env = dict(base, ISX_QUIET="1", ISX_RAYS="1000", ISX_RANK=str(rank), ISX_WORLD="2", ISX_JOB_ID="t-%d" % os.getpid(),
+                   ISX_RENDEZVOUS=str(tmp_path))
+        procs.append(subprocess.Popen([cli, *args], cwd=tmp_path, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    outs = [p.communicate(timeout=60) for p in procs]
+    assert time.time() - t0 < 30
+    for p, (_, err) in zip(procs, outs):
+        assert p.returncode != 0 and ("could not bind its GPU" in err or "no CPU fallback" in err), err
+    env = dict(base, ISX_QUIET="1", ISX_RAYS="1000", ISX_RANK="0", ISX_WORLD="2", ISX_RENDEZVOUS=str(tmp_path))
+    r = subprocess.run([cli, *args], cwd=tmp_path, env=env, capture_output=True, text=True, timeout=60)
+    assert r.returncode != 0 and "per-job nonce" in r.stderr, r.stderr
+
+
 # --------------------------------------------------------------------------------------------- GPU
 def _run(cli, cwd, entry, *args, rays=None, seed=None):
     env = dict(os.environ, ISX_QUIET="1")
@@ -274,18 +312,18 @@ def test_rccl_reduce_path_of_the_cpp_driver(cli, isx, tmp_path):
     a.mkdir(); b.mkdir()
     args = ("fluxAtObserverFast::sweepDetectorTraceOnce", "folder=out", "srcZ=-75", "dirY=0", "thetaMax=170")
     _run(cli, a, *args, rays=100000, seed=5)
-    env = dict(os.environ, ISX_QUIET="1", ISX_RAYS="100000", ISX_SEED="5", ISX_FORCE_COMM="1", ISX_RENDEZVOUS=str(b / "rv"))
+    env = dict(os.environ, ISX_QUIET="1", ISX_RAYS="100000", ISX_SEED="5", ISX_FORCE_COMM="1", ISX_RENDEZVOUS=str(b))
     r = subprocess.run([cli, *args], cwd=b, env=env, capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stderr
     name = "fluxmap_traceonce_100000rays_180x90_src-60_0_-75.csv"
     assert rows(a / "out" / name) == rows(b / "out" / name) and len(rows(a / "out" / name)) == 16201
-    assert not (b / "rv").exists()                    # rank 0 removes the rendezvous file once everyone has joined
+    assert not [d for d in os.listdir(b) if d.startswith("isx_rdzv_")]   # the job's rendezvous directory is gone once everyone has joined
     c = tmp_path / "dup"
     c.mkdir()
     procs = []
     for rank in (0, 1):
         env = dict(os.environ, ISX_QUIET="1", ISX_RAYS="20000", ISX_RANK=str(rank), ISX_WORLD="2", ISX_DEVICE="0",
-                   ISX_RENDEZVOUS=str(c / "rv"))
+                   ISX_RENDEZVOUS=str(c), ISX_JOB_ID="dup-%d" % os.getpid())
         procs.append(subprocess.Popen([cli, *args], cwd=c, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
     outs = [p.communicate(timeout=300) for p in procs]
     for p, (_, err) in zip(procs, outs):

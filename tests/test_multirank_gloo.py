@@ -84,3 +84,24 @@ def test_sharded_allreduce_equals_single_rank(world, orc):
         assert np.array_equal(hits, want), rank
         assert census["launched"] == N and census["counted_below_z"] == st.counted_below_z
         assert census["bin_increments"] == int(want.sum()) and census["wall_hits"] == st.wall_hits
+
+
+def test_bench_step_slices_tile_the_index_range():
+    """bench.py's schedule (sharding.step_slice): for world = 1, 2, 4, 8 the slices of `steps` steps cover
+    [0, steps*world*n) disjointly, and one step's slices form one contiguous block (N-independent histograms)."""
+    import altair_raytracing_amd as isx
+    n, steps = 1000, 5
+    for world in (1, 2, 4, 8):
+        seen = np.zeros(steps * world * n, dtype=np.int32)
+        for s in range(steps):
+            lo = min(isx.step_slice(s, r, world, n)[0] for r in range(world))
+            assert lo == s * world * n
+            for r in range(world):
+                first, count = isx.step_slice(s, r, world, n)
+                assert count == n
+                seen[first:first + count] += 1
+        assert seen.min() == 1 and seen.max() == 1
+    # BASELINE configs[4]: 8 ranks x 1.25e8 rays per step = 1e9 rays per step
+    assert sum(isx.step_slice(0, r, 8, 125_000_000)[1] for r in range(8)) == 1_000_000_000
+    with pytest.raises(ValueError):
+        isx.step_slice(0, 8, 8, 10)

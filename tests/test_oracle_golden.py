@@ -1,8 +1,11 @@
 """Pin the oracle against every fixture the reference's own result files offer.
 
 The reference has no seeded tests and its trace arithmetic lives in ROBAST (absent), so these
-are distribution-level checks with tolerances derived from the files' own run-to-run scatter;
-bit-level parity vs ROOT/ROBAST is "unpinned" (DESIGN.md §2)."""
+are distribution-level checks; bit-level parity vs ROOT/ROBAST is "unpinned" (DESIGN.md §2).
+
+Tolerances are the statistical resolution of the two samples being compared (pure binomial / Poisson sigmas, no
+additive percentage floors).  Where round 2 measured a residual against the reference's 8.1e8-ray maps (totals 0.3-1.0 %
+low, profiles/r02_parity_scan.md) the expected value of the comparison is that measured residual, stated in the test."""
 import numpy as np
 import pytest
 
@@ -37,16 +40,35 @@ def test_per_position_map_170(orc, golden):
     n = 400_000
     h, st = orc.fluxmap(orc.default_config(), n, SEED)
     frac = h / n
-    assert abs(frac.sum() / m["sum_fraction"] - 1) < 0.02
+    # total: this sample's own noise is 1.16/sqrt(n) = 0.18 % (hits per ray: 0 or ~270); known residual -0.3..-0.6 %
+    assert -0.012 < frac.sum() / m["sum_fraction"] - 1 < 0.004
     assert st.bin_increments == int(h.sum())
     prof, gold = frac.mean(axis=1), np.array(m["theta_profile"])
     # noise of the reference rows (binomial, 90 x 50000 rays) + ours (correlated: ~n*p_exit/4 rays touch a row)
     sig_ref = np.sqrt(np.maximum(gold, 1e-7) / (m["rays_per_position"] * m["n_phi"]))
     sig_our = gold / np.sqrt(n * 0.42 * 0.2)
-    z = np.abs(prof - gold) / (np.hypot(sig_ref, sig_our) + 0.01 * gold)
+    z = np.abs(prof - gold) / np.hypot(sig_ref, sig_our)
     assert z.max() < 5, (z.max(), int(z.argmax()))
     # the documented quirk: detectors are edge-on at theta=90, the map collapses there
     assert prof[179] < 0.02 * prof[0]
+
+
+def test_every_bin_of_the_170_map(orc):
+    """All 16 200 bins of the reference's 8.1e8-ray map (tests/golden/reference_maps.npz) against 4e5 oracle rays, binomial
+    sigmas: chi2/dof ~ 1.0-1.06 (the GPU tests do the same with 8.1e8 rays for all seven maps)."""
+    import json
+    import os
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "reference_maps.npz"))
+    info = [i for i in json.loads(str(z["index_json"])) if i["name"] == "pp_03_31_0"][0]
+    ref = z["pp_03_31_0_hits"].astype(np.float64)
+    assert ref.shape == (180, 90) and int(ref.sum()) == info["total_hits_footer"] == 5723365
+    n, n_ref = 400_000, info["rays_per_position"]
+    h, _ = orc.fluxmap(orc.default_config(), n, SEED + 1)
+    p = (ref + h) / (n_ref + n)
+    var = p * (1 - p) * (1.0 / n_ref + 1.0 / n)
+    use = p * n_ref >= 5
+    chi2 = (((ref / n_ref - h / n) ** 2)[use] / var[use]).sum() / use.sum()
+    assert use.sum() > 15000 and chi2 < 1.12, chi2
 
 
 def test_total_hits_vs_port_angle_and_direction(orc, golden):
@@ -61,7 +83,8 @@ def test_total_hits_vs_port_angle_and_direction(orc, golden):
             cfg.dir[k] = m["source_direction"][k]
         h, _ = orc.fluxmap(cfg, n, SEED + int(m["port_deg"]))
         assert m["total_hits"] == pytest.approx(m["sum_fraction"] * m["rays_per_position"], rel=1e-4)
-        assert abs(h.sum() / n / m["sum_fraction"] - 1) < 0.03, (m["port_deg"], m["source_direction"])
+        # own noise 1.16/sqrt(n) = 0.37 %; known residual -0.4 % (port 172) .. -1.0 % (port 163)
+        assert -0.025 < h.sum() / n / m["sum_fraction"] - 1 < 0.010, (m["port_deg"], m["source_direction"])
 
 
 def test_exit_direction_histogram(orc, golden):
@@ -96,8 +119,32 @@ def test_sigma_half_map_pins_lambertian_ignores_roughness(orc, golden):
     assert abs(frac.sum() / g["sum_fraction"] - 1) < 0.02
     prof, gold = frac.mean(axis=1), np.array(g["theta_profile"])
     sig = np.sqrt(np.maximum(gold, 2e-7) / (100000 * 20)) + gold / np.sqrt(n * 0.2)
-    z = np.abs(prof - gold) / (sig + 0.015 * gold)
+    z = np.abs(prof - gold) / sig
     assert z.max() < 5, (z.max(), int(z.argmax()))
+
+
+def _nl_cfg(orc, source_model):
+    cfg = orc.default_config()
+    cfg.src[2] = -80.0; cfg.reflectance = 1.0; cfg.roughness_rad = 0.5; cfg.max_points = 10000; cfg.box_half = 200.0
+    cfg.n_theta, cfg.n_phi, cfg.det_diameter = 45, 20, 10.0
+    cfg.source_model = source_model
+    cfg.brdf[0], cfg.brdf[1], cfg.brdf[2] = 0.3, 0.4, 0.6
+    return cfg
+
+
+@pytest.mark.xfail(strict=True, reason="BRDF source model unpinned: the only committed nonLambertianFlux.C output is matched "
+                                       "with the BRDF re-scatter OFF (sum ratio 0.997) and missed with it ON (0.81)")
+def test_nonlambertian_file_with_the_brdf_rescatter_on(orc, golden):
+    """run source_model = 1 (nonLambertianFlux.C:147-208,253-268 as committed) at the macro's own settings
+    (45x20, 10 cm detector, src z = -80) against flux_at_observer/fluxmap_data.csv.  Measured in round 2 (4e6 rays):
+    sum(fraction) 0.7673 vs the file's 0.9488 (ratio 0.809), chi2 per theta-row 1011; with the re-scatter off 0.9463
+    (ratio 0.997), chi2 per row 1.10.  So that file was written by a revision WITHOUT the re-scatter (the committed
+    nonLambertianFlux_C.so is older than the source), no reference data constrains the BRDF model, and
+    BASELINE configs[2] is benchmarked on a restatement that only the source text pins."""
+    g = golden["nonlambertian_map"]
+    n = 600_000
+    h, st = orc.fluxmap(_nl_cfg(orc, 1), n, SEED)
+    assert abs(h.sum() / n / g["sum_fraction"] - 1) < 0.02
 
 
 def test_physical_disc_sweep(orc, golden):
@@ -124,8 +171,9 @@ def test_physical_disc_sweep(orc, golden):
     hits, st = orc.disc_sweep(cfg, np.array(ca), 5.0, 0.1, n, SEED)
     got = (hits.reshape(len(thetas), len(phis)) / n).mean(axis=1)
     gold = np.array(g["phi_mean_fraction"])
-    sig = np.sqrt(np.maximum(gold, 1e-5) / (1000 * g["n_phi"]))     # 1000 rays x 360 phi per reference point
-    z = np.abs(got - gold) / (sig + 0.03 * gold)
+    sig_ref = np.sqrt(np.maximum(gold, 1e-5) / (1000 * g["n_phi"]))     # 1000 rays x 360 phi per reference point
+    sig_our = np.sqrt(np.maximum(got, 1e-6) / (n * len(phis)))
+    z = np.abs(got - gold) / np.hypot(sig_ref, sig_our)
     assert z.max() < 5, (z.max(), got, gold)
     assert got[len(thetas) // 2] == pytest.approx(gold[len(thetas) // 2], rel=0.12)
 
@@ -178,11 +226,11 @@ def test_chord_mode_meets_the_same_fixtures(orc, golden):
     n = 400_000
     h, _ = orc.fluxmap(c, n, SEED)
     frac = h / n
-    assert abs(frac.sum() / m["sum_fraction"] - 1) < 0.02
+    assert -0.012 < frac.sum() / m["sum_fraction"] - 1 < 0.004      # as in test_per_position_map_170
     prof, gold = frac.mean(axis=1), np.array(m["theta_profile"])
     sig_ref = np.sqrt(np.maximum(gold, 1e-7) / (m["rays_per_position"] * m["n_phi"]))
     sig_our = gold / np.sqrt(n * 0.42 * 0.2)
-    z = np.abs(prof - gold) / (np.hypot(sig_ref, sig_our) + 0.01 * gold)
+    z = np.abs(prof - gold) / np.hypot(sig_ref, sig_our)
     assert z.max() < 5, (z.max(), int(z.argmax()))
 
 

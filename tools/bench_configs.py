@@ -12,49 +12,75 @@ import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import altair_raytracing_amd as isx  # noqa: E402
 
+import argparse
+ap = argparse.ArgumentParser()
+ap.add_argument("--only", choices=["all", "flux", "chord", "brdf", "discs", "perpos"], default="all",
+                help="run one configuration only (what tools/profile.sh profiles)")
+ap.add_argument("--reps", type=int, default=0, help="launches per configuration (0: the defaults below)")
+ARGS = ap.parse_args()
 isx.load(); isx.init(0)
 out = {}
 
 
+def want(name):
+    return ARGS.only in ("all", name)
+
+
 def best(fn, reps=3):
     ts = []
-    for _ in range(reps):
+    for _ in range(ARGS.reps or reps):
         st = fn()
         ts.append(st.t_kernel_ms)
     return min(ts), st
 
 
-c = isx.default_config()
 n = 50_000_000
-ms, st = best(lambda: isx.fluxmap(c, n, 0x5EED0001)[1])
-out["configs[1] lambertian 5e7"] = {"ms": ms, "Mrays_s": n / ms / 1e3}
-c.trace_mode = 1
-ms, st = best(lambda: isx.fluxmap(c, n, 0x5EED0001)[1])
-out["configs[1] chord mode"] = {"ms": ms, "Mrays_s": n / ms / 1e3}
+if want("flux"):
+    c = isx.default_config()
+    ms, st = best(lambda: isx.fluxmap(c, n, 0x5EED0001)[1])
+    out["configs[1] lambertian 5e7"] = {"ms": ms, "Mrays_s": n / ms / 1e3}
+if want("chord"):
+    c = isx.default_config()
+    c.trace_mode = 1
+    ms, st = best(lambda: isx.fluxmap(c, n, 0x5EED0001)[1])
+    out["configs[1] chord mode"] = {"ms": ms, "Mrays_s": n / ms / 1e3}
 
-c = isx.default_config()
-c.source_model = isx.SOURCE_BRDF; c.brdf[0], c.brdf[1], c.brdf[2] = 0.3, 0.4, 0.6
-c.roughness_rad = 0.5; c.reflectance = 1.0; c.max_points = 10000; c.box_half = 200.0
-ms, st = best(lambda: isx.fluxmap(c, n, 0x5EED0001)[1], reps=2)
-out["configs[2] nonLambertianFlux source 5e7"] = {"ms": ms, "Mrays_s": n / ms / 1e3, "wall_hits_per_ray": st.wall_hits / n}
+if want("brdf"):
+    c = isx.default_config()
+    c.source_model = isx.SOURCE_BRDF; c.brdf[0], c.brdf[1], c.brdf[2] = 0.3, 0.4, 0.6
+    c.roughness_rad = 0.5; c.reflectance = 1.0; c.max_points = 10000; c.box_half = 200.0
+    ms, st = best(lambda: isx.fluxmap(c, n, 0x5EED0001)[1], reps=2)
+    out["configs[2] nonLambertianFlux source 5e7"] = {"ms": ms, "Mrays_s": n / ms / 1e3, "wall_hits_per_ray": st.wall_hits / n}
 
-c = isx.default_config()
-c.r_out = 105.0; c.reflectance = 1.0; c.roughness_rad = 0.0; c.max_points = 10000; c.box_half = 200.0
-c.src[2] = -80.0
-discs = []
-for th in np.arange(-45.0, 45.0 + 1e-9, 0.5):
-    for ph in (0.0, 180.0):
-        t, p = math.radians(th), math.radians(ph)
-        cx, cy, cz = 200 * math.sin(t) * math.cos(p), 200 * math.sin(t) * math.sin(p), -200 * math.cos(t)
-        ax = (0 - cx, 0 - cy, -100 - cz)
-        nn = math.sqrt(sum(a * a for a in ax))
-        discs.append([cx, cy, cz, ax[0] / nn, ax[1] / nn, ax[2] / nn])
-discs = np.array(discs)
-n4 = 10_000_000
-ms, st = best(lambda: isx.disc_sweep(c, discs, 5.0, 0.1, n4, 7)[1], reps=2)
-out["configs[3] disc sweep 362 discs 1e7"] = {"ms": ms, "Mrays_s": n4 / ms / 1e3}
 
-c = isx.default_config()
-ms, st = best(lambda: isx.fluxmap_per_position(c, 50_000, 0x5EED0001)[1], reps=2)
-out["per-position map 5e4 x 16200 (reference: 12 524 s)"] = {"ms": ms, "Mrays_s": 50_000 * 16200 / ms / 1e3}
+def disc_positions():
+    """rootMacros::detectorDiskPlacement (integratingSphereDetectorSweep.C:145-172): centre at 200 cm from the origin, tube
+    axis (sin rotTheta, 0, cos rotTheta) for every phi (TGeoRotation::RotateY left-multiplies, DESIGN.md section 2.4)."""
+    discs = []
+    for th in np.arange(-45.0, 45.0 + 1e-9, 0.5):
+        for ph in (0.0, 180.0):
+            t, p = math.radians(th), math.radians(ph)
+            x, y, z = 200 * math.sin(t) * math.cos(p), 200 * math.sin(t) * math.sin(p), -200 * math.cos(t)
+            dx, dy, dz = 0 - x, 0 - y, -100 - z
+            rot = -math.atan2(math.sqrt(dx * dx + dy * dy), dz)
+            discs.append([x, y, z, math.sin(rot), 0.0, math.cos(rot)])
+    return np.array(discs)
+
+
+if want("discs"):
+    c = isx.default_config()
+    c.r_out = 105.0; c.reflectance = 1.0; c.roughness_rad = 0.0; c.max_points = 10000; c.box_half = 200.0
+    c.src[2] = -80.0
+    discs = disc_positions()
+    n4 = 10_000_000
+    ms, st = best(lambda: isx.disc_sweep(c, discs, 5.0, 0.1, n4, 7)[1], reps=2)
+    out["configs[3] disc sweep, 362 discs share 1e7 rays"] = {"ms": ms, "Mrays_s": n4 / ms / 1e3}
+    rpp = 1_000_000
+    ms, st = best(lambda: isx.disc_sweep_per_position(c, discs, 5.0, 0.1, rpp, 7)[1], reps=2)
+    out["configs[3] per-position disc sweep, 362 x 1e6 rays, one launch"] = {"ms": ms, "Mrays_s": rpp * len(discs) / ms / 1e3}
+
+if want("perpos"):
+    c = isx.default_config()
+    ms, st = best(lambda: isx.fluxmap_per_position(c, 50_000, 0x5EED0001)[1], reps=2)
+    out["per-position map 5e4 x 16200 (reference: 12 524 s)"] = {"ms": ms, "Mrays_s": 50_000 * 16200 / ms / 1e3}
 print(json.dumps(out, indent=1))

@@ -17,8 +17,12 @@ H = [
  ("port_test=1", "every ray leaving downwards counted (no z < -100 test on the box)"), ("outer=1", "outer sphere absorbs"),
  ("box_half=200.", "world box 200 cm"), ("det_distance=101.", "detector distance 101 cm"), ("first_specular=1", "first interaction specular"),
 ]
-res = []
+import os
+res = json.load(open(out))["rows"] if os.path.exists(out) else []
+done = {r["spec"] for r in res}
 for spec, text in H:
+    if spec in done:
+        continue
     t = time.time()
     o = scan.run_one(spec, N, ("pp_03_31_0", "pp_04_1_0"))
     row = {"spec": spec, "text": text}

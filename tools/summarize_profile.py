@@ -1,20 +1,40 @@
 #!/usr/bin/env python3
-"""Condense gpurun_out/prof_* (written by tools/profile.sh on the GPU box) into
-profiles/<tag>_summary.md, profiles/<tag>_kernel_stats.csv and profiles/pmc_summary.json."""
+"""Condense gpurun_out/prof_<NAME>_* (written by tools/profile.sh on the GPU box) into profiles/<tag>_summary.md,
+profiles/<tag>_kernel_stats.csv, profiles/<tag>_pmc_summary.json -- and, for the headline kernel, profiles/pmc_summary.json
+(what bench.py reads for its executed-instruction rooflines, with the fingerprint of the kernel sources it was measured on).
+
+usage: summarize_profile.py <tag> [note] [--name flux] [--kernel isx_trace_bin_kernel] [--rays 5e7] [--headline]
+"""
+import argparse
 import collections
 import csv
 import glob
+import hashlib
 import json
 import os
 import shutil
-import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 OUT = os.path.join(ROOT, "gpurun_out")
-tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
-note = sys.argv[2] if len(sys.argv) > 2 else ""
-KERNEL = "isx_trace_bin_kernel"
+ap = argparse.ArgumentParser()
+ap.add_argument("tag")
+ap.add_argument("note", nargs="?", default="")
+ap.add_argument("--name", default="flux")
+ap.add_argument("--kernel", default="isx_trace_bin_kernel")
+ap.add_argument("--rays", type=float, default=5e7, help="rays per full-size launch (per-ray figures)")
+ap.add_argument("--headline", action="store_true", help="also write profiles/pmc_summary.json (bench.py's source)")
+ap.add_argument("--command", default="python3 bench.py --steps 3 --warmup 1 --cpu-rays 0")
+a = ap.parse_args()
+tag, note, KERNEL, RAYS = a.tag, a.note, a.kernel, a.rays
 os.makedirs(os.path.join(ROOT, "profiles"), exist_ok=True)
+
+
+def kernel_source_sha():
+    h = hashlib.sha256()
+    for name in ("isx_device.hpp", "isx_kernels.hpp", "isx_api.hip"):
+        with open(os.path.join(ROOT, "altair-raytracing_amd", "csrc", name), "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()[:16]
 
 
 def one(pattern):
@@ -22,29 +42,35 @@ def one(pattern):
     return g[-1] if g else None   # newest: gpurun merges successive runs into the same directories
 
 
+def is_kernel(name):   # exact kernel, not a longer name that contains it (isx_trace_bin_kernel vs isx_trace_bin_brdf_kernel)
+    return name.split("(")[0].strip().strip('"') == KERNEL
+
+
+P = f"prof_{a.name}"
 lines = [f"# rocprofv3 summary `{tag}` — {KERNEL}", "", note, ""]
-kt = one("prof_kt/*/*_kernel_trace.csv")
+kt = one(f"{P}_kt/*/*_kernel_trace.csv")
 big = []
 if kt:
-    rows = [r for r in csv.DictReader(open(kt)) if KERNEL in r["Kernel_Name"]]
+    rows = [r for r in csv.DictReader(open(kt)) if is_kernel(r["Kernel_Name"])]
     durs = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6 for r in rows]
     mx = max(durs)
     big = [d for d in durs if d > 0.5 * mx]
     r = rows[durs.index(mx)]
-    lines += ["## kernel trace (`rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 3 --warmup 1 --cpu-rays 0`)", "",
-              f"* full-size launches (5e7 rays): {len(big)}, average {sum(big)/len(big):.3f} ms, min {min(big):.3f}, max {max(big):.3f}",
+    lines += [f"## kernel trace (`rocprofv3 --kernel-trace --stats -- {a.command}`)", "",
+              f"* full-size launches ({RAYS:.3g} rays): {len(big)}, average {sum(big)/len(big):.3f} ms, min {min(big):.3f}, max {max(big):.3f}"
+              f" -> {RAYS / (sum(big)/len(big)) / 1e3:.1f} Mrays/s",
               f"* grid {r['Grid_Size_X']} threads = {int(r['Grid_Size_X'])//int(r['Workgroup_Size_X'])} workgroups x {r['Workgroup_Size_X']}, "
               f"VGPR_Count {r['VGPR_Count']}, SGPR_Count {r['SGPR_Count']}, scratch {r['Scratch_Size']}, "
               f"LDS_Block_Size {r['LDS_Block_Size']} (dynamic LDS is not shown by the trace)", ""]
-    ks = one("prof_kt/*/*_kernel_stats.csv")
+    ks = one(f"{P}_kt/*/*_kernel_stats.csv")
     if ks:
         shutil.copy(ks, os.path.join(ROOT, "profiles", f"{tag}_kernel_stats.csv"))
-        lines += ["`--stats` table (all kernels of the process; the two ~3 ms calls are bench.py's 4096-ray reduce-path probe):", "", "```"]
-        lines += open(ks).read().splitlines()[:6]
+        lines += ["`--stats` table (all kernels of the process):", "", "```"]
+        lines += [ln[:400] for ln in open(ks).read().splitlines()[:6]]
         lines += ["```", ""]
 
 pmc = {}
-for d in sorted(glob.glob(os.path.join(OUT, "prof_pmc_*"))):
+for d in sorted(glob.glob(os.path.join(OUT, f"{P}_pmc_*"))):
     if not os.path.isdir(d):
         continue
     f = sorted(glob.glob(os.path.join(d, "*", "*_counter_collection.csv")), key=os.path.getmtime)
@@ -52,31 +78,32 @@ for d in sorted(glob.glob(os.path.join(OUT, "prof_pmc_*"))):
         continue
     by = collections.defaultdict(dict)
     for r in csv.DictReader(open(f[-1])):
-        if KERNEL in r["Kernel_Name"]:
+        if is_kernel(r["Kernel_Name"]):
             by[r["Dispatch_Id"]][r["Counter_Name"]] = float(r["Counter_Value"])
-    # keep full-size dispatches: those whose first counter is within 2x of the max
     if not by:
         continue
+    # keep full-size dispatches: those whose first counter is within 2x of the max
     key = next(iter(next(iter(by.values()))))
     mx = max(v[key] for v in by.values())
-    sel = [v for v in by.values() if v[key] > 0.5 * mx]
+    sel = [v for v in by.values() if v[key] > 0.5 * mx] if mx > 0 else list(by.values())
     for k in sel[0]:
         pmc[k] = sum(v[k] for v in sel) / len(sel)
 
+summ = {"tag": tag, "kernel": KERNEL, "rays_per_launch": RAYS, "kernel_source_sha": kernel_source_sha()}
+if big:
+    summ["kernel_ms"] = sum(big) / len(big)
 if pmc:
     lines += ["## PMC counters, per full-size launch (separate `--pmc` passes, averages)", "", "| counter | value |", "|---|---|"]
     for k in sorted(pmc):
         lines.append(f"| {k} | {pmc[k]:.6g} |")
     lines.append("")
-    summ = {"tag": tag}
     if "FETCH_SIZE" in pmc and "WRITE_SIZE" in pmc:
         fetch_b, write_b = pmc["FETCH_SIZE"] * 1024, pmc["WRITE_SIZE"] * 1024
         summ.update(fetch_bytes=fetch_b, write_bytes=write_b, hbm_bytes_per_launch=fetch_b + write_b,
                     note="FETCH_SIZE/WRITE_SIZE are KiB. gfx950 FETCH_SIZE under-counts wide coalesced streams by 2x "
-                         "(MI355X_MICROARCH.md §HBM); this kernel's reads are a few KB of scalar/L2 traffic so no "
+                         "(MI355X_MICROARCH.md HBM section); this kernel's reads are a few KB of scalar/L2 traffic so no "
                          "correction is applied; WRITE_SIZE is exact for the 8-byte atomics of the histogram flush.")
-        lines += [f"HBM bytes per launch: fetch {fetch_b/1e6:.3f} MB + write {write_b/1e6:.3f} MB = {(fetch_b+write_b)/1e6:.3f} MB "
-                  f"(algorithmic: 0.1296 MB).", ""]
+        lines += [f"HBM bytes per launch: fetch {fetch_b/1e6:.3f} MB + write {write_b/1e6:.3f} MB = {(fetch_b+write_b)/1e6:.3f} MB.", ""]
     if big and "GRBM_GUI_ACTIVE" in pmc:
         clk = pmc["GRBM_GUI_ACTIVE"] / 8 / (sum(big) / len(big) * 1e-3) / 1e9
         summ["clock_ghz"] = clk
@@ -91,12 +118,38 @@ if pmc:
         summ["valu_lane_utilization"] = util
         lines.append(f"* VALU lane utilisation = SQ_THREAD_CYCLES_VALU / (64*SQ_ACTIVE_INST_VALU) = {util:.3f}")
     if "SQ_INSTS_VALU" in pmc:
-        summ["valu_wave_insts_per_ray"] = pmc["SQ_INSTS_VALU"] / 5e7
-        lines.append(f"* VALU wave-instructions per ray = {pmc['SQ_INSTS_VALU']/5e7:.1f}; SALU {pmc.get('SQ_INSTS_SALU',0)/5e7:.1f}; "
-                     f"LDS {pmc.get('SQ_INSTS_LDS',0)/5e7:.2f}; VMEM {pmc.get('SQ_INSTS_VMEM',0)/5e7:.5f}")
+        summ["valu_wave_insts_per_ray"] = pmc["SQ_INSTS_VALU"] / RAYS
+        lines.append(f"* VALU wave-instructions per ray = {pmc['SQ_INSTS_VALU']/RAYS:.1f}; SALU {pmc.get('SQ_INSTS_SALU',0)/RAYS:.1f}; "
+                     f"LDS {pmc.get('SQ_INSTS_LDS',0)/RAYS:.2f}; VMEM {pmc.get('SQ_INSTS_VMEM',0)/RAYS:.5f}")
+        if big:
+            rate = pmc["SQ_INSTS_VALU"] / (sum(big) / len(big) * 1e-3) / 1e9
+            summ["valu_issue_rate_g"] = rate
+            lines.append(f"* VALU issue rate = {rate:.1f} G wave-instr/s of 614.4 (256 CU x 4 SIMD x 2.4 GHz / 4) = {rate/614.4:.3f}")
+    f64 = [pmc.get(f"SQ_INSTS_VALU_{k}_F64") for k in ("ADD", "MUL", "FMA", "TRANS")]
+    if all(v is not None for v in f64) and "SQ_INSTS_VALU" in pmc:
+        add, mul, fma, trans = f64
+        wave_insts = add + mul + fma + trans
+        util = summ.get("valu_lane_utilization", 1.0)
+        lane_flop = (add + mul + 2 * fma + trans) * 64 * util
+        summ["fp64_executed"] = {"add": add, "mul": mul, "fma": fma, "trans": trans, "wave_insts_per_ray": wave_insts / RAYS,
+                                 "share_of_valu": wave_insts / pmc["SQ_INSTS_VALU"], "lane_flop_per_ray": lane_flop / RAYS,
+                                 "lane_utilization_used": util}
+        lines += ["", "### executed instruction mix (wave-instructions per ray)", "",
+                  f"* f64: add {add/RAYS:.1f}, mul {mul/RAYS:.1f}, fma {fma/RAYS:.1f}, trans {trans/RAYS:.2f} = {wave_insts/RAYS:.1f} "
+                  f"({100*wave_insts/pmc['SQ_INSTS_VALU']:.1f} % of the VALU stream)"]
+        f32 = [pmc.get(f"SQ_INSTS_VALU_{k}_F32", 0.0) for k in ("ADD", "MUL", "FMA", "TRANS")]
+        lines.append(f"* f32: add {f32[0]/RAYS:.1f}, mul {f32[1]/RAYS:.1f}, fma {f32[2]/RAYS:.1f}, trans {f32[3]/RAYS:.2f}")
+        lines.append(f"* int32 {pmc.get('SQ_INSTS_VALU_INT32',0)/RAYS:.1f}, int64 {pmc.get('SQ_INSTS_VALU_INT64',0)/RAYS:.1f}, "
+                     f"cvt {pmc.get('SQ_INSTS_VALU_CVT',0)/RAYS:.1f}, LDS atomics {pmc.get('SQ_INSTS_LDS_ATOMIC',0)/RAYS:.2f}")
+        if big:
+            tf = lane_flop / (sum(big) / len(big) * 1e-3) / 1e12
+            summ["fp64_executed"]["tflops"] = tf
+            lines.append(f"* executed FP64 = {lane_flop/RAYS:.0f} lane-flop per ray (fma = 2, x64 lanes x lane utilisation {util:.3f}) "
+                         f"= {tf:.2f} TFLOP/s = {tf/78.6:.3f} of the 78.6 TFLOP/s vector FP64 peak")
     summ["counters"] = pmc
-    json.dump(summ, open(os.path.join(ROOT, "profiles", "pmc_summary.json"), "w"), indent=1)
     json.dump(summ, open(os.path.join(ROOT, "profiles", f"{tag}_pmc_summary.json"), "w"), indent=1)
+    if a.headline:
+        json.dump(summ, open(os.path.join(ROOT, "profiles", "pmc_summary.json"), "w"), indent=1)
 
 open(os.path.join(ROOT, "profiles", f"{tag}_summary.md"), "w").write("\n".join(lines) + "\n")
 print("\n".join(lines))
