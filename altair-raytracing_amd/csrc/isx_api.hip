@@ -291,8 +291,9 @@ int enqueue(int sink, const isx_config* c, uint64_t n, uint64_t seed, uint64_t f
   // the per-block histogram (+ tables) must fit the workgroup's LDS: a grid too fine for that is a configuration error
   if (lds > S.lds_limit) return ISX_ERR_BAD_CONFIG;
   if (sink == SINK_FLUX) {
-    // room for the per-lane exit-line records of the lean kernels (20 B per lane), if the grid leaves it
-    const size_t stage = 16 + (size_t)kBlock * 20;
+    // room for the per-lane exit-line records of the lean kernels (16 + 4 B per lane) and the long-row list of the column
+    // walk (4 B per lane), if the grid leaves it
+    const size_t stage = 16 + (size_t)kBlock * 24;
     if (lds + stage <= S.lds_limit) { lds += stage; d.rec_stage = 1; }
   }
   if (n == 0) return ISX_OK;
@@ -783,5 +784,17 @@ int isx_exit_dz_hist(const isx_config* cfg, uint64_t n_rays, uint64_t seed, uint
   HIPCHK(hipMemcpyAsync(hist, S.d_hist, (size_t)nbins * sizeof(unsigned long long), hipMemcpyDeviceToHost, S.stream));
   return collect_stats(stats);
 }
+
+#ifdef ISX_DIAG
+// tuning builds only (not declared in isx.h): read and clear the binning diagnostics of isx_kernels.hpp
+int isx_diag_read(uint64_t* out16) {
+  if (!S.init || !out16) return ISX_ERR_BAD_ARG;
+  HIPCHK(hipStreamSynchronize(S.stream));
+  HIPCHK(hipMemcpyFromSymbol(out16, HIP_SYMBOL(isx::g_diag), 16 * sizeof(unsigned long long)));
+  unsigned long long z[16] = {0};
+  HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(isx::g_diag), z, sizeof(z)));
+  return ISX_OK;
+}
+#endif
 
 }  // extern "C"

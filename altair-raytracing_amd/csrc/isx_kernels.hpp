@@ -51,6 +51,19 @@ struct DetGrid {
   uint64_t log_cap;
 };
 
+// -DISX_DIAG (tuning builds only, never the shipped library): where the binning work goes.
+// [0] lines via the per-lane fast path, [1] via bin_culled caps, [2] via the whole-row fallback, [3] skipped (miss),
+// [4..6] column-loop iterations (wave level) of those three paths, [7..9] candidates (lane level), [10] split passes,
+// [11] row passes
+#ifdef ISX_DIAG
+__device__ unsigned long long g_diag[16];
+#define ISX_DIAG_ADD(k, v) do { if (lane == 0) atomicAdd(&g_diag[k], (unsigned long long)(v)); } while (0)
+#define ISX_DIAG_ADD_LANES(k, v) atomicAdd(&g_diag[k], (unsigned long long)(v))
+#else
+#define ISX_DIAG_ADD(k, v) do { } while (0)
+#define ISX_DIAG_ADD_LANES(k, v) do { } while (0)
+#endif
+
 enum : int { SINK_FLUX = 0, SINK_DZ = 1, SINK_DISC = 2, SINK_PERPOS = 3, SINK_LOG = 4, SINK_DISCPOS = 5 };
 
 struct Work {
@@ -149,79 +162,142 @@ struct CapWin {            // what the row windows need:
   int jlo_u, cnt_u;                       // otherwise: one phi-window shared by all rows
 };
 
+// Coefficients of row i for the line (P,V) and the walk over columns [jlo + start, jlo + start + len) of its window, with the
+// exact decision (shared by every row-to-lane mapping below).  jlo may be negative on entry (wrapped here).
+template <class D>
+__device__ __forceinline__ void walk_columns(const D& d, uint32_t* __restrict__ hist, const ColX* __restrict__ colx, const V3& P,
+                                             const V3& V, int lane, int i, double Sd, double Cd, double zd, double Ad, int jlo,
+                                             int start, int len, int path) {
+  double a0c = 0, a1c = 0, a2c = 0, b0c = 0, b1c = 0, b2c = 0, e0c = 0, e1c = 0, e2c = 0, f0c = 0, f1c = 0, f2c = 0, bandc = 0;
+  if (len > 0) {
+    const double pz = P.z - zd;
+    a0c = -(Cd * V.z); a1c = Sd * V.y; a2c = -(Sd * V.x);
+    b0c = -(Cd * pz);  b1c = Sd * P.y; b2c = -(Sd * P.x);
+    // e: -2 dv,  f: dd - (w/2)^2   (the factors the sign test needs, folded into the row constants)
+    e0c = -2.0 * fma(P.x, V.x, fma(P.y, V.y, pz * V.z)); e1c = 2.0 * (Ad * V.x); e2c = 2.0 * (Ad * V.y);
+    const double f0 = fma(P.x, P.x, fma(P.y, P.y, fma(Ad, Ad, pz * pz)));
+    f0c = f0 - d.half_w2; f1c = -2.0 * (Ad * P.x); f2c = -2.0 * (Ad * P.y);
+    // bound of 2e-9 (t1 + t3 + rhs) over every column of the row (t1 = dd dot^2, t3 = num^2, rhs = (w/2)^2 dot^2
+    // in the notation of the header comment): |dot| <= |V||n| = 1 and num^2 <= dd |n|^2 = dd (Cauchy-Schwarz),
+    // dd <= f0 + |f1| + |f2|, so t1 + t3 + rhs <= 2 dd_max + (w/2)^2.
+    bandc = 2.1e-9 * fma(2.0, f0 + (fabs(f1c) + fabs(f2c)), d.half_w2);
+    if (jlo < 0) jlo += d.n_phi;   // start column in [0, n_phi); the window then runs to < 2 n_phi
+  }
+  const ColX* cp = colx + (jlo + start);
+  const uint32_t rowoff = (uint32_t)(i * d.n_phi) * 4u;
+  if (len > 0) ISX_DIAG_ADD_LANES(7 + path, len);
+  for (int k = 0;; ++k) {                    // until the widest (part of a) window of the wave is done
+    const bool act = k < len;
+    if (__ballot(act) == 0ull) break;
+    ISX_DIAG_ADD(4 + path, 1);
+    bool hit = false;
+    uint32_t boff = 0;
+    if (act) {
+      const double cph = cp->c, sph = cp->s;
+      boff = rowoff + cp->off4;
+      cp++;
+      const double dot = fma(a1c, cph, fma(a2c, sph, a0c));
+      const double num = fma(b1c, cph, fma(b2c, sph, b0c));
+      const double m2dv = fma(e1c, cph, fma(e2c, sph, e0c));
+      const double ddw = fma(f1c, cph, fma(f2c, sph, f0c));
+      // sign of  dot^2 (dd - (w/2)^2) - 2 num dot dv + num^2  (|V| = 1 to rounding: Newton-renormalised)
+      const double diff = fma(dot, fma(dot, ddw, num * m2dv), num * num);
+      // evaluation error ~1e-15 of the terms' scale; bandc >= 2e-9 of that scale for every column of the row
+      // (an f32 version of this test was tried and rejected: its error grows like 1/|dot| and it
+      //  mis-decided 16 of 2.3e9 hits at 2e7 rays; f64 keeps >100x margin down to |dot| = 1e-4)
+      hit = diff < 0.0;
+      if (fabs(dot) < 1e-4 || fabs(diff) <= bandc)  // too close to call: exact reference-order test
+        hit = check_intersection(d.table + 6 * (size_t)(boff >> 2), d.half_w2, P, V);
+    }
+    if (hit) atomicAdd(reinterpret_cast<uint32_t*>(reinterpret_cast<unsigned char*>(hist) + boff), 1u);
+  }
+}
+
 // Rows ilo..ihi, 64 at a time (lane = row).  CAPS: each row's phi-window is its intersection with the cap `w`;
 // otherwise the same window [jlo_u, jlo_u + cnt_u) for every row.  Then the column walk with the exact decision.
+//
+// Long windows (CAPS, `split` = 64 ints of wave-private LDS): a column pass lasts as long as the widest window of the wave, and
+// the widths are heavy-tailed -- the rows next to the pole of the detector hemisphere span the whole ring (n_phi columns)
+// while a typical row has ~8: 4 % of the headline's exit lines owned 27 % of the column iterations, and nearly every line of
+// the BRDF source model is such a line.  So when a wave meets windows longer than kSplitAt + 16 columns and at most 32 rows
+// have more than kSplitAt, pass 0 stops every window at kSplitAt and a pass 1 deals the remainders to Q = 2, 4 or 8 lanes per
+// long row (lane -> (row, part) through the LDS list; the row's window and coefficients are simply derived again by its new
+// lanes, from wave-uniform inputs, so they are the same numbers).  Same candidates, same decisions, fewer idle lanes.
+#ifndef ISX_SPLIT_AT
+#define ISX_SPLIT_AT 24
+#endif
+constexpr int kSplitAt = ISX_SPLIT_AT;
 template <bool CAPS, class D>
 __device__ __forceinline__ void walk_rows(const D& d, uint32_t* __restrict__ hist, const double* __restrict__ rowt,
                                           const ColX* __restrict__ colx, const V3& P, const V3& V, int lane, int ilo,
-                                          int ihi, const CapWin& w) {
+                                          int ihi, const CapWin& w, int* split = nullptr, int path = 0) {
 #pragma unroll 1
   for (int i0 = ilo; i0 <= ihi; i0 += 64) {
-    const int i = i0 + lane;
-    int jlo = 0, cnt = 0;
-    double a0c = 0, a1c = 0, a2c = 0, b0c = 0, b1c = 0, b2c = 0, e0c = 0, e1c = 0, e2c = 0, f0c = 0, f1c = 0, f2c = 0, bandc = 0;
-    if (i <= ihi) {
-      const double Sd = rowt[4 * i + 0], Cd = rowt[4 * i + 1], zd = rowt[4 * i + 2], Ad = rowt[4 * i + 3];
-      if (!CAPS) { jlo = w.jlo_u; cnt = w.cnt_u; }
-      else {
-        const float zi = (float)zd, Ai = (float)Ad;
-        const float dzi = zi - w.Fz;
-        const float num = fmaf(Ai, Ai, fmaf(dzi, dzi, w.AF2)) - w.ch2;
-        const float den = 2.0f * Ai * w.AF;
-        const float slack = 2e-5f * (fmaf(Ai, Ai, w.AF2) + w.ch2);  // f32 rounding of num
-        if (num - slack <= -den) { jlo = 0; cnt = d.n_phi; }
-        else if (num - slack > den) { cnt = 0; }
+    int npass = 1, logq = 0, nlong = 0;
+#pragma unroll 1
+    for (int pass = 0; pass < npass; ++pass) {
+      int i = i0 + lane, part = 0;
+      bool have = i <= ihi;
+      if (CAPS && pass == 1) {
+        const int slot = lane >> logq;
+        part = lane & ((1 << logq) - 1);
+        have = slot < nlong;
+        i = have ? reinterpret_cast<volatile int*>(split)[slot] : 0;
+      }
+      int jlo = 0, cnt = 0;
+      double Sd = 0, Cd = 0, zd = 0, Ad = 0;
+      if (have) {
+        Sd = rowt[4 * i + 0]; Cd = rowt[4 * i + 1]; zd = rowt[4 * i + 2]; Ad = rowt[4 * i + 3];
+        if (!CAPS) { jlo = w.jlo_u; cnt = w.cnt_u; }
         else {
-          float K = (num - slack) * rcp_cull(den) - 2e-5f;
-          K = fminf(1.f, fmaxf(-1.f, K));
-          const float dl = acos_cull(K) + 1e-3f;
-          const float hw = dl * w.inv_dphi;
-          const int lo = (int)ceilf(w.jf - hw), hi = (int)floorf(w.jf + hw);
-          jlo = lo; cnt = hi - lo + 1;
-          if (cnt < 0) cnt = 0;
-          if (cnt >= d.n_phi) { jlo = 0; cnt = d.n_phi; }
+          const float zi = (float)zd, Ai = (float)Ad;
+          const float dzi = zi - w.Fz;
+          const float num = fmaf(Ai, Ai, fmaf(dzi, dzi, w.AF2)) - w.ch2;
+          const float den = 2.0f * Ai * w.AF;
+          const float slack = 2e-5f * (fmaf(Ai, Ai, w.AF2) + w.ch2);  // f32 rounding of num
+          if (num - slack <= -den) { jlo = 0; cnt = d.n_phi; }
+          else if (num - slack > den) { cnt = 0; }
+          else {
+            float K = (num - slack) * rcp_cull(den) - 2e-5f;
+            K = fminf(1.f, fmaxf(-1.f, K));
+            const float dl = acos_cull(K) + 1e-3f;
+            const float hw = dl * w.inv_dphi;
+            const int lo = (int)ceilf(w.jf - hw), hi = (int)floorf(w.jf + hw);
+            jlo = lo; cnt = hi - lo + 1;
+            if (cnt < 0) cnt = 0;
+            if (cnt >= d.n_phi) { jlo = 0; cnt = d.n_phi; }
+          }
         }
       }
-      if (cnt > 0) {
-        const double pz = P.z - zd;
-        a0c = -(Cd * V.z); a1c = Sd * V.y; a2c = -(Sd * V.x);
-        b0c = -(Cd * pz);  b1c = Sd * P.y; b2c = -(Sd * P.x);
-        // e: -2 dv,  f: dd - (w/2)^2   (the factors the sign test needs, folded into the row constants)
-        e0c = -2.0 * fma(P.x, V.x, fma(P.y, V.y, pz * V.z)); e1c = 2.0 * (Ad * V.x); e2c = 2.0 * (Ad * V.y);
-        const double f0 = fma(P.x, P.x, fma(P.y, P.y, fma(Ad, Ad, pz * pz)));
-        f0c = f0 - d.half_w2; f1c = -2.0 * (Ad * P.x); f2c = -2.0 * (Ad * P.y);
-        // bound of 2e-9 (t1 + t3 + rhs) over every column of the row (t1 = dd dot^2, t3 = num^2, rhs = (w/2)^2 dot^2
-        // in the notation of the header comment): |dot| <= |V||n| = 1 and num^2 <= dd |n|^2 = dd (Cauchy-Schwarz),
-        // dd <= f0 + |f1| + |f2|, so t1 + t3 + rhs <= 2 dd_max + (w/2)^2.
-        bandc = 2.1e-9 * fma(2.0, f0 + (fabs(f1c) + fabs(f2c)), d.half_w2);
-        if (jlo < 0) jlo += d.n_phi;   // start column in [0, n_phi); the window then runs to < 2 n_phi
+      // the part of the window this lane walks in this pass: [start, start + len)
+      int start = 0, len = cnt;
+      if (CAPS && split != nullptr) {
+        if (pass == 0) {
+          const unsigned long long lm = __ballot(cnt > kSplitAt);
+          if (lm != 0ull && __ballot(cnt >= kSplitAt + 16) != 0ull) {
+            nlong = (int)__popcll(lm);
+            logq = nlong <= 8 ? 3 : (nlong <= 16 ? 2 : (nlong <= 32 ? 1 : 0));
+            if (logq > 0) {
+              npass = 2;
+              if (cnt > kSplitAt) {
+                const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(lm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)lm, 0u));
+                reinterpret_cast<volatile int*>(split)[rank] = i;
+                len = kSplitAt;
+              }
+              __builtin_amdgcn_wave_barrier();
+            }
+          }
+        } else {
+          const int rem = cnt - kSplitAt;                       // > 0: the row was listed because cnt > kSplitAt
+          const int chunk = (rem + (1 << logq) - 1) >> logq;
+          start = kSplitAt + part * chunk;
+          len = rem - part * chunk;
+          len = len < 0 ? 0 : (len > chunk ? chunk : len);
+          if (!have) len = 0;
+        }
       }
-    }
-    const ColX* cp = colx + jlo;
-    const uint32_t rowoff = (uint32_t)(i * d.n_phi) * 4u;
-    for (int k = 0;; ++k) {                    // until the widest window of the wave is done
-      const bool act = k < cnt;
-      if (__ballot(act) == 0ull) break;
-      bool hit = false;
-      uint32_t boff = 0;
-      if (act) {
-        const double cph = cp->c, sph = cp->s;
-        boff = rowoff + cp->off4;
-        cp++;
-        const double dot = fma(a1c, cph, fma(a2c, sph, a0c));
-        const double num = fma(b1c, cph, fma(b2c, sph, b0c));
-        const double m2dv = fma(e1c, cph, fma(e2c, sph, e0c));
-        const double ddw = fma(f1c, cph, fma(f2c, sph, f0c));
-        // sign of  dot^2 (dd - (w/2)^2) - 2 num dot dv + num^2  (|V| = 1 to rounding: Newton-renormalised)
-        const double diff = fma(dot, fma(dot, ddw, num * m2dv), num * num);
-        // evaluation error ~1e-15 of the terms' scale; bandc >= 2e-9 of that scale for every column of the row
-        // (an f32 version of this test was tried and rejected: its error grows like 1/|dot| and it
-        //  mis-decided 16 of 2.3e9 hits at 2e7 rays; f64 keeps >100x margin down to |dot| = 1e-4)
-        hit = diff < 0.0;
-        if (fabs(dot) < 1e-4 || fabs(diff) <= bandc)  // too close to call: exact reference-order test
-          hit = check_intersection(d.table + 6 * (size_t)(boff >> 2), d.half_w2, P, V);
-      }
-      if (hit) atomicAdd(reinterpret_cast<uint32_t*>(reinterpret_cast<unsigned char*>(hist) + boff), 1u);
+      ISX_DIAG_ADD(11, 1); if (pass == 1) ISX_DIAG_ADD(10, 1);
+      walk_columns(d, hist, colx, P, V, lane, i, Sd, Cd, zd, Ad, jlo, start, len, path);
     }
   }
 }
@@ -275,7 +351,7 @@ __device__ __forceinline__ RecPre prep_record(const GridConst& k, const V3& P, c
 template <class DG>
 __device__ inline void bin_culled(const DG& dd, uint32_t* __restrict__ hist,
                                       const double* __restrict__ rowt, const ColX* __restrict__ colx,
-                                      const V3 P, const V3 V, int lane) {
+                                      const V3 P, const V3 V, int lane, int* split = nullptr) {
   // one read of each constant (dd is a volatile LDS copy: nothing of it lives in SGPRs across the trace loop)
   struct { int n_theta, n_phi; double half_w2, rho_d, R, portz; const double* table; } d;
   d.n_theta = dd.n_theta; d.n_phi = dd.n_phi; d.half_w2 = dd.half_w2; d.rho_d = dd.rho_d; d.R = dd.R;
@@ -315,7 +391,7 @@ __device__ inline void bin_culled(const DG& dd, uint32_t* __restrict__ hist,
     // of the line inside the shell R +- rho_d: a centre within rho_d of the line point X = H + s V has
     // | |X-O| - R | <= rho_d, so s^2 <= (R+rho_d)^2 - dO^2, and its height differs from X's by at most rho_d, i.e.
     // z_i - O_z = -R cos(theta_i) lies in [hz - dz, hz + dz].  Same exact decision as in the cap case.
-    if (dO - rho > 1.001f * Rf) return;
+    if (dO - rho > 1.001f * Rf) { ISX_DIAG_ADD(3, 1); return; }
     const float sm = sqrt_cull(fmaxf(0.f, fmaf(Rf + rho, Rf + rho, -dO2))) * 1.001f;
     const float dz = fmaf(sm, fabsf((float)V.z), rho) * 1.001f + 1e-3f;
     const float iR = rcp_cull(Rf);
@@ -353,9 +429,11 @@ __device__ inline void bin_culled(const DG& dd, uint32_t* __restrict__ hist,
         }
       }
     }
-    walk_rows<false>(d, hist, rowt, colx, P, V, lane, ilo, ihi, w);
+    ISX_DIAG_ADD(2, 1);
+    walk_rows<false>(d, hist, rowt, colx, P, V, lane, ilo, ihi, w, nullptr, 2);
     return;
   }
+  ISX_DIAG_ADD(1, 1);
 #pragma unroll 1
   for (int side = 0; side < 2; ++side) {
     const double s = side == 0 ? ((double)sF - wv) : (-(double)sF - wv);
@@ -371,7 +449,7 @@ __device__ inline void bin_culled(const DG& dd, uint32_t* __restrict__ hist,
     const float thF = atan2_cull(w.AF, (float)d.portz - w.Fz);
     const int ilo = max((int)floorf((thF - omega) * inv_dth - 0.5f - 1e-3f), 0);
     const int ihi = min((int)ceilf((thF + omega) * inv_dth - 0.5f + 1e-3f), d.n_theta - 1);
-    walk_rows<true>(d, hist, rowt, colx, P, V, lane, ilo, ihi, w);
+    walk_rows<true>(d, hist, rowt, colx, P, V, lane, ilo, ihi, w, split, 1);
   }
 }
 
@@ -438,13 +516,26 @@ __device__ __forceinline__ int ray_arrive(const Hot& h, const G& g, Ray& r, uint
 // Chord-mode arrival: the lane holds a target point T in r.v.  Returns true if T is on the mirror patch (then
 // q = T, and r.v becomes the un-normalised last chord); false if T lies in the port opening (then r.v becomes
 // the unit direction P->T and the generic boundary search takes over).
-__device__ __forceinline__ bool chord_arrive(const Hot& h, Ray& r, V3& q) {
+__device__ __forceinline__ void chord_leave(Ray& r) {   // T lies in the port opening: unit direction P -> T
   V3 d;
   d.x = r.v.x - r.p.x; d.y = r.v.y - r.p.y; d.z = r.v.z - r.p.z;
-  r.tgt = false;
-  if (r.v.z >= h.zcut_in) { q = r.v; r.v = d; return true; }
   const double mag = sqrt(dot3(d, d));
   r.v.x = d.x / mag; r.v.y = d.y / mag; r.v.z = d.z / mag;
+  r.tgt = false;
+}
+// DEFER: the persistent kernels leave the lane as it is (r.tgt stays set, r.v keeps T) and form the direction when the
+// parked lanes are flushed -- the IEEE sqrt and three divides of chord_leave ran in ~36 % of all wave-steps for the 0.8 % of
+// the lanes that need them (chord mode was 2 % faster than explicit bounces, not the 10 % its shorter step promises).
+template <bool DEFER = false>
+__device__ __forceinline__ bool chord_arrive(const Hot& h, Ray& r, V3& q) {
+  if (r.v.z >= h.zcut_in) {
+    V3 d;
+    d.x = r.v.x - r.p.x; d.y = r.v.y - r.p.y; d.z = r.v.z - r.p.z;
+    r.tgt = false;
+    q = r.v; r.v = d;
+    return true;
+  }
+  if (!DEFER) chord_leave(r);
   return false;
 }
 
@@ -638,7 +729,7 @@ __device__ __forceinline__ void persistent_body(const Geom& g_arg, const DetGrid
     };
     // hot boundary search of one lane: true if it arrived on the inner mirror patch, else the lane parks
     auto hot_search = [&](V3& q, auto first) -> bool {
-      if (CH != 0 && r.tgt) return chord_arrive(h, r, q);
+      if (CH != 0 && r.tgt) return chord_arrive<true>(h, r, q);
       return next_hit_s1<decltype(first)::value>(h, g, r.p, r.v, r.on, q);
     };
     {
@@ -655,6 +746,7 @@ __device__ __forceinline__ void persistent_body(const Geom& g_arg, const DetGrid
         const bool flush = ((int)__popcll(pm) >= sched_min) || ((iter & (uint32_t)sched_mask) == (uint32_t)sched_mask) ||
                            (__ballot(run) == 0ull);
         if (flush && parked) {
+          if (CH != 0 && r.tgt) chord_leave(r);   // a chord whose end point lies in the port opening (chord_arrive<DEFER>)
           kind = next_hit_generic(g, r.p, r.v, r.on, q);
           arrived = true;
           parked = false;
@@ -783,6 +875,7 @@ __device__ __forceinline__ void persistent_body(const Geom& g_arg, const DetGrid
       // per-wave staging of the exit-line records in LDS (16 B + 4 B per lane, after the parameter blocks)
       float4* rec4 = nullptr;
       int* reci = nullptr;
+      int* spl = nullptr;
       if (fast && em) {
         // (offsets from `smem`, not pointer-to-integer casts: the accesses must stay ds_read/ds_write with 32-bit addresses)
         const uint32_t off_rec = ((uint32_t)(reinterpret_cast<unsigned char*>(d_lds + 1) - smem) + 15u) & ~15u;
@@ -793,6 +886,7 @@ __device__ __forceinline__ void persistent_body(const Geom& g_arg, const DetGrid
         asm volatile("" : "+v"(wslot));
         rec4 = base + wslot * 64u;
         reci = reinterpret_cast<int*>(base + kWavesPerBlock * 64) + wslot * 64u;
+        spl = reinterpret_cast<int*>(base + kWavesPerBlock * 64) + (kWavesPerBlock + wslot) * 64u;   // long-row list of walk_rows
         if (bin_me) {   // the exiting lanes prepare their own lines, all at once, and park the result in LDS
           GridConst k;
           k.Rf = (float)d.R; k.rho = (float)d.rho_d; k.portz = (float)d.portz; k.n_theta = d.n_theta;
@@ -825,9 +919,10 @@ __device__ __forceinline__ void persistent_body(const Geom& g_arg, const DetGrid
               CapWin wfast;
               wfast.inv_dphi = (float)dfast.n_phi * 0.15915494309f;
               wfast.Fz = q4.x; wfast.AF = q4.y; wfast.AF2 = q4.y * q4.y; wfast.jf = q4.z; wfast.ch2 = q4.w;
-              walk_rows<true>(dfast, hist, rowt, colx, P, V, lane, rows & 0xffff, rows >> 16, wfast);
+              ISX_DIAG_ADD(0, 1);
+              walk_rows<true>(dfast, hist, rowt, colx, P, V, lane, rows & 0xffff, rows >> 16, wfast, spl, 0);
             } else {
-              bin_culled(d, hist, rowt, colx, P, V, lane);
+              bin_culled(d, hist, rowt, colx, P, V, lane, spl);
             }
           }
           // bin_mode 2: diagnostic only (trace without binning; results are NOT a flux map)
@@ -854,9 +949,15 @@ __device__ __forceinline__ void persistent_body(const Geom& g_arg, const DetGrid
   }
   if (SINK != SINK_LOG && flushed) atomicAdd(&sstat[5], flushed);
   __syncthreads();
-  if (tid < 7) {
-    const unsigned long long c = sstat[tid];
-    if (c) atomicAdd(&wk.stats[tid], c);
+  {
+    // (the index is re-derived behind a compiler barrier: kept alive from the `sstat[tid] = 0` at the top of the kernel,
+    //  this one address cost a VGPR across the whole trace loop -- 8 B/lane of scratch at the 128-VGPR limit)
+    uint32_t t2 = threadIdx.x;
+    asm volatile("" : "+v"(t2));
+    if (t2 < 7u) {
+      const unsigned long long c = sstat[t2];
+      if (c) atomicAdd(&wk.stats[t2], c);
+    }
   }
 }
 

@@ -176,12 +176,12 @@ def _chi2(ref_hits, n_ref, our_hits, n_our):
 
 
 # What round 2 established about the residual against the reference's data (profiles/r02_parity_scan.md): with the
-# model of this build every one of the seven maps has chi2/dof <= 1.08 over ~16 000 bins, i.e. bin by bin the maps are
+# model of this build every one of the seven maps has chi2/dof <= 1.04 over ~16 000 bins, i.e. bin by bin the maps are
 # indistinguishable at the resolution of one 50 000-ray bin (3.6 %); summed over a map the total is 0.3-1.0 % low, a
 # smooth theta-only pattern (+1 % on axis, -1.5 % at 25-35 deg) that none of the inferred ROBAST behaviours removes and
 # that the reference's own single-threaded exit log does not show.  The windows below are that measured state: they fail
 # if the model moves away from the reference OR if somebody "improves" it without updating the record.
-CHI2_MAX = 1.12
+CHI2_MAX = 1.08
 TOTAL_WINDOW = (0.9870, 0.9990)
 
 

@@ -1,0 +1,28 @@
+"""Where the binning work goes (GPU box; needs variants/libisx_diag.so = libisx built with -DISX_DIAG):
+   ISX_LIB_PATH=variants/libisx_diag.so python tools/diag_binning.py"""
+import ctypes as C, json, os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import altair_raytracing_amd as isx
+L = isx.load(); isx.init(0)
+L.isx_diag_read.argtypes = [C.POINTER(C.c_uint64)]
+def diag():
+    a = (C.c_uint64 * 16)()
+    assert L.isx_diag_read(a) == 0
+    return np.array(a[:], dtype=np.uint64)
+def run(name, c, n):
+    diag()
+    h, st = isx.fluxmap(c, n, 5)
+    d = diag().astype(float)
+    lines = st.counted_below_z
+    out = {"lines": lines, "hits_per_line": st.bin_increments / lines,
+           "path_share": {"fast": d[0] / lines, "caps": d[1] / lines, "fallback": d[2] / lines, "miss": d[3] / lines},
+           "col_iterations_per_line": {"fast": d[4] / max(d[0], 1), "caps": d[5] / max(d[1], 1), "fallback": d[6] / max(d[2], 1)},
+           "candidates_per_line": {"fast": d[7] / max(d[0], 1), "caps": d[8] / max(d[1], 1), "fallback": d[9] / max(d[2], 1)},
+           "row_passes_per_line": d[11] / lines, "split_passes_per_line": d[10] / lines,
+           "lane_fill": {"fast": d[7] / max(d[4] * 64, 1), "caps": d[8] / max(d[5] * 64, 1), "fallback": d[9] / max(d[6] * 64, 1)}}
+    print(name, json.dumps(out, indent=1))
+c = isx.default_config()
+run("headline", c, 5_000_000)
+c.source_model = 1; c.roughness_rad = 0.5; c.reflectance = 1.0; c.max_points = 10000; c.box_half = 200.0
+run("brdf", c, 5_000_000)

@@ -38,7 +38,9 @@ typedef struct {
   int retry_into_wall; /* placeholder */
   int det_normal_mode; /* 0 reference quirk (-dy,dx,dz); 1 towards the port (dx,dy,dz)/mag */
   int port_test;       /* 0 last point z < port_z on the box; 1 every ray that leaves the shell downward */
-  int two_sided;       /* placeholder */
+  int two_sided;       /* 1: class exit rays by emission angle (invert.py) */
+  double replay_q;     /* model of a racy shared RNG: with this probability a bounce re-uses the PREVIOUS bounce's random numbers */
+  int replay_what;     /* 1 polar number only, 2 azimuth only, 3 both */
 } hyp_cfg;
 
 typedef struct {
@@ -134,6 +136,7 @@ static inline v3 normal_of(const geom* g, const hyp_cfg* c, int kind, v3 q) {
   return unit(n);
 }
 
+static __thread double last_u1 = 0.5, last_u2 = 0.5;
 static v3 emit(const hyp_cfg* c, v3 n, rng* r) {
   v3 a, b;
   double ct, st;
@@ -145,6 +148,8 @@ static v3 emit(const hyp_cfg* c, v3 n, rng* r) {
     }
   }
   double u1 = rng_u(r), u2 = rng_u(r);
+  if (c->replay_q > 0 && rng_u(r) < c->replay_q) { if (c->replay_what & 1) u1 = last_u1; if (c->replay_what & 2) u2 = last_u2; }
+  last_u1 = u1; last_u2 = u2;
   switch (c->law) {
     case 1: ct = u1; st = sqrt(1 - ct * ct); break;
     case 2: st = u1; ct = sqrt(1 - st * st); break;

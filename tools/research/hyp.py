@@ -20,6 +20,7 @@ class Cfg(C.Structure):
         ("rho_rim", C.c_double), ("outer", C.c_int), ("absorb_after", C.c_int), ("step_back", C.c_double),
         ("count_absorbed", C.c_int), ("hit_line", C.c_int), ("first_specular", C.c_int), ("rho_angle_k", C.c_double),
         ("retry_into_wall", C.c_int), ("det_normal_mode", C.c_int), ("port_test", C.c_int), ("two_sided", C.c_int),
+        ("replay_q", C.c_double), ("replay_what", C.c_int),
     ]
 
 
