@@ -37,6 +37,13 @@ struct State {
   unsigned long long* d_stats = nullptr;  // [8]
   double* d_aux = nullptr;                // caller-supplied detector / disc lists of the current call (grown, never shrunk)
   size_t cap_aux = 0;
+  // two-kernel pipeline of the headline flux map: exit lines in HBM (48 B per traced ray of a chunk) + lines per wave
+  double* d_rec = nullptr;
+  size_t cap_rec = 0;                     // rays
+  uint32_t* d_rec_counts = nullptr;
+  size_t cap_rec_counts = 0;              // waves
+  int pipeline = 0;                       // 1: trace kernel -> HBM -> binning kernel (lean flux map); 0 (default): fused kernel
+  uint64_t pipe_chunk = 1ull << 26;       // rays per trace/bin pair (3.2 GB of exit-line workspace at most)
   // options
   int bin_mode = 1;
   int blocks_per_cu = 1;   // 1024-thread blocks: 16 waves/CU, 4 per SIMD
@@ -224,6 +231,8 @@ int pick_grid(uint64_t n) {
   return want < (uint64_t)full ? (int)want : full;
 }
 
+int ensure_pipeline(size_t rays, size_t waves);
+
 // enqueue one persistent kernel accumulating into d_hist (device) and S.d_stats
 struct PerPos { uint64_t map_first = 0, rays_per_group = 0; int fold = 1; const double* d_table = nullptr; double width = 0; };
 struct LogSink { double* rec = nullptr; unsigned long long* count = nullptr; uint64_t cap = 0; };
@@ -323,6 +332,40 @@ int enqueue(int sink, const isx_config* c, uint64_t n, uint64_t seed, uint64_t f
     case SINK_DISCPOS: fn = lean_explicit ? isx_trace_discpos_lean_kernel : isx_trace_discpos_kernel; break;
     default: fn = lean_explicit ? isx_trace_log_lean_kernel : isx_trace_log_kernel; break;
   }
+  // ---- two-kernel pipeline (headline configuration): trace kernel -> exit lines in HBM -> binning kernel, chunk by chunk
+  if (sink == SINK_FLUX && lean_explicit && S.pipeline && d.rec_stage) {
+    const size_t lds_trace = 16 + 64 + sizeof(Geom) + sizeof(DetGrid);
+    const size_t lds_bin = (((size_t)d.nbins * 4 + 15) & ~(size_t)15) + (size_t)(4 * d.n_theta) * 8 + (size_t)(2 * d.n_phi) * sizeof(ColX) +
+                           sizeof(DetGrid) + (size_t)kWavesPerBlock * 64 * 4 + 16;
+    if (lds_bin <= S.lds_limit) {
+      const uint64_t chunk = n < S.pipe_chunk ? n : S.pipe_chunk;
+      const int cgrid = pick_grid(chunk);
+      rc = ensure_pipeline((size_t)chunk, (size_t)cgrid * kWavesPerBlock);
+      if (rc) { S.ev_used -= 2; return rc; }
+      HIPCHK(hipFuncSetAttribute((const void*)isx_trace_rec_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_trace));
+      HIPCHK(hipFuncSetAttribute((const void*)isx_bin_lines_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bin));
+      HIPCHK(hipEventRecord(e0, S.stream));
+      for (uint64_t off = 0; off < n; off += chunk) {
+        const uint64_t cnt = n - off < chunk ? n - off : chunk;
+        Work w2 = wk;
+        w2.first = first + off; w2.n = cnt;
+        const int g2 = pick_grid(cnt) < cgrid ? pick_grid(cnt) : cgrid;
+        DetGrid dt = d;              // the trace kernel keeps no histogram
+        dt.nbins = 1; dt.n_theta = 0; dt.n_phi = 0;
+        dt.rec_lines = S.d_rec; dt.rec_counts = S.d_rec_counts;
+        hipLaunchKernelGGL(isx_trace_rec_kernel, dim3(g2), dim3(kBlock), lds_trace, S.stream, g, dt, w2);
+        HIPCHK(hipGetLastError());
+        if (S.bin_mode != 2) {       // bin_mode 2: diagnostic, trace only
+          DetGrid db = d;
+          db.rec_lines = S.d_rec; db.rec_counts = S.d_rec_counts;
+          hipLaunchKernelGGL(isx_bin_lines_kernel, dim3(g2), dim3(kBlock), lds_bin, S.stream, db, w2);
+          HIPCHK(hipGetLastError());
+        }
+      }
+      HIPCHK(hipEventRecord(e1, S.stream));
+      return ISX_OK;
+    }
+  }
   HIPCHK(hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   HIPCHK(hipEventRecord(e0, S.stream));
   hipLaunchKernelGGL(fn, dim3(grid), dim3(kBlock), lds, S.stream, g, d, wk);
@@ -343,6 +386,25 @@ int upload_aux(const double* host, size_t n_doubles) {
   }
   HIPCHK(hipMemcpyAsync(S.d_aux, host, n_doubles * sizeof(double), hipMemcpyHostToDevice, S.stream));
   HIPCHK(hipStreamSynchronize(S.stream));   // `host` may be a temporary of the caller
+  return ISX_OK;
+}
+
+// workspace of the two-kernel pipeline for a chunk of `rays` rays traced by `waves` waves
+int ensure_pipeline(size_t rays, size_t waves) {
+  if (rays > S.cap_rec) {
+    HIPCHK(hipStreamSynchronize(S.stream));
+    if (S.d_rec) HIPCHK(hipFree(S.d_rec));
+    S.d_rec = nullptr; S.cap_rec = 0;
+    HIPCHK(hipMalloc(&S.d_rec, rays * 6 * sizeof(double)));
+    S.cap_rec = rays;
+  }
+  if (waves > S.cap_rec_counts) {
+    HIPCHK(hipStreamSynchronize(S.stream));
+    if (S.d_rec_counts) HIPCHK(hipFree(S.d_rec_counts));
+    S.d_rec_counts = nullptr; S.cap_rec_counts = 0;
+    HIPCHK(hipMalloc(&S.d_rec_counts, waves * sizeof(uint32_t)));
+    S.cap_rec_counts = waves;
+  }
   return ISX_OK;
 }
 
@@ -460,6 +522,9 @@ void isx_shutdown(void) {
   if (S.d_stats) (void)hipFree(S.d_stats);
   if (S.d_aux) (void)hipFree(S.d_aux);
   S.d_aux = nullptr; S.cap_aux = 0;
+  if (S.d_rec) (void)hipFree(S.d_rec);
+  if (S.d_rec_counts) (void)hipFree(S.d_rec_counts);
+  S.d_rec = nullptr; S.cap_rec = 0; S.d_rec_counts = nullptr; S.cap_rec_counts = 0;
   S.d_table = S.d_rowtab = S.d_coltab = nullptr;
   S.d_hist = S.d_stats = nullptr;
   S.cap_bins = S.cap_rows = S.cap_cols = S.cap_hist = 0;
@@ -483,6 +548,8 @@ int isx_set_option(const char* key, int64_t value) {
   if (!std::strcmp(key, "blocks_per_cu")) { if (value < 1 || value > 8) return ISX_ERR_BAD_ARG; S.blocks_per_cu = (int)value; return ISX_OK; }
   if (!std::strcmp(key, "sched_mask")) { if (value < 0 || value > 255) return ISX_ERR_BAD_ARG; S.sched_mask = (int)value; return ISX_OK; }
   if (!std::strcmp(key, "sched_min")) { if (value < 1 || value > 65) return ISX_ERR_BAD_ARG; S.sched_min = (int)value; return ISX_OK; }
+  if (!std::strcmp(key, "pipeline")) { if (value < 0 || value > 1) return ISX_ERR_BAD_ARG; S.pipeline = (int)value; return ISX_OK; }
+  if (!std::strcmp(key, "pipeline_chunk")) { if (value < 4096 || value > (1ll << 32)) return ISX_ERR_BAD_ARG; S.pipe_chunk = (uint64_t)value; return ISX_OK; }
   if (!std::strcmp(key, "grid_blocks")) { if (value < 0 || value > 65535) return ISX_ERR_BAD_ARG; S.grid_blocks = (int)value; return ISX_OK; }
   return ISX_ERR_BAD_ARG;
 }

@@ -46,6 +46,11 @@ struct DetGrid {
   // SINK_LOG: un-binned exit log (3dRayLog.txt): records {ray id, dx, dy, dz} = 32 B per counted ray,
   // the one sink with real HBM output.  log_count is the device-side cursor; records beyond log_cap are dropped
   // (the cursor still counts them, so the caller can tell).
+  // SINK_REC (two-kernel pipeline of the flux map): the exit line (last point, direction: 48 B) of every counted ray goes to
+  // HBM, into the slice of rec_lines that belongs to the wave's own ray range (slot = ray offset of the range + running
+  // count: no atomics, no overflow -- a wave cannot have more exits than rays); rec_counts[wave] = lines written.
+  double* rec_lines;             // [n rays of the launch][6]
+  uint32_t* rec_counts;          // [waves of the launch]
   double* log_rec;               // [log_cap][4]  (id bit-cast into the first double)
   unsigned long long* log_count;
   uint64_t log_cap;
@@ -64,7 +69,7 @@ __device__ unsigned long long g_diag[16];
 #define ISX_DIAG_ADD_LANES(k, v) do { } while (0)
 #endif
 
-enum : int { SINK_FLUX = 0, SINK_DZ = 1, SINK_DISC = 2, SINK_PERPOS = 3, SINK_LOG = 4, SINK_DISCPOS = 5 };
+enum : int { SINK_FLUX = 0, SINK_DZ = 1, SINK_DISC = 2, SINK_PERPOS = 3, SINK_LOG = 4, SINK_DISCPOS = 5, SINK_REC = 6 };
 
 struct Work {
   uint64_t seed, first, n;
@@ -123,7 +128,8 @@ __device__ __forceinline__ float atan2_cull(float y, float x) {
 struct __align__(16) ColX {
   double c, s;
   uint32_t off4;
-  uint32_t pad[3];
+  float c32, s32;   // the same cosine / sine rounded to binary32 (fast classifier of walk_columns)
+  uint32_t pad;
 };
 
 // acos in f32 for |x| <= 1, |error| < 1e-4 rad (Abramowitz & Stegun 4.4.45 on |x|, reflected for x < 0;
@@ -164,23 +170,44 @@ struct CapWin {            // what the row windows need:
 
 // Coefficients of row i for the line (P,V) and the walk over columns [jlo + start, jlo + start + len) of its window, with the
 // exact decision (shared by every row-to-lane mapping below).  jlo may be negative on entry (wrapped here).
+//
+// Three tiers per candidate, each handing on only what it cannot decide (the cheap ones never decide wrongly):
+//   1. binary32, packed: the four affine forms dot, num, -2dv, dd-(w/2)^2 in two v_pk_fma_f32 pairs and the sign of
+//      g = dot (dot (dd-(w/2)^2) - 2 num dv) + num^2  -- evaluated about the point Pq = P + t0 V of the SAME line that is nearest
+//      to the centre of the detector sphere (|Pq - c| <= ~125 cm instead of up to 350 from the world box, so the forms are 8x
+//      better conditioned).  Error bound: every coefficient, cosine and sine carries a relative rounding u = 2^-24 and a form is
+//      two fused operations, so |delta form| <= 5u M_form with M_form = |k0| + |k1| + |k2| >= max |form| over the row; through
+//      dg = (2 dot ddw + num dv') d(dot) + dot^2 d(ddw) + (dot dv' + 2 num) d(num) + dot num d(dv')  plus the three roundings of
+//      the evaluation of g itself:  |delta g| <= (15 + 3) u S,  S = Md (Md Mf + Mn Mv) + Mn^2  (one number per row).
+//      18u = 1.07e-6; the band is 1.3e-6 S.  |g32| > band32 decides; about 1e-3 of the candidates do not get that far.
+//   2. binary64: the same sign with the 2.1e-9 relative band of round 1 (coefficients derived again from the row constants --
+//      they are no longer resident, which frees 18 VGPRs);
+//   3. the reference's own operation sequence (check_intersection) from the detector table.
+// |dot32| < 2e-4 + 5u Md also leaves tier 1 (the reference rejects |dot| < 1e-10; tier 2 keeps its 1e-4 guard).
+typedef float isx_f2 __attribute__((ext_vector_type(2)));
 template <class D>
 __device__ __forceinline__ void walk_columns(const D& d, uint32_t* __restrict__ hist, const ColX* __restrict__ colx, const V3& P,
-                                             const V3& V, int lane, int i, double Sd, double Cd, double zd, double Ad, int jlo,
+                                             const V3& V, double t0, int lane, int i, const double* __restrict__ rowt, int jlo,
                                              int start, int len, int path) {
-  double a0c = 0, a1c = 0, a2c = 0, b0c = 0, b1c = 0, b2c = 0, e0c = 0, e1c = 0, e2c = 0, f0c = 0, f1c = 0, f2c = 0, bandc = 0;
+  isx_f2 k0a = {0.f, 0.f}, k1a = {0.f, 0.f}, k2a = {0.f, 0.f};   // (dot, num)
+  isx_f2 k0b = {0.f, 0.f}, k1b = {0.f, 0.f}, k2b = {0.f, 0.f};   // (-2 dv, dd - (w/2)^2)
+  float band32 = 0.f, dmin32 = 0.f;
   if (len > 0) {
-    const double pz = P.z - zd;
-    a0c = -(Cd * V.z); a1c = Sd * V.y; a2c = -(Sd * V.x);
-    b0c = -(Cd * pz);  b1c = Sd * P.y; b2c = -(Sd * P.x);
-    // e: -2 dv,  f: dd - (w/2)^2   (the factors the sign test needs, folded into the row constants)
-    e0c = -2.0 * fma(P.x, V.x, fma(P.y, V.y, pz * V.z)); e1c = 2.0 * (Ad * V.x); e2c = 2.0 * (Ad * V.y);
-    const double f0 = fma(P.x, P.x, fma(P.y, P.y, fma(Ad, Ad, pz * pz)));
-    f0c = f0 - d.half_w2; f1c = -2.0 * (Ad * P.x); f2c = -2.0 * (Ad * P.y);
-    // bound of 2e-9 (t1 + t3 + rhs) over every column of the row (t1 = dd dot^2, t3 = num^2, rhs = (w/2)^2 dot^2
-    // in the notation of the header comment): |dot| <= |V||n| = 1 and num^2 <= dd |n|^2 = dd (Cauchy-Schwarz),
-    // dd <= f0 + |f1| + |f2|, so t1 + t3 + rhs <= 2 dd_max + (w/2)^2.
-    bandc = 2.1e-9 * fma(2.0, f0 + (fabs(f1c) + fabs(f2c)), d.half_w2);
+    const double Sd = rowt[4 * i + 0], Cd = rowt[4 * i + 1], zd = rowt[4 * i + 2], Ad = rowt[4 * i + 3];
+    const double qx = fma(t0, V.x, P.x), qy = fma(t0, V.y, P.y), qz = fma(t0, V.z, P.z);   // Pq: same line, nearest to O
+    const double pz = qz - zd;
+    const double a0 = -(Cd * V.z), a1 = Sd * V.y, a2 = -(Sd * V.x);
+    const double b0 = -(Cd * pz), b1 = Sd * qy, b2 = -(Sd * qx);
+    const double e0 = -2.0 * fma(qx, V.x, fma(qy, V.y, pz * V.z)), e1 = 2.0 * (Ad * V.x), e2 = 2.0 * (Ad * V.y);
+    const double f0 = fma(qx, qx, fma(qy, qy, fma(Ad, Ad, pz * pz))) - d.half_w2, f1 = -2.0 * (Ad * qx), f2 = -2.0 * (Ad * qy);
+    k0a.x = (float)a0; k1a.x = (float)a1; k2a.x = (float)a2;
+    k0a.y = (float)b0; k1a.y = (float)b1; k2a.y = (float)b2;
+    k0b.x = (float)e0; k1b.x = (float)e1; k2b.x = (float)e2;
+    k0b.y = (float)f0; k1b.y = (float)f1; k2b.y = (float)f2;
+    const double Md = fabs(a0) + (fabs(a1) + fabs(a2)), Mn = fabs(b0) + (fabs(b1) + fabs(b2));
+    const double Mv = fabs(e0) + (fabs(e1) + fabs(e2)), Mf = fabs(f0) + (fabs(f1) + fabs(f2));
+    band32 = (float)(1.3e-6 * fma(Md, fma(Md, Mf, Mn * Mv), Mn * Mn)) * 1.000001f + 1e-30f;
+    dmin32 = (float)fma(3.0e-7, Md, 2.0e-4);
     if (jlo < 0) jlo += d.n_phi;   // start column in [0, n_phi); the window then runs to < 2 n_phi
   }
   const ColX* cp = colx + (jlo + start);
@@ -193,21 +220,48 @@ __device__ __forceinline__ void walk_columns(const D& d, uint32_t* __restrict__ 
     bool hit = false;
     uint32_t boff = 0;
     if (act) {
-      const double cph = cp->c, sph = cp->s;
+      const float c32 = cp->c32, s32 = cp->s32;
       boff = rowoff + cp->off4;
+      const isx_f2 cc = {c32, c32}, ss = {s32, s32};
+      const isx_f2 ta = __builtin_elementwise_fma(k1a, cc, __builtin_elementwise_fma(k2a, ss, k0a));   // (dot, num)
+      const isx_f2 tb = __builtin_elementwise_fma(k1b, cc, __builtin_elementwise_fma(k2b, ss, k0b));   // (-2dv, ddw)
+      const float g = fmaf(ta.x, fmaf(ta.x, tb.y, ta.y * tb.x), ta.y * ta.y);
+      hit = g < 0.f;
+      if (!(fabsf(g) > band32) || !(fabsf(ta.x) >= dmin32)) {
+        // tier 2: binary64 about the original point, exactly the test of round 1
+        ISX_DIAG_ADD_LANES(12, 1);
+        const double cph = cp->c, sph = cp->s;
+        // (the row constants are read again here, from the LDS row table and behind a compiler barrier: otherwise the twelve
+        //  binary64 coefficients below are hoisted out of the column loop as loop invariants and the kernel spills 59 VGPRs
+        //  to keep them next to the binary32 ones)
+        int ir = i;
+        asm volatile("" : "+v"(ir));
+        const double sd = rowt[4 * ir + 0], cd = rowt[4 * ir + 1], zz = rowt[4 * ir + 2], ad = rowt[4 * ir + 3];
+        const double pz = P.z - zz;
+        const double dot = fma(sd * V.y, cph, fma(-(sd * V.x), sph, -(cd * V.z)));
+        const double num = fma(sd * P.y, cph, fma(-(sd * P.x), sph, -(cd * pz)));
+        const double m2dv = fma(2.0 * (ad * V.x), cph, fma(2.0 * (ad * V.y), sph, -2.0 * fma(P.x, V.x, fma(P.y, V.y, pz * V.z))));
+        const double f0 = fma(P.x, P.x, fma(P.y, P.y, fma(ad, ad, pz * pz)));
+        const double f1c = -2.0 * (ad * P.x), f2c = -2.0 * (ad * P.y);
+        const double ddw = fma(f1c, cph, fma(f2c, sph, f0 - d.half_w2));
+        // sign of  dot^2 (dd - (w/2)^2) - 2 num dot dv + num^2  (|V| = 1 to rounding: Newton-renormalised);
+        // evaluation error ~1e-15 of the terms' scale, the band is 2.1e-9 (2 dd_max + (w/2)^2) >= 2e-9 of that scale:
+        // |dot| <= 1, num^2 <= dd (Cauchy-Schwarz), dd <= f0 + |f1| + |f2|
+        const double diff = fma(dot, fma(dot, ddw, num * m2dv), num * num);
+        const double bandc = 2.1e-9 * fma(2.0, f0 + (fabs(f1c) + fabs(f2c)), d.half_w2);
+        hit = diff < 0.0;
+        if (fabs(dot) < 1e-4 || fabs(diff) <= bandc) {   // tier 3: too close to call, exact reference-order test
+          ISX_DIAG_ADD_LANES(13, 1);
+          hit = check_intersection(d.table + 6 * (size_t)(boff >> 2), d.half_w2, P, V);
+        }
+      }
+#ifdef ISX_DIAG
+      {   // tuning builds: a decision taken by tier 1 must be the reference's
+        const bool ref = check_intersection(d.table + 6 * (size_t)(boff >> 2), d.half_w2, P, V);
+        if (ref != hit) ISX_DIAG_ADD_LANES(14, 1);
+      }
+#endif
       cp++;
-      const double dot = fma(a1c, cph, fma(a2c, sph, a0c));
-      const double num = fma(b1c, cph, fma(b2c, sph, b0c));
-      const double m2dv = fma(e1c, cph, fma(e2c, sph, e0c));
-      const double ddw = fma(f1c, cph, fma(f2c, sph, f0c));
-      // sign of  dot^2 (dd - (w/2)^2) - 2 num dot dv + num^2  (|V| = 1 to rounding: Newton-renormalised)
-      const double diff = fma(dot, fma(dot, ddw, num * m2dv), num * num);
-      // evaluation error ~1e-15 of the terms' scale; bandc >= 2e-9 of that scale for every column of the row
-      // (an f32 version of this test was tried and rejected: its error grows like 1/|dot| and it
-      //  mis-decided 16 of 2.3e9 hits at 2e7 rays; f64 keeps >100x margin down to |dot| = 1e-4)
-      hit = diff < 0.0;
-      if (fabs(dot) < 1e-4 || fabs(diff) <= bandc)  // too close to call: exact reference-order test
-        hit = check_intersection(d.table + 6 * (size_t)(boff >> 2), d.half_w2, P, V);
     }
     if (hit) atomicAdd(reinterpret_cast<uint32_t*>(reinterpret_cast<unsigned char*>(hist) + boff), 1u);
   }
@@ -231,6 +285,8 @@ template <bool CAPS, class D>
 __device__ __forceinline__ void walk_rows(const D& d, uint32_t* __restrict__ hist, const double* __restrict__ rowt,
                                           const ColX* __restrict__ colx, const V3& P, const V3& V, int lane, int ilo,
                                           int ihi, const CapWin& w, int* split = nullptr, int path = 0) {
+  // parameter of the point of the line nearest to O = (0,0,portz), the centre of the detector sphere (walk_columns)
+  const double t0 = -fma(P.x, V.x, fma(P.y, V.y, (P.z - d.portz) * V.z));
 #pragma unroll 1
   for (int i0 = ilo; i0 <= ihi; i0 += 64) {
     int npass = 1, logq = 0, nlong = 0;
@@ -297,7 +353,7 @@ __device__ __forceinline__ void walk_rows(const D& d, uint32_t* __restrict__ his
         }
       }
       ISX_DIAG_ADD(11, 1); if (pass == 1) ISX_DIAG_ADD(10, 1);
-      walk_columns(d, hist, colx, P, V, lane, i, Sd, Cd, zd, Ad, jlo, start, len, path);
+      walk_columns(d, hist, colx, P, V, t0, lane, i, rowt, jlo, start, len, path);
     }
   }
 }
@@ -650,7 +706,7 @@ __device__ __forceinline__ void persistent_body(const Geom& g_arg, const DetGrid
     for (int b = tid; b < 2 * d_arg.n_phi; b += kBlock) {
       const int j = b < d_arg.n_phi ? b : b - d_arg.n_phi;
       ColX e;
-      e.c = d_arg.coltab[2 * j]; e.s = d_arg.coltab[2 * j + 1]; e.off4 = (uint32_t)j * 4u; e.pad[0] = e.pad[1] = e.pad[2] = 0u;
+      e.c = d_arg.coltab[2 * j]; e.s = d_arg.coltab[2 * j + 1]; e.off4 = (uint32_t)j * 4u; e.c32 = (float)e.c; e.s32 = (float)e.s; e.pad = 0u;
       colx[b] = e;
     }
   }
@@ -691,6 +747,7 @@ __device__ __forceinline__ void persistent_body(const Geom& g_arg, const DetGrid
   uint32_t n_wall = 0;                                                           // per lane: mirror interactions of its finished rays
   uint32_t n_exited = 0, n_counted = 0, n_susp = 0, n_ended = 0;                 // per wave (ballot counts: scalar registers)
   unsigned long long n_inc = 0;                                                  // per wave (SINK_LOG; the histogram sinks count at flush)
+  uint32_t n_rec = 0;                                                            // per wave (SINK_REC): exit lines written so far
 
   for (;;) {
     // ---- refill dead lanes from this wave's range
@@ -812,6 +869,16 @@ __device__ __forceinline__ void persistent_body(const Geom& g_arg, const DetGrid
         }
         n_inc += (unsigned long long)__popcll(m);
       }
+    } else if (SINK == SINK_REC) {
+      const unsigned long long m = __ballot(bin_me);
+      if (m) {
+        if (bin_me) {
+          const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+          double2* dst = reinterpret_cast<double2*>(d_arg.rec_lines + 6ull * ((range_first - wk.first) + (uint64_t)(n_rec + rank)));
+          dst[0] = make_double2(r.p.x, r.p.y); dst[1] = make_double2(r.p.z, r.v.x); dst[2] = make_double2(r.v.y, r.v.z);
+        }
+        n_rec += (uint32_t)__popcll(m);
+      }
     } else if (SINK == SINK_PERPOS) {
       // per-lane: the ray's own detector group only (one or two exact tests)
       bool hit0 = false, hit1 = false;
@@ -914,8 +981,8 @@ __device__ __forceinline__ void persistent_body(const Geom& g_arg, const DetGrid
             const int rows = fast ? __builtin_amdgcn_readfirstlane(reci[src]) : -1;   // same address in every lane
             if (rows >= 0) {
               const float4 q4 = rec4[src];
-              struct { int n_phi; double half_w2; const double* table; } dfast;
-              dfast.n_phi = d.n_phi; dfast.half_w2 = d.half_w2; dfast.table = d.table;
+              struct { int n_phi; double half_w2, portz; const double* table; } dfast;
+              dfast.n_phi = d.n_phi; dfast.half_w2 = d.half_w2; dfast.portz = portz; dfast.table = d.table;
               CapWin wfast;
               wfast.inv_dphi = (float)dfast.n_phi * 0.15915494309f;
               wfast.Fz = q4.x; wfast.AF = q4.y; wfast.AF2 = q4.y * q4.y; wfast.jf = q4.z; wfast.ch2 = q4.w;
@@ -932,6 +999,8 @@ __device__ __forceinline__ void persistent_body(const Geom& g_arg, const DetGrid
   }
 
   // ---- census + histogram flush
+  if (SINK == SINK_REC && lane == 0)
+    d_arg.rec_counts[(uint64_t)blockIdx.x * kWavesPerBlock + (uint64_t)(tid >> 6)] = n_rec;
   atomicAdd(&sstat[6], (unsigned long long)n_wall);
   if (lane == 0) {
     atomicAdd(&sstat[1], (unsigned long long)n_exited);
@@ -989,10 +1058,106 @@ isx_trace_perpos_kernel(const Geom g, const DetGrid d, const Work wk) { persiste
 // the reference's main sweep (per-position maps) in the headline configuration: lean trace, one exact test per exiting ray
 extern "C" __global__ void ISX_KERNEL_ATTR
 isx_trace_perpos_lean_kernel(const Geom g, const DetGrid d, const Work wk) { persistent_body<SINK_PERPOS, true, 0>(g, d, wk); }
+// Two-kernel pipeline of the headline flux map: this kernel only traces and writes the exit lines (no histogram, no binning
+// state: 0 B of LDS histogram), isx_bin_lines_kernel bins them.
+extern "C" __global__ void ISX_KERNEL_ATTR
+isx_trace_rec_kernel(const Geom g, const DetGrid d, const Work wk) { persistent_body<SINK_REC, true, 0>(g, d, wk); }
 extern "C" __global__ void ISX_KERNEL_ATTR
 isx_trace_log_kernel(const Geom g, const DetGrid d, const Work wk) { persistent_body<SINK_LOG>(g, d, wk); }
 extern "C" __global__ void ISX_KERNEL_ATTR
 isx_trace_log_lean_kernel(const Geom g, const DetGrid d, const Work wk) { persistent_body<SINK_LOG, true, 0>(g, d, wk); }
+
+// ------------------------------------------------------------------ binning kernel of the two-kernel pipeline
+// Same launch shape as the trace kernel that filled rec_lines: wave w bins the lines of the trace wave w (slice of the ray
+// range, count in rec_counts[w]), 64 at a time: lane = line for the per-line preparation (prep_record), then every line is
+// broadcast and binned by the whole wave exactly as in the fused kernel (walk_rows / bin_culled: same cull, same exact
+// decision, so the histogram is the same).  No ray state lives here.
+#ifndef ISX_BIN_WAVES_PER_EU
+#define ISX_BIN_WAVES_PER_EU 4
+#endif
+extern "C" __global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(ISX_BIN_WAVES_PER_EU, ISX_BIN_WAVES_PER_EU)))
+isx_bin_lines_kernel(const DetGrid d_arg, const Work wk) {
+  extern __shared__ __align__(16) unsigned char smem[];
+  uint32_t* hist = reinterpret_cast<uint32_t*>(smem);
+  const int nbins = d_arg.nbins;
+  const size_t off_row = ((size_t)nbins * 4 + 15) & ~(size_t)15;
+  double* rowt = reinterpret_cast<double*>(smem + off_row);
+  ColX* colx = reinterpret_cast<ColX*>(rowt + 4 * d_arg.n_theta);
+  DetGrid* d_lds = reinterpret_cast<DetGrid*>(colx + 2 * d_arg.n_phi);
+  int* split_all = reinterpret_cast<int*>(d_lds + 1);
+  const int tid = threadIdx.x, lane = tid & 63;
+  for (int b = tid; b < nbins; b += kBlock) hist[b] = 0u;
+  for (int b = tid; b < 4 * d_arg.n_theta; b += kBlock) rowt[b] = d_arg.rowtab[b];
+  for (int b = tid; b < 2 * d_arg.n_phi; b += kBlock) {
+    const int j = b < d_arg.n_phi ? b : b - d_arg.n_phi;
+    ColX e;
+    e.c = d_arg.coltab[2 * j]; e.s = d_arg.coltab[2 * j + 1]; e.off4 = (uint32_t)j * 4u; e.c32 = (float)e.c; e.s32 = (float)e.s; e.pad = 0u;
+    colx[b] = e;
+  }
+  if (tid == 128) *d_lds = d_arg;
+  __syncthreads();
+  typedef __attribute__((address_space(3))) DetGrid LdsDetGrid;
+  const volatile LdsDetGrid& d = *(const volatile LdsDetGrid*)d_lds;
+  int* spl = split_all + (tid >> 6) * 64;
+
+  const uint64_t wave = (uint64_t)blockIdx.x * kWavesPerBlock + (uint64_t)(tid >> 6);
+  const uint64_t nwaves = (uint64_t)gridDim.x * kWavesPerBlock;
+  const uint64_t q = wk.n / nwaves, rem = wk.n % nwaves;
+  const uint64_t base = wave * q + (wave < rem ? wave : rem);   // ray offset of the wave's range = first slot of its slice
+  const uint32_t n_lines = d_arg.rec_counts[wave];
+  const double* rec = d_arg.rec_lines + 6ull * base;
+  GridConst k;
+  k.Rf = (float)d_arg.R; k.rho = (float)d_arg.rho_d; k.portz = (float)d_arg.portz; k.n_theta = d_arg.n_theta;
+  k.inv_dphi = (float)d_arg.n_phi * 0.15915494309f;
+  k.inv_dth = (float)k.n_theta * 0.63661977237f;
+  const int bin_mode = d_arg.bin_mode;
+#pragma unroll 1
+  for (uint32_t b0 = 0; b0 < n_lines; b0 += 64u) {
+    const bool have = b0 + (uint32_t)lane < n_lines;
+    V3 lp, lv;
+    lp.x = lp.y = lp.z = 0.0; lv.x = lv.y = 0.0; lv.z = -1.0;
+    RecPre pre;
+    pre.Fz = pre.AF = pre.jf = pre.ch2 = 0.f; pre.rows = -1;
+    if (have) {
+      const double2* src = reinterpret_cast<const double2*>(rec + 6ull * (b0 + (uint32_t)lane));
+      const double2 a = src[0], b = src[1], c = src[2];
+      lp.x = a.x; lp.y = a.y; lp.z = b.x; lv.x = b.y; lv.y = c.x; lv.z = c.y;
+      if (bin_mode == 1) pre = prep_record(k, lp, lv);
+    }
+    unsigned long long em = __ballot(have);
+    while (em) {
+      const int src = __builtin_ctzll(em);
+      em &= em - 1ull;
+      V3 P, V;
+      P.x = readlane_f64(lp.x, src); P.y = readlane_f64(lp.y, src); P.z = readlane_f64(lp.z, src);
+      V.x = readlane_f64(lv.x, src); V.y = readlane_f64(lv.y, src); V.z = readlane_f64(lv.z, src);
+      if (bin_mode == 0) { bin_brute(d, hist, P, V, lane); continue; }
+      const int rows = __builtin_amdgcn_readlane(pre.rows, src);
+      if (rows >= 0) {
+        struct { int n_phi; double half_w2, portz; const double* table; } dfast;
+        dfast.n_phi = d.n_phi; dfast.half_w2 = d.half_w2; dfast.portz = d_arg.portz; dfast.table = d.table;
+        CapWin wfast;
+        wfast.inv_dphi = k.inv_dphi;
+        wfast.Fz = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, pre.Fz), src));
+        wfast.AF = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, pre.AF), src));
+        wfast.AF2 = wfast.AF * wfast.AF;
+        wfast.jf = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, pre.jf), src));
+        wfast.ch2 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, pre.ch2), src));
+        ISX_DIAG_ADD(0, 1);
+        walk_rows<true>(dfast, hist, rowt, colx, P, V, lane, rows & 0xffff, rows >> 16, wfast, spl, 0);
+      } else {
+        bin_culled(d, hist, rowt, colx, P, V, lane, spl);
+      }
+    }
+  }
+  __syncthreads();
+  unsigned long long flushed = 0;
+  for (int b = tid; b < nbins; b += kBlock) {
+    const uint32_t c = hist[b];
+    if (c) { atomicAdd(&wk.hist[b], (unsigned long long)c); flushed += c; }
+  }
+  if (flushed) atomicAdd(&wk.stats[5], flushed);
+}
 
 // ------------------------------------------------------------------ per-ray end states (parity tests)
 extern "C" __global__ void __launch_bounds__(256)

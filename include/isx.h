@@ -168,7 +168,9 @@ void* isx_stream(void);
 
 /* Tuning/diagnostic switches.  "bin_mode": 1 (default) culled + classified binning,
  * 0 brute-force reference-order test of every detector position; "blocks_per_cu";
- * "grid_blocks" (0 = auto).  None of them changes any result. */
+ * "grid_blocks" (0 = auto); "pipeline" 0 (default) fused trace+bin kernel, 1 two kernels for the headline configuration:
+ * a trace kernel writes the exit lines (48 B per counted ray) to an HBM workspace, a binning kernel reads them
+ * ("pipeline_chunk" = rays per pair, default 2^26 = 3.2 GB of workspace).  None of them changes any result. */
 int isx_set_option(const char* key, int64_t value);
 
 /* Device-side probe of the numeric contract (tests): out[i] = op(a[i],b[i],c[i]) with

@@ -44,6 +44,35 @@ def test_refill_cursor_at_the_end_of_the_index_space(isx, orc):
         isx.set_option("grid_blocks", 0)
 
 
+def test_two_kernel_pipeline_equals_the_fused_kernel(isx, orc):
+    """isx_set_option("pipeline", 1): trace kernel -> exit lines in HBM -> binning kernel.  Same histogram and census as the fused
+    kernel (and as the oracle), also when the launch is cut into several trace/bin pairs and when the grid is tiny."""
+    c = isx.default_config()
+    ref, rst = isx.fluxmap(c, 3_000_000, SEED, 17)
+    try:
+        isx.set_option("pipeline", 1)
+        for chunk in (1 << 26, 1_000_000, 4096 * 100 + 1):
+            isx.set_option("pipeline_chunk", chunk)
+            h, st = isx.fluxmap(c, 3_000_000, SEED, 17)
+            assert np.array_equal(h, ref), chunk
+            _census_equal(st, rst)
+        isx.set_option("pipeline_chunk", 1 << 26)
+        gh, gst = isx.fluxmap(c, 30000, SEED)
+        oh, ost = orc.fluxmap(orc.default_config(), 30000, SEED)
+        assert np.array_equal(gh, oh)
+        _census_equal(gst, ost)
+        isx.set_option("grid_blocks", 1)
+        h1, st1 = isx.fluxmap(c, 50000, SEED, 5)
+        isx.set_option("grid_blocks", 0)
+        h2, st2 = isx.fluxmap(c, 50000, SEED, 5)
+        assert np.array_equal(h1, h2)
+        _census_equal(st1, st2)
+    finally:
+        isx.set_option("grid_blocks", 0)
+        isx.set_option("pipeline_chunk", 1 << 26)
+        isx.set_option("pipeline", 0)
+
+
 def test_config_of_another_abi_is_refused_on_the_device_path(isx):
     c = isx.default_config()
     c.struct_size = C.sizeof(isx.Config) - 8

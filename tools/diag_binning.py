@@ -20,9 +20,17 @@ def run(name, c, n):
            "col_iterations_per_line": {"fast": d[4] / max(d[0], 1), "caps": d[5] / max(d[1], 1), "fallback": d[6] / max(d[2], 1)},
            "candidates_per_line": {"fast": d[7] / max(d[0], 1), "caps": d[8] / max(d[1], 1), "fallback": d[9] / max(d[2], 1)},
            "row_passes_per_line": d[11] / lines, "split_passes_per_line": d[10] / lines,
+           "tier2_per_candidate": d[12] / max(d[7] + d[8] + d[9], 1), "tier3_per_candidate": d[13] / max(d[7] + d[8] + d[9], 1),
+           "WRONG_DECISIONS": int(d[14]), "candidates_total": int(d[7] + d[8] + d[9]),
            "lane_fill": {"fast": d[7] / max(d[4] * 64, 1), "caps": d[8] / max(d[5] * 64, 1), "fallback": d[9] / max(d[6] * 64, 1)}}
     print(name, json.dumps(out, indent=1))
 c = isx.default_config()
-run("headline", c, 5_000_000)
+run("headline", c, 20_000_000)
 c.source_model = 1; c.roughness_rad = 0.5; c.reflectance = 1.0; c.max_points = 10000; c.box_half = 200.0
-run("brdf", c, 5_000_000)
+run("brdf", c, 10_000_000)
+c = isx.default_config(); c.theta_max_deg = 160.0; c.dir[1] = 2.0
+run("port160", c, 10_000_000)
+c = isx.default_config(); c.n_theta, c.n_phi, c.det_diameter = 200, 180, 4.0
+run("grid200x180_4cm", c, 5_000_000)
+c = isx.default_config(); c.n_theta, c.n_phi, c.det_diameter, c.det_distance = 45, 20, 10.0, 100.0
+run("grid45x20_10cm", c, 10_000_000)
