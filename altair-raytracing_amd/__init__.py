@@ -14,11 +14,11 @@ from . import sharding  # noqa: F401
 from .sharding import shard, step_slice, fluxmap_sharded, disc_sweep_sharded  # noqa: F401
 from ._abi import (  # noqa: F401
     Config, Stats, IsxError, default_config, init, shutdown, device_info, set_option, fluxmap, fluxmap_device, sync,
-    take_stats, trace_endstates, disc_sweep, disc_sweep_per_position, exit_dz_hist, fluxmap_per_position, trace_rays_detector, exit_directions, fluxmap_series, detector_table, mathprobe, load, LIB_PATH, EXPORTS,
+    take_stats, last_kernel_ms, trace_endstates, disc_sweep, disc_sweep_per_position, exit_dz_hist, fluxmap_per_position, trace_rays_detector, exit_directions, fluxmap_series, detector_table, mathprobe, load, LIB_PATH, EXPORTS,
     SOURCE_PENCIL, SOURCE_BRDF, RAY_EXITED, RAY_ABSORBED, RAY_SUSPENDED,
 )
 
 __all__ = ["abi", "sharding", "shard", "step_slice", "fluxmap_sharded", "disc_sweep_sharded", "Config", "Stats", "IsxError", "default_config", "init", "shutdown", "device_info", "set_option",
-           "fluxmap", "fluxmap_device", "fluxmap_per_position", "trace_rays_detector", "exit_directions", "fluxmap_series", "sync", "take_stats", "trace_endstates", "disc_sweep", "disc_sweep_per_position", "exit_dz_hist",
+           "fluxmap", "fluxmap_device", "fluxmap_per_position", "trace_rays_detector", "exit_directions", "fluxmap_series", "sync", "take_stats", "last_kernel_ms", "trace_endstates", "disc_sweep", "disc_sweep_per_position", "exit_dz_hist",
            "detector_table", "mathprobe", "load", "LIB_PATH", "EXPORTS",
            "SOURCE_PENCIL", "SOURCE_BRDF", "RAY_EXITED", "RAY_ABSORBED", "RAY_SUSPENDED"]

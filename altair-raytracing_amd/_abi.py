@@ -31,7 +31,7 @@ EXPORTS = [
     "isx_device_info", "isx_fluxmap", "isx_fluxmap_device", "isx_sync", "isx_take_stats", "isx_stream",
     "isx_set_option", "isx_mathprobe", "isx_trace_endstates", "isx_disc_sweep", "isx_detector_table",
     "isx_exit_dz_hist", "isx_fluxmap_per_position", "isx_trace_rays_detector", "isx_exit_directions",
-    "isx_fluxmap_series", "isx_disc_sweep_per_position",
+    "isx_fluxmap_series", "isx_disc_sweep_per_position", "isx_last_kernel_ms",
 ]
 
 
@@ -106,6 +106,7 @@ def load():
     L.isx_trace_endstates.argtypes = [P(Config), u64, u64, u64, P(i32), P(i32), P(dbl), P(dbl)]
     L.isx_disc_sweep.argtypes = [P(Config), P(dbl), i32, dbl, dbl, u64, u64, u64, P(u64), P(Stats)]
     L.isx_disc_sweep_per_position.argtypes = [P(Config), P(dbl), i32, dbl, dbl, u64, u64, u64, P(u64), P(Stats)]
+    L.isx_last_kernel_ms.argtypes = [P(dbl), P(dbl), P(dbl)]
     L.isx_detector_table.argtypes = [P(Config), P(dbl)]
     L.isx_exit_dz_hist.argtypes = [P(Config), u64, u64, u64, i32, P(u64), P(Stats)]
     L.isx_fluxmap_per_position.argtypes = [P(Config), u64, i32, u64, u64, u64, u64, P(u64), P(Stats)]
@@ -194,6 +195,13 @@ def disc_sweep(cfg, centers_axes, radius, half_thick, n_rays, seed, first_ray=0)
     _chk(load().isx_disc_sweep(C.byref(cfg), _p(ca, C.c_double), nd, float(radius), float(half_thick), int(n_rays),
                                int(seed), int(first_ray), _p(hits, C.c_uint64), C.byref(st)), "isx_disc_sweep")
     return hits, st
+
+
+def last_kernel_ms():
+    """(single, trace, bin) HIP-event milliseconds of the launches collected by the last blocking call / take_stats()."""
+    a, b, c = C.c_double(), C.c_double(), C.c_double()
+    _chk(load().isx_last_kernel_ms(C.byref(a), C.byref(b), C.byref(c)), "isx_last_kernel_ms")
+    return a.value, b.value, c.value
 
 
 def disc_sweep_per_position(cfg, centers_axes, radius, half_thick, rays_per_position, seed, first_ray=0):

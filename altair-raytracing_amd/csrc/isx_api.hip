@@ -42,7 +42,7 @@ struct State {
   size_t cap_rec = 0;                     // rays
   uint32_t* d_rec_counts = nullptr;
   size_t cap_rec_counts = 0;              // waves
-  int pipeline = 0;                       // 1: trace kernel -> HBM -> binning kernel (lean flux map); 0 (default): fused kernel
+  int pipeline = 1;                       // 1 (default): trace kernel -> HBM -> binning kernel (lean flux map); 0: fused kernel
   uint64_t pipe_chunk = 1ull << 26;       // rays per trace/bin pair (3.2 GB of exit-line workspace at most)
   // options
   int bin_mode = 1;
@@ -52,6 +52,10 @@ struct State {
   // timing of enqueued-but-not-collected launches
   std::vector<hipEvent_t> ev_pool;
   size_t ev_used = 0;
+  struct Span { size_t a, b; int kind; };   // kind 0: single-kernel launch, 1: trace kernel of the pipeline, 2: its binning kernel
+  std::vector<Span> spans;
+  double last_ms[3] = {0, 0, 0};           // per kind, of the launches collected by the last collect_stats()
+  int trace_block = 512, trace_blocks_per_cu = 4;   // workgroup shape of the kernels that keep no LDS histogram (6 waves/SIMD)
 } S;
 
 // Scratch device allocation of one call: freed on every return path.
@@ -222,11 +226,11 @@ int get_event(hipEvent_t* ev) {
   return ISX_OK;
 }
 
-int pick_grid(uint64_t n) {
+int pick_grid(uint64_t n, int block = kBlock, int blocks_per_cu = 0) {
   if (S.grid_blocks > 0) return S.grid_blocks;
-  const int full = S.cu_count * S.blocks_per_cu;
+  const int full = S.cu_count * (blocks_per_cu > 0 ? blocks_per_cu : S.blocks_per_cu);
   // keep >= 16 rays per lane so the refill loop has something to refill from
-  const uint64_t want = (n + (uint64_t)kBlock * 16 - 1) / ((uint64_t)kBlock * 16);
+  const uint64_t want = (n + (uint64_t)block * 16 - 1) / ((uint64_t)block * 16);
   if (want < 1) return 1;
   return want < (uint64_t)full ? (int)want : full;
 }
@@ -308,13 +312,6 @@ int enqueue(int sink, const isx_config* c, uint64_t n, uint64_t seed, uint64_t f
   if (n == 0) return ISX_OK;
   Work wk;
   wk.seed = seed; wk.first = first; wk.n = n; wk.hist = d_hist; wk.stats = d_stats ? d_stats : S.d_stats;
-  const int grid = pick_grid(n);
-  // a block counts in 32-bit LDS bins: at most 2^32-1 rays per block; a wave addresses its rays by 31-bit offsets
-  if ((n + (uint64_t)grid - 1) / (uint64_t)grid > 0xffffffffull) return ISX_ERR_TOO_LARGE;
-  if (n / ((uint64_t)grid * kWavesPerBlock) >= 0x7fffffffull) return ISX_ERR_TOO_LARGE;
-  hipEvent_t e0, e1;
-  rc = get_event(&e0); if (rc) return rc;
-  rc = get_event(&e1); if (rc) { S.ev_used--; return rc; }   // events are consumed in pairs
   // the lean kernel serves the headline configuration; anything else takes the full-featured variant
   const bool lean_surface = c->lambertian && c->surface_model == ISX_SURFACE_ROBAST && c->hit_line_mode == ISX_HITLINE_LAST_SEGMENT;
   const bool lean = lean_surface && c->source_model == ISX_SOURCE_PENCIL;
@@ -332,46 +329,73 @@ int enqueue(int sink, const isx_config* c, uint64_t n, uint64_t seed, uint64_t f
     case SINK_DISCPOS: fn = lean_explicit ? isx_trace_discpos_lean_kernel : isx_trace_discpos_kernel; break;
     default: fn = lean_explicit ? isx_trace_log_lean_kernel : isx_trace_log_kernel; break;
   }
+  // Workgroup shape.  The kernels that keep the 64.8 KB LDS histogram run one 1024-thread workgroup per CU (4 waves per SIMD,
+  // 128 VGPRs).  The lean trace-only kernels need 75-90 VGPRs and almost no LDS: as 512-thread workgroups, four to a CU, they
+  // reach 6 waves per SIMD (measured: 18.8 -> 17.5 ms for 5e7 rays, 299 -> 282 ms for the 8.1e8-ray per-position map).
+  const bool small = lean_explicit && (sink == SINK_PERPOS || sink == SINK_DISCPOS || sink == SINK_DZ || sink == SINK_LOG);
+  const int block = small ? S.trace_block : kBlock;
+  const int bpc = small ? S.trace_blocks_per_cu : 0;
+  auto span = [&](int kind, hipEvent_t* first_ev) -> int {   // [previous event, new event) is one kernel of `kind`
+    hipEvent_t e;
+    if (first_ev) { int r = get_event(first_ev); if (r) return r; HIPCHK(hipEventRecord(*first_ev, S.stream)); return ISX_OK; }
+    int r = get_event(&e); if (r) return r;
+    HIPCHK(hipEventRecord(e, S.stream));
+    S.spans.push_back({S.ev_used - 2, S.ev_used - 1, kind});
+    return ISX_OK;
+  };
+  hipEvent_t e0;
   // ---- two-kernel pipeline (headline configuration): trace kernel -> exit lines in HBM -> binning kernel, chunk by chunk
-  if (sink == SINK_FLUX && lean_explicit && S.pipeline && d.rec_stage) {
+  if (sink == SINK_FLUX && lean_explicit && S.pipeline && S.bin_mode != 0) {
+    const int pblock = S.trace_block, pwaves = pblock / 64;
     const size_t lds_trace = 16 + 64 + sizeof(Geom) + sizeof(DetGrid);
     const size_t lds_bin = (((size_t)d.nbins * 4 + 15) & ~(size_t)15) + (size_t)(4 * d.n_theta) * 8 + (size_t)(2 * d.n_phi) * sizeof(ColX) +
-                           sizeof(DetGrid) + (size_t)kWavesPerBlock * 64 * 4 + 16;
+                           sizeof(DetGrid) + (size_t)pwaves * 64 * 4 + 16;
     if (lds_bin <= S.lds_limit) {
       const uint64_t chunk = n < S.pipe_chunk ? n : S.pipe_chunk;
-      const int cgrid = pick_grid(chunk);
-      rc = ensure_pipeline((size_t)chunk, (size_t)cgrid * kWavesPerBlock);
-      if (rc) { S.ev_used -= 2; return rc; }
+      const int cgrid = pick_grid(chunk, pblock, S.trace_blocks_per_cu);
+      // same rule as the single-kernel launches (isx.h): at most 2^32-1 rays of one call per workgroup, 2^31-1 per wave
+      {
+        const int ngrid = pick_grid(n, pblock, S.trace_blocks_per_cu);
+        if ((n + (uint64_t)ngrid - 1) / (uint64_t)ngrid > 0xffffffffull) return ISX_ERR_TOO_LARGE;
+      }
+      if (chunk / ((uint64_t)cgrid * pwaves) >= 0x7fffffffull) return ISX_ERR_TOO_LARGE;
+      rc = ensure_pipeline((size_t)chunk, (size_t)cgrid * pwaves);
+      if (rc) return rc;
       HIPCHK(hipFuncSetAttribute((const void*)isx_trace_rec_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_trace));
       HIPCHK(hipFuncSetAttribute((const void*)isx_bin_lines_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bin));
-      HIPCHK(hipEventRecord(e0, S.stream));
+      rc = span(0, &e0); if (rc) return rc;
       for (uint64_t off = 0; off < n; off += chunk) {
         const uint64_t cnt = n - off < chunk ? n - off : chunk;
         Work w2 = wk;
         w2.first = first + off; w2.n = cnt;
-        const int g2 = pick_grid(cnt) < cgrid ? pick_grid(cnt) : cgrid;
+        const int gc = pick_grid(cnt, pblock, S.trace_blocks_per_cu);
+        const int g2 = gc < cgrid ? gc : cgrid;
         DetGrid dt = d;              // the trace kernel keeps no histogram
         dt.nbins = 1; dt.n_theta = 0; dt.n_phi = 0;
         dt.rec_lines = S.d_rec; dt.rec_counts = S.d_rec_counts;
-        hipLaunchKernelGGL(isx_trace_rec_kernel, dim3(g2), dim3(kBlock), lds_trace, S.stream, g, dt, w2);
+        hipLaunchKernelGGL(isx_trace_rec_kernel, dim3(g2), dim3(pblock), lds_trace, S.stream, g, dt, w2);
         HIPCHK(hipGetLastError());
+        rc = span(1, nullptr); if (rc) return rc;
         if (S.bin_mode != 2) {       // bin_mode 2: diagnostic, trace only
           DetGrid db = d;
           db.rec_lines = S.d_rec; db.rec_counts = S.d_rec_counts;
-          hipLaunchKernelGGL(isx_bin_lines_kernel, dim3(g2), dim3(kBlock), lds_bin, S.stream, db, w2);
+          hipLaunchKernelGGL(isx_bin_lines_kernel, dim3(g2), dim3(pblock), lds_bin, S.stream, db, w2);   // same shape: wave w bins what wave w traced
           HIPCHK(hipGetLastError());
+          rc = span(2, nullptr); if (rc) return rc;
         }
       }
-      HIPCHK(hipEventRecord(e1, S.stream));
       return ISX_OK;
     }
   }
+  const int grid = pick_grid(n, block, bpc);
+  // a block counts in 32-bit LDS bins: at most 2^32-1 rays per block; a wave addresses its rays by 31-bit offsets
+  if ((n + (uint64_t)grid - 1) / (uint64_t)grid > 0xffffffffull) return ISX_ERR_TOO_LARGE;
+  if (n / ((uint64_t)grid * (uint64_t)(block / 64)) >= 0x7fffffffull) return ISX_ERR_TOO_LARGE;
   HIPCHK(hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  HIPCHK(hipEventRecord(e0, S.stream));
-  hipLaunchKernelGGL(fn, dim3(grid), dim3(kBlock), lds, S.stream, g, d, wk);
+  rc = span(0, &e0); if (rc) return rc;
+  hipLaunchKernelGGL(fn, dim3(grid), dim3(block), lds, S.stream, g, d, wk);
   HIPCHK(hipGetLastError());
-  HIPCHK(hipEventRecord(e1, S.stream));
-  return ISX_OK;
+  return span(0, nullptr);
 }
 
 // device copy of a caller's detector / disc list in the pooled buffer (no hipMalloc/hipFree per call)
@@ -421,11 +445,14 @@ int ensure_hist(size_t nb) {
 int collect_stats(isx_stats* out) {
   HIPCHK(hipStreamSynchronize(S.stream));
   double ms = 0;
-  for (size_t k = 0; k + 1 < S.ev_used; k += 2) {
+  S.last_ms[0] = S.last_ms[1] = S.last_ms[2] = 0;
+  for (const State::Span& sp : S.spans) {
     float t = 0;
-    HIPCHK(hipEventElapsedTime(&t, S.ev_pool[k], S.ev_pool[k + 1]));
+    HIPCHK(hipEventElapsedTime(&t, S.ev_pool[sp.a], S.ev_pool[sp.b]));
     ms += t;
+    S.last_ms[sp.kind] += t;
   }
+  S.spans.clear();
   S.ev_used = 0;
   unsigned long long h[8];
   HIPCHK(hipMemcpy(h, S.d_stats, sizeof(h), hipMemcpyDeviceToHost));
@@ -515,6 +542,7 @@ void isx_shutdown(void) {
   for (hipEvent_t e : S.ev_pool) (void)hipEventDestroy(e);
   S.ev_pool.clear();
   S.ev_used = 0;
+  S.spans.clear();
   if (S.d_table) (void)hipFree(S.d_table);
   if (S.d_rowtab) (void)hipFree(S.d_rowtab);
   if (S.d_coltab) (void)hipFree(S.d_coltab);
@@ -548,6 +576,8 @@ int isx_set_option(const char* key, int64_t value) {
   if (!std::strcmp(key, "blocks_per_cu")) { if (value < 1 || value > 8) return ISX_ERR_BAD_ARG; S.blocks_per_cu = (int)value; return ISX_OK; }
   if (!std::strcmp(key, "sched_mask")) { if (value < 0 || value > 255) return ISX_ERR_BAD_ARG; S.sched_mask = (int)value; return ISX_OK; }
   if (!std::strcmp(key, "sched_min")) { if (value < 1 || value > 65) return ISX_ERR_BAD_ARG; S.sched_min = (int)value; return ISX_OK; }
+  if (!std::strcmp(key, "trace_blocks_per_cu")) { if (value < 1 || value > 8) return ISX_ERR_BAD_ARG; S.trace_blocks_per_cu = (int)value; return ISX_OK; }
+  if (!std::strcmp(key, "trace_block")) { if (value != 256 && value != 512 && value != 1024) return ISX_ERR_BAD_ARG; S.trace_block = (int)value; return ISX_OK; }
   if (!std::strcmp(key, "pipeline")) { if (value < 0 || value > 1) return ISX_ERR_BAD_ARG; S.pipeline = (int)value; return ISX_OK; }
   if (!std::strcmp(key, "pipeline_chunk")) { if (value < 4096 || value > (1ll << 32)) return ISX_ERR_BAD_ARG; S.pipe_chunk = (uint64_t)value; return ISX_OK; }
   if (!std::strcmp(key, "grid_blocks")) { if (value < 0 || value > 65535) return ISX_ERR_BAD_ARG; S.grid_blocks = (int)value; return ISX_OK; }
@@ -555,6 +585,14 @@ int isx_set_option(const char* key, int64_t value) {
 }
 
 void* isx_stream(void) { return (void*)S.stream; }
+
+int isx_last_kernel_ms(double* single_ms, double* trace_ms, double* bin_ms) {
+  if (!S.init) return ISX_ERR_NOT_INIT;
+  if (single_ms) *single_ms = S.last_ms[0];
+  if (trace_ms) *trace_ms = S.last_ms[1];
+  if (bin_ms) *bin_ms = S.last_ms[2];
+  return ISX_OK;
+}
 
 int isx_sync(void) {
   if (!S.init) return ISX_ERR_NOT_INIT;

@@ -700,10 +700,13 @@ __device__ __forceinline__ void persistent_body(const Geom& g_arg, const DetGrid
   DetGrid* d_lds = reinterpret_cast<DetGrid*>(g_lds + 1);
 
   const int tid = threadIdx.x;
-  for (int b = tid; b < nbins; b += kBlock) hist[b] = 0u;
+  // the workgroup size is the launch's (1024 threads for the kernels that keep the LDS histogram, 512 for the trace-only ones,
+  // which then fit 6 waves per SIMD: isx_api.hip block_for())
+  const int nthr = (int)blockDim.x, wpb = nthr >> 6;
+  for (int b = tid; b < nbins; b += nthr) hist[b] = 0u;
   if (SINK == SINK_FLUX) {
-    for (int b = tid; b < 4 * d_arg.n_theta; b += kBlock) rowt[b] = d_arg.rowtab[b];
-    for (int b = tid; b < 2 * d_arg.n_phi; b += kBlock) {
+    for (int b = tid; b < 4 * d_arg.n_theta; b += nthr) rowt[b] = d_arg.rowtab[b];
+    for (int b = tid; b < 2 * d_arg.n_phi; b += nthr) {
       const int j = b < d_arg.n_phi ? b : b - d_arg.n_phi;
       ColX e;
       e.c = d_arg.coltab[2 * j]; e.s = d_arg.coltab[2 * j + 1]; e.off4 = (uint32_t)j * 4u; e.c32 = (float)e.c; e.s32 = (float)e.s; e.pad = 0u;
@@ -725,8 +728,8 @@ __device__ __forceinline__ void persistent_body(const Geom& g_arg, const DetGrid
   const int lane = tid & 63;
   uint64_t next, end;
   {
-    const uint64_t wave = (uint64_t)blockIdx.x * kWavesPerBlock + (uint64_t)(tid >> 6);
-    const uint64_t nwaves = (uint64_t)gridDim.x * kWavesPerBlock;
+    const uint64_t wave = (uint64_t)blockIdx.x * (uint64_t)wpb + (uint64_t)(tid >> 6);
+    const uint64_t nwaves = (uint64_t)gridDim.x * (uint64_t)wpb;
     // contiguous ray range of this wave: [next,end)
     const uint64_t q = wk.n / nwaves, rem = wk.n % nwaves;
     next = wk.first + wave * q + (wave < rem ? wave : rem);
@@ -952,8 +955,8 @@ __device__ __forceinline__ void persistent_body(const Geom& g_arg, const DetGrid
         uint32_t wslot = (uint32_t)tid >> 6;
         asm volatile("" : "+v"(wslot));
         rec4 = base + wslot * 64u;
-        reci = reinterpret_cast<int*>(base + kWavesPerBlock * 64) + wslot * 64u;
-        spl = reinterpret_cast<int*>(base + kWavesPerBlock * 64) + (kWavesPerBlock + wslot) * 64u;   // long-row list of walk_rows
+        reci = reinterpret_cast<int*>(base + wpb * 64) + wslot * 64u;
+        spl = reinterpret_cast<int*>(base + wpb * 64) + ((uint32_t)wpb + wslot) * 64u;   // long-row list of walk_rows
         if (bin_me) {   // the exiting lanes prepare their own lines, all at once, and park the result in LDS
           GridConst k;
           k.Rf = (float)d.R; k.rho = (float)d.rho_d; k.portz = (float)d.portz; k.n_theta = d.n_theta;
@@ -1000,7 +1003,7 @@ __device__ __forceinline__ void persistent_body(const Geom& g_arg, const DetGrid
 
   // ---- census + histogram flush
   if (SINK == SINK_REC && lane == 0)
-    d_arg.rec_counts[(uint64_t)blockIdx.x * kWavesPerBlock + (uint64_t)(tid >> 6)] = n_rec;
+    d_arg.rec_counts[(uint64_t)blockIdx.x * (uint64_t)wpb + (uint64_t)(tid >> 6)] = n_rec;
   atomicAdd(&sstat[6], (unsigned long long)n_wall);
   if (lane == 0) {
     atomicAdd(&sstat[1], (unsigned long long)n_exited);
@@ -1012,7 +1015,7 @@ __device__ __forceinline__ void persistent_body(const Geom& g_arg, const DetGrid
   }
   __syncthreads();
   unsigned long long flushed = 0;   // increments of this block = sum of its LDS bins
-  for (int b = tid; b < nbins; b += kBlock) {
+  for (int b = tid; b < nbins; b += nthr) {
     const uint32_t c = hist[b];
     if (c) { atomicAdd(&wk.hist[b], (unsigned long long)c); flushed += c; }
   }
@@ -1086,9 +1089,10 @@ isx_bin_lines_kernel(const DetGrid d_arg, const Work wk) {
   DetGrid* d_lds = reinterpret_cast<DetGrid*>(colx + 2 * d_arg.n_phi);
   int* split_all = reinterpret_cast<int*>(d_lds + 1);
   const int tid = threadIdx.x, lane = tid & 63;
-  for (int b = tid; b < nbins; b += kBlock) hist[b] = 0u;
-  for (int b = tid; b < 4 * d_arg.n_theta; b += kBlock) rowt[b] = d_arg.rowtab[b];
-  for (int b = tid; b < 2 * d_arg.n_phi; b += kBlock) {
+  const int nthr = (int)blockDim.x, wpb = nthr >> 6;   // launched with the trace kernel's shape
+  for (int b = tid; b < nbins; b += nthr) hist[b] = 0u;
+  for (int b = tid; b < 4 * d_arg.n_theta; b += nthr) rowt[b] = d_arg.rowtab[b];
+  for (int b = tid; b < 2 * d_arg.n_phi; b += nthr) {
     const int j = b < d_arg.n_phi ? b : b - d_arg.n_phi;
     ColX e;
     e.c = d_arg.coltab[2 * j]; e.s = d_arg.coltab[2 * j + 1]; e.off4 = (uint32_t)j * 4u; e.c32 = (float)e.c; e.s32 = (float)e.s; e.pad = 0u;
@@ -1100,8 +1104,8 @@ isx_bin_lines_kernel(const DetGrid d_arg, const Work wk) {
   const volatile LdsDetGrid& d = *(const volatile LdsDetGrid*)d_lds;
   int* spl = split_all + (tid >> 6) * 64;
 
-  const uint64_t wave = (uint64_t)blockIdx.x * kWavesPerBlock + (uint64_t)(tid >> 6);
-  const uint64_t nwaves = (uint64_t)gridDim.x * kWavesPerBlock;
+  const uint64_t wave = (uint64_t)blockIdx.x * (uint64_t)wpb + (uint64_t)(tid >> 6);
+  const uint64_t nwaves = (uint64_t)gridDim.x * (uint64_t)wpb;
   const uint64_t q = wk.n / nwaves, rem = wk.n % nwaves;
   const uint64_t base = wave * q + (wave < rem ? wave : rem);   // ray offset of the wave's range = first slot of its slice
   const uint32_t n_lines = d_arg.rec_counts[wave];
@@ -1152,7 +1156,7 @@ isx_bin_lines_kernel(const DetGrid d_arg, const Work wk) {
   }
   __syncthreads();
   unsigned long long flushed = 0;
-  for (int b = tid; b < nbins; b += kBlock) {
+  for (int b = tid; b < nbins; b += nthr) {
     const uint32_t c = hist[b];
     if (c) { atomicAdd(&wk.hist[b], (unsigned long long)c); flushed += c; }
   }

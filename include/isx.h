@@ -165,12 +165,16 @@ int isx_sync(void);
 int isx_take_stats(isx_stats* stats);
 /* The hipStream_t the library launches on (so callers can order work after it). */
 void* isx_stream(void);
+/* HIP-event times (ms) of the kernels collected by the last blocking call / isx_take_stats(), by kind: single-kernel
+ * launches, the trace kernel of the two-kernel flux-map pipeline, its binning kernel.  Any pointer may be NULL. */
+int isx_last_kernel_ms(double* single_ms, double* trace_ms, double* bin_ms);
 
 /* Tuning/diagnostic switches.  "bin_mode": 1 (default) culled + classified binning,
  * 0 brute-force reference-order test of every detector position; "blocks_per_cu";
- * "grid_blocks" (0 = auto); "pipeline" 0 (default) fused trace+bin kernel, 1 two kernels for the headline configuration:
- * a trace kernel writes the exit lines (48 B per counted ray) to an HBM workspace, a binning kernel reads them
- * ("pipeline_chunk" = rays per pair, default 2^26 = 3.2 GB of workspace).  None of them changes any result. */
+ * "grid_blocks" (0 = auto); "pipeline" 1 (default): the headline configuration runs as two kernels -- a trace kernel writes
+ * the exit lines (48 B per counted ray) to an HBM workspace, a binning kernel reads them ("pipeline_chunk" = rays per pair,
+ * default 2^26 = at most 3.2 GB of workspace) -- 0: one fused trace+bin kernel; "trace_block" (256/512/1024) and
+ * "trace_blocks_per_cu": workgroup shape of the kernels that keep no LDS histogram.  None of them changes any result. */
 int isx_set_option(const char* key, int64_t value);
 
 /* Device-side probe of the numeric contract (tests): out[i] = op(a[i],b[i],c[i]) with

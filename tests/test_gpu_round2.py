@@ -45,22 +45,35 @@ def test_refill_cursor_at_the_end_of_the_index_space(isx, orc):
 
 
 def test_two_kernel_pipeline_equals_the_fused_kernel(isx, orc):
-    """isx_set_option("pipeline", 1): trace kernel -> exit lines in HBM -> binning kernel.  Same histogram and census as the fused
-    kernel (and as the oracle), also when the launch is cut into several trace/bin pairs and when the grid is tiny."""
+    """The headline configuration runs as trace kernel -> exit lines in HBM -> binning kernel ("pipeline" = 1, the default);
+    "pipeline" = 0 is the fused kernel.  Same histogram and census from both (and from the oracle), also when the launch is
+    cut into several trace/bin pairs, when the grid is tiny, and for other workgroup shapes of the trace kernel."""
     c = isx.default_config()
-    ref, rst = isx.fluxmap(c, 3_000_000, SEED, 17)
     try:
+        isx.set_option("pipeline", 0)
+        ref, rst = isx.fluxmap(c, 3_000_000, SEED, 17)
+        assert isx.last_kernel_ms()[0] > 0 and isx.last_kernel_ms()[1] == 0
+        small_ref, small_st = isx.fluxmap(c, 30000, SEED)
         isx.set_option("pipeline", 1)
         for chunk in (1 << 26, 1_000_000, 4096 * 100 + 1):
             isx.set_option("pipeline_chunk", chunk)
             h, st = isx.fluxmap(c, 3_000_000, SEED, 17)
             assert np.array_equal(h, ref), chunk
             _census_equal(st, rst)
+        single, trace, binning = isx.last_kernel_ms()
+        assert single == 0 and trace > 0 and binning > 0 and abs(trace + binning - st.t_kernel_ms) < 1e-3 * st.t_kernel_ms
         isx.set_option("pipeline_chunk", 1 << 26)
         gh, gst = isx.fluxmap(c, 30000, SEED)
         oh, ost = orc.fluxmap(orc.default_config(), 30000, SEED)
-        assert np.array_equal(gh, oh)
+        assert np.array_equal(gh, oh) and np.array_equal(gh, small_ref)
         _census_equal(gst, ost)
+        _census_equal(gst, small_st)
+        for block, bpc in ((256, 8), (1024, 1), (512, 2)):
+            isx.set_option("trace_block", block); isx.set_option("trace_blocks_per_cu", bpc)
+            h, st = isx.fluxmap(c, 3_000_000, SEED, 17)
+            assert np.array_equal(h, ref), (block, bpc)
+            _census_equal(st, rst)
+        isx.set_option("trace_block", 512); isx.set_option("trace_blocks_per_cu", 4)
         isx.set_option("grid_blocks", 1)
         h1, st1 = isx.fluxmap(c, 50000, SEED, 5)
         isx.set_option("grid_blocks", 0)
@@ -69,8 +82,9 @@ def test_two_kernel_pipeline_equals_the_fused_kernel(isx, orc):
         _census_equal(st1, st2)
     finally:
         isx.set_option("grid_blocks", 0)
+        isx.set_option("trace_block", 512); isx.set_option("trace_blocks_per_cu", 4)
         isx.set_option("pipeline_chunk", 1 << 26)
-        isx.set_option("pipeline", 0)
+        isx.set_option("pipeline", 1)
 
 
 def test_config_of_another_abi_is_refused_on_the_device_path(isx):

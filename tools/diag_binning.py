@@ -5,6 +5,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 import altair_raytracing_amd as isx
 L = isx.load(); isx.init(0)
+if os.environ.get('ISX_PIPELINE'): isx.set_option('pipeline', int(os.environ['ISX_PIPELINE']))
 L.isx_diag_read.argtypes = [C.POINTER(C.c_uint64)]
 def diag():
     a = (C.c_uint64 * 16)()

@@ -15,7 +15,7 @@ for mode in (0, 1):
         h, st = isx.fluxmap(c, n, 5)
         ts.append(st.t_kernel_ms)
     res[mode] = (min(ts), h, st)
-    print(f"pipeline={mode}: {min(ts):.2f} ms = {n/min(ts)/1e3:.1f} Mrays/s  (all: {[round(t,2) for t in ts]}) increments {st.bin_increments} counted {st.counted_below_z}", flush=True)
+    print(f"pipeline={mode}: {min(ts):.2f} ms = {n/min(ts)/1e3:.1f} Mrays/s  (all: {[round(t,2) for t in ts]}) increments {st.bin_increments} counted {st.counted_below_z} last_kernel_ms {[round(x,2) for x in isx.last_kernel_ms()]}", flush=True)
 print("histograms equal:", np.array_equal(res[0][1], res[1][1]), "census equal:", all(getattr(res[0][2], k) == getattr(res[1][2], k) for k in ("launched","exited","counted_below_z","absorbed","suspended","bin_increments","wall_hits")))
 for bm in (2,):
     isx.set_option("bin_mode", bm)

@@ -20,11 +20,35 @@ ap = argparse.ArgumentParser()
 ap.add_argument("tag")
 ap.add_argument("note", nargs="?", default="")
 ap.add_argument("--name", default="flux")
-ap.add_argument("--kernel", default="isx_trace_bin_kernel")
+ap.add_argument("--kernel", default="isx_trace_bin_kernel",
+                help="kernel name; a comma-separated list (the two kernels of the flux-map pipeline) writes one summary per "
+                     "kernel (<tag>_<kernel>) and, with --headline, a combined profiles/pmc_summary.json")
 ap.add_argument("--rays", type=float, default=5e7, help="rays per full-size launch (per-ray figures)")
 ap.add_argument("--headline", action="store_true", help="also write profiles/pmc_summary.json (bench.py's source)")
 ap.add_argument("--command", default="python3 bench.py --steps 3 --warmup 1 --cpu-rays 0")
 a = ap.parse_args()
+if "," in a.kernel:   # several kernels of one profiled command: one pass per kernel, then the combined headline file
+    import subprocess, sys
+    parts = {}
+    for kname in a.kernel.split(","):
+        short = kname.replace("isx_", "").replace("_kernel", "")
+        subprocess.check_call([sys.executable, os.path.abspath(__file__), f"{a.tag}_{short}", a.note, "--name", a.name, "--kernel", kname,
+                               "--rays", str(a.rays), "--command", a.command])
+        parts[kname] = json.load(open(os.path.join(ROOT, "profiles", f"{a.tag}_{short}_pmc_summary.json")))
+    if a.headline:
+        comb = {"tag": a.tag, "kernel": a.kernel, "rays_per_launch": a.rays,
+                "kernel_source_sha": next(iter(parts.values()))["kernel_source_sha"], "kernels": parts,
+                "kernel_ms": sum(p.get("kernel_ms", 0.0) for p in parts.values()),
+                "valu_wave_insts_per_ray": sum(p.get("valu_wave_insts_per_ray", 0.0) for p in parts.values()),
+                "hbm_bytes_per_launch": sum(p.get("hbm_bytes_per_launch", 0.0) for p in parts.values())}
+        f64 = [p.get("fp64_executed") for p in parts.values()]
+        if all(f64):
+            comb["fp64_executed"] = {"wave_insts_per_ray": sum(x["wave_insts_per_ray"] for x in f64),
+                                     "lane_flop_per_ray": sum(x["lane_flop_per_ray"] for x in f64),
+                                     "share_of_valu": sum(x["wave_insts_per_ray"] for x in f64) / comb["valu_wave_insts_per_ray"]}
+        json.dump(comb, open(os.path.join(ROOT, "profiles", "pmc_summary.json"), "w"), indent=1)
+        json.dump(comb, open(os.path.join(ROOT, "profiles", f"{a.tag}_pmc_summary.json"), "w"), indent=1)
+    raise SystemExit(0)
 tag, note, KERNEL, RAYS = a.tag, a.note, a.kernel, a.rays
 os.makedirs(os.path.join(ROOT, "profiles"), exist_ok=True)
 
