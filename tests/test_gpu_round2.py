@@ -97,6 +97,24 @@ def test_config_of_another_abi_is_refused_on_the_device_path(isx):
     assert st.launched == 1000
 
 
+def test_exit_log_capacity_rules(isx, orc):
+    """isx_exit_directions: a capacity above ISX_MAX_LOG_RECORDS is refused before anything is allocated, a
+    capacity above n_rays is treated as n_rays, and the log stays sorted and bit-equal to the oracle's."""
+    c = isx.default_config()
+    n = 20000
+    ids = np.zeros(n, np.uint64); dirs = np.zeros((n, 3)); cnt = C.c_uint64(0); st = isx.Stats()
+    rc = isx.load().isx_exit_directions(C.byref(c), n, 5, 0, (1 << 28) + 1, ids.ctypes.data_as(C.POINTER(C.c_uint64)),
+                                        dirs.ctypes.data_as(C.POINTER(C.c_double)), C.byref(cnt), C.byref(st))
+    assert rc == isx.abi.ERR_TOO_LARGE
+    rc = isx.load().isx_exit_directions(C.byref(c), n, 5, 0, 1 << 27, ids.ctypes.data_as(C.POINTER(C.c_uint64)),
+                                        dirs.ctypes.data_as(C.POINTER(C.c_double)), C.byref(cnt), C.byref(st))
+    assert rc == 0 and 0 < cnt.value <= n and cnt.value == st.counted_below_z
+    k = cnt.value
+    assert np.all(np.diff(ids[:k].astype(np.int64)) > 0)
+    oids, odirs, ocnt = orc.exit_directions(orc.default_config(), n, 5)
+    assert ocnt == k and np.array_equal(oids[:k], ids[:k]) and np.array_equal(odirs[:k].view(np.uint64), dirs[:k].view(np.uint64))
+
+
 def _disc_cfg(mod):
     """integratingSphereDetectorSweep.C:114-123: shell 100.1-105 cm, port 170 deg, Lambertian, rho = 1, limit 10000."""
     c = mod.default_config()
