@@ -344,8 +344,9 @@ int enqueue(int sink, const isx_config* c, uint64_t n, uint64_t seed, uint64_t f
     return ISX_OK;
   };
   hipEvent_t e0;
-  // ---- two-kernel pipeline (headline configuration): trace kernel -> exit lines in HBM -> binning kernel, chunk by chunk
-  if (sink == SINK_FLUX && lean_explicit && S.pipeline && S.bin_mode != 0) {
+  // ---- two-kernel pipeline (lean flux maps: headline, chord mode, BRDF source): trace kernel -> exit lines in HBM -> binning kernel, chunk by chunk
+  if (sink == SINK_FLUX && (lean || brdf) && S.pipeline && S.bin_mode != 0) {
+    const KernelFn rec_fn = chord ? isx_trace_rec_chord_kernel : brdf ? isx_trace_rec_brdf_kernel : isx_trace_rec_kernel;
     const int pblock = S.trace_block, pwaves = pblock / 64;
     const size_t lds_trace = 16 + 64 + sizeof(Geom) + sizeof(DetGrid);
     const size_t lds_bin = (((size_t)d.nbins * 4 + 15) & ~(size_t)15) + (size_t)(4 * d.n_theta) * 8 + (size_t)(2 * d.n_phi) * sizeof(ColX) +
@@ -361,7 +362,7 @@ int enqueue(int sink, const isx_config* c, uint64_t n, uint64_t seed, uint64_t f
       if (chunk / ((uint64_t)cgrid * pwaves) >= 0x7fffffffull) return ISX_ERR_TOO_LARGE;
       rc = ensure_pipeline((size_t)chunk, (size_t)cgrid * pwaves);
       if (rc) return rc;
-      HIPCHK(hipFuncSetAttribute((const void*)isx_trace_rec_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_trace));
+      HIPCHK(hipFuncSetAttribute((const void*)rec_fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_trace));
       HIPCHK(hipFuncSetAttribute((const void*)isx_bin_lines_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bin));
       rc = span(0, &e0); if (rc) return rc;
       for (uint64_t off = 0; off < n; off += chunk) {
@@ -373,7 +374,7 @@ int enqueue(int sink, const isx_config* c, uint64_t n, uint64_t seed, uint64_t f
         DetGrid dt = d;              // the trace kernel keeps no histogram
         dt.nbins = 1; dt.n_theta = 0; dt.n_phi = 0;
         dt.rec_lines = S.d_rec; dt.rec_counts = S.d_rec_counts;
-        hipLaunchKernelGGL(isx_trace_rec_kernel, dim3(g2), dim3(pblock), lds_trace, S.stream, g, dt, w2);
+        hipLaunchKernelGGL(rec_fn, dim3(g2), dim3(pblock), lds_trace, S.stream, g, dt, w2);
         HIPCHK(hipGetLastError());
         rc = span(1, nullptr); if (rc) return rc;
         if (S.bin_mode != 2) {       // bin_mode 2: diagnostic, trace only

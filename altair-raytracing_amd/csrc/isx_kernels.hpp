@@ -163,10 +163,136 @@ __device__ __forceinline__ void bin_brute(const DG& dd, uint32_t* __restrict__ h
 //   dot = V.n, num = (P-c).n, dv = (P-c).V, dd = |P-c|^2
 // are all of the form k0 + k1*cos(phi_j) + k2*sin(phi_j)  (c = (A c, A s, z), n = (-S s, S c, -C)),
 // so one candidate costs 8 fma + the sign test of  dd*dot^2 - 2*num*dot*dv + num^2 - (w/2)^2*dot^2.
-struct CapWin {            // what the row windows need:
-  float Fz, AF2, AF, jf, ch2, inv_dphi;   // CAPS: the cap around one piercing point
-  int jlo_u, cnt_u;                       // otherwise: one phi-window shared by all rows
+struct CapWin {            // what the cap windows need: the cap around one piercing point
+  float Fz, AF2, AF, jf, ch2, inv_dphi;
 };
+
+// ---- "box" windows: the general construction (any line; the cap windows above are the cheaper special case of a line that
+// passes near O).  A detector centre c that the line X(s) = H + s V (H = foot of O = (0,0,portz) on the line) can hit lies
+// within rho_d of it: c = X(s) + e, e perpendicular to V, |e| <= rho.  With m = V_xy/|V_xy| and n = the horizontal unit vector
+// perpendicular to it (n.V = 0), and |V| = 1:
+//   |e.n| <= rho,   |e.m| <= rho |V_z|,   |e_z| <= rho |V_xy|            (components of unit vectors perpendicular to V)
+//   c_z = z_i  =>  s V_z in [z_i - H_z - rho|V_xy|, z_i - H_z + rho|V_xy|]      (the stretch of the line that can reach row i)
+//   |c - O| = R =>  s^2 = R^2 - |H-O|^2 - 2 e.(H-O) - |e|^2  in [R^2 - (h+rho)^2, (R+rho)^2 - h^2]     (smin^2, smax^2)
+// so in the plane of row i the centre lies in the rectangle  c.n in [dn - rho, dn + rho],  c.m in [Hm + sa|V_xy| - rho|V_z|,
+// Hm + sb|V_xy| + rho|V_z|]  (the bounding box of the ellipse in which the rho-tube around the line cuts that plane), and on
+// the circle of radius A_i about the z-axis: at most one arc on either side of the direction n, each reduced to the hull of
+// its part inside the rectangle -> at most two column windows per row, disjoint by construction (trimmed in whole columns).
+// All in binary32 with explicit slack (rho: 0.1 % + 2e-3 cm, angles 1.5e-3 rad, 1e-2 column); restated in numpy and checked
+// against the exact test on oracle exit lines in tests/test_cull_math.py.  Never decides a result.
+struct BoxLine {
+  float smax, smin, vxy, avz, ivz, dn, Hm, Hz, phin, rs, sig;
+};
+
+template <class D>
+__device__ __forceinline__ bool box_line(const D& d, const V3& P, const V3& V, float inv_dth, BoxLine& b, int& ilo, int& ihi) {
+  const double wz = P.z - d.portz;
+  const double wv = fma(P.x, V.x, fma(P.y, V.y, wz * V.z));
+  const double hx = fma(-wv, V.x, P.x), hy = fma(-wv, V.y, P.y), hz = fma(-wv, V.z, wz);
+  const float dO2 = (float)fma(hx, hx, fma(hy, hy, hz * hz));
+  const float Rf = (float)d.R, rho = (float)d.rho_d;
+  const float dO = sqrt_cull(dO2);
+  if (dO - rho > 1.001f * Rf) return false;          // dist(O, line) > R + rho_d: nothing can be hit
+  b.rs = fmaf(rho, 1.001f, 2e-3f);
+  const float Rr = Rf + b.rs;
+  b.smax = sqrt_cull(fmaxf(0.f, fmaf(Rr, Rr, -dO2))) * 1.001f + 1e-2f;
+  const float a1 = dO + b.rs;
+  b.smin = a1 >= Rf ? 0.f : fmaxf(0.f, sqrt_cull(fmaf(Rf, Rf, -(a1 * a1))) * 0.999f - 1e-2f);
+  const float Vx = (float)V.x, Vy = (float)V.y, Vz = (float)V.z;
+  const float vxy2 = fmaf(Vx, Vx, Vy * Vy);
+  float mx = 1.f, my = 0.f;
+  b.vxy = 0.f;
+  if (vxy2 > 1e-10f) {
+    b.vxy = sqrt_cull(vxy2);
+    const float iv = rcp_cull(b.vxy);
+    mx = Vx * iv; my = Vy * iv;
+  }
+  b.avz = fabsf(Vz);
+  b.ivz = b.avz > 1e-3f ? rcp_cull(Vz) : 0.f;
+  float nx = -my, ny = mx;
+  const float Hx = (float)hx, Hy = (float)hy;
+  b.Hz = (float)hz;
+  float dn = fmaf(Hx, nx, Hy * ny);
+  b.sig = -1.f;                                       // phi = phin + sig * psi, psi measured from n towards m
+  if (dn < 0.f) { nx = -nx; ny = -ny; dn = -dn; b.sig = 1.f; }
+  b.dn = dn;
+  b.Hm = fmaf(Hx, mx, Hy * my);
+  b.phin = atan2_cull(ny, nx);
+  // rows: z_i - O_z = -R cos(theta_i) within dz of H_z over the stretch |s| <= smax
+  const float dz = fmaf(b.smax, b.avz, b.rs * b.vxy) + 1e-3f;
+  const float iR = rcp_cull(Rf);
+  const float clo = fminf(1.f, fmaxf(-1.f, -(b.Hz - dz) * iR)), chi = fminf(1.f, fmaxf(-1.f, -(b.Hz + dz) * iR));
+  ilo = max((int)floorf((acos_cull(clo) - 2e-3f) * inv_dth - 0.5f - 1e-2f), 0);
+  ihi = min((int)ceilf((acos_cull(chi) + 2e-3f) * inv_dth - 0.5f + 1e-2f), d.n_theta - 1);
+  return ihi >= ilo;
+}
+
+// the (at most two) column windows of row (zrel0 = z_i - O_z, A = A_i): [j0, j0 + c0) and [j1, j1 + c1), starts in [0, n_phi)
+__device__ __forceinline__ void box_window(const BoxLine& b, float zrel0, float A, int n_phi, float inv_dphi, int& j0, int& c0,
+                                           int& j1, int& c1) {
+  j0 = 0; c0 = 0; j1 = 0; c1 = 0;
+  const float kPi = 3.14159274f, kHalfPi = 1.57079637f, dl = 1.5e-3f;
+  const float zrel = zrel0 - b.Hz;
+  const float rz = b.rs * b.vxy;
+  float sa, sb;
+  bool ok = true;
+  if (b.avz > 1e-3f) {
+    const float s1 = (zrel - rz) * b.ivz, s2 = (zrel + rz) * b.ivz;
+    sa = fminf(s1, s2); sb = fmaxf(s1, s2);
+    const float pad = fmaf(1e-4f, fabsf(sa) + fabsf(sb), 1e-3f);
+    sa -= pad; sb += pad;
+  } else {                                            // nearly horizontal: the whole stretch inside the shell, or nothing
+    ok = fabsf(zrel) <= fmaf(b.smax, b.avz, rz) + 1e-2f;
+    sa = -b.smax; sb = b.smax;
+  }
+  sa = fmaxf(sa, -b.smax); sb = fminf(sb, b.smax);
+  ok = ok && sa <= sb && !(sa > -b.smin && sb < b.smin);
+  const float em = b.rs * b.avz;
+  const float iA = rcp_cull(A);
+  const float sl = (fmaf(sa, b.vxy, b.Hm) - em) * iA, sh = (fmaf(sb, b.vxy, b.Hm) + em) * iA;
+  const float chi = (b.dn + b.rs) * iA, clo = (b.dn - b.rs) * iA;
+  if (!ok || clo > 1.f) return;
+  const float psi1 = chi >= 1.f ? 0.f : fmaxf(0.f, acos_cull(chi) - dl);
+  const float psi2 = clo <= -1.f ? kPi : fminf(kPi, acos_cull(clo) + dl);
+  // hull of { psi in [psi1, psi2] : l <= sin(psi) <= h }
+  auto arc = [&](float l, float h, float& lo, float& hi) -> bool {
+    const float al = l <= 0.f ? 0.f : (kHalfPi - acos_cull(fminf(l, 1.f))) - dl;
+    const float be = h >= 1.f ? kHalfPi : (kHalfPi - acos_cull(fmaxf(h, 0.f))) + dl;
+    const float a_lo = fmaxf(al, psi1), a_hi = fminf(be, psi2);
+    const float b_lo = fmaxf(kPi - be, psi1), b_hi = fminf(kPi - al, psi2);
+    const bool ha = a_lo <= a_hi, hb = b_lo <= b_hi;
+    lo = ha ? a_lo : b_lo;
+    hi = hb ? b_hi : a_hi;
+    return h >= 0.f && l <= 1.f && (ha || hb);
+  };
+  float p_lo, p_hi, q_lo, q_hi;
+  const bool p_ne = arc(sl, sh, p_lo, p_hi), q_ne = arc(-sh, -sl, q_lo, q_hi);
+  const bool up = b.sig > 0.f;                        // upper window: phi = phin + psi, lower: phi = phin - psi
+  const float u_lo = up ? p_lo : q_lo, u_hi = up ? p_hi : q_hi, l_lo = up ? q_lo : p_lo, l_hi = up ? q_hi : p_hi;
+  const bool u_ne = up ? p_ne : q_ne, l_ne = up ? q_ne : p_ne;
+  const int jU0 = (int)ceilf(fmaf(b.phin + u_lo, inv_dphi, -0.51f)), jU1 = (int)floorf(fmaf(b.phin + u_hi, inv_dphi, -0.49f));
+  const int jL0 = (int)ceilf(fmaf(b.phin - l_hi, inv_dphi, -0.51f)), jL1 = (int)floorf(fmaf(b.phin - l_lo, inv_dphi, -0.49f));
+  int cU = u_ne ? max(0, jU1 - jU0 + 1) : 0, cL = l_ne ? max(0, jL1 - jL0 + 1) : 0;
+  // no column twice: L ends below U (they meet at psi = 0), U ends below L's next period (they meet at psi = pi)
+  if (cU > 0 && cL > 0 && jL0 + cL > jU0) cL = max(0, jU0 - jL0);
+  if (cU > 0 && cL > 0 && jU0 + cU > jL0 + n_phi) cU = max(0, jL0 + n_phi - jU0);
+  cU = min(cU, n_phi); cL = min(cL, n_phi);
+  if (cL > 0 && cU > 0) {
+    if (jL0 + cL == jU0) { j0 = jL0; c0 = cL + cU; }                   // adjacent: one window
+    else if (jU0 + cU == jL0 + n_phi) { j0 = jU0; c0 = cU + cL; }
+    else { j0 = jL0; c0 = cL; j1 = jU0; c1 = cU; }
+  } else if (cL > 0) { j0 = jL0; c0 = cL; }
+  else { j0 = jU0; c0 = cU; }
+  c0 = min(c0, n_phi);
+  if (j0 < 0) j0 += n_phi;
+  if (j0 < 0) j0 += n_phi;
+  if (j0 >= n_phi) j0 -= n_phi;
+  if (j0 >= n_phi) j0 -= n_phi;
+  if (j1 < 0) j1 += n_phi;
+  if (j1 < 0) j1 += n_phi;
+  if (j1 >= n_phi) j1 -= n_phi;
+  if (j1 >= n_phi) j1 -= n_phi;
+}
 
 // Coefficients of row i for the line (P,V) and the walk over columns [jlo + start, jlo + start + len) of its window, with the
 // exact decision (shared by every row-to-lane mapping below).  jlo may be negative on entry (wrapped here).
@@ -267,13 +393,14 @@ __device__ __forceinline__ void walk_columns(const D& d, uint32_t* __restrict__ 
   }
 }
 
-// Rows ilo..ihi, 64 at a time (lane = row).  CAPS: each row's phi-window is its intersection with the cap `w`;
-// otherwise the same window [jlo_u, jlo_u + cnt_u) for every row.  Then the column walk with the exact decision.
+// Rows ilo..ihi, 64 at a time (lane = row).  MODE_CAP: each row's phi-window is its intersection with the cap `w`;
+// MODE_BOX: the (at most two) box windows of the row for the line `bx` -- the second windows, where any row has one, in a
+// second sweep over the same rows.  Then the column walk with the exact decision.
 //
-// Long windows (CAPS, `split` = 64 ints of wave-private LDS): a column pass lasts as long as the widest window of the wave, and
+// Long windows (`split` = 64 ints of wave-private LDS): a column pass lasts as long as the widest window of the wave, and
 // the widths are heavy-tailed -- the rows next to the pole of the detector hemisphere span the whole ring (n_phi columns)
-// while a typical row has ~8: 4 % of the headline's exit lines owned 27 % of the column iterations, and nearly every line of
-// the BRDF source model is such a line.  So when a wave meets windows longer than kSplitAt + 16 columns and at most 32 rows
+// while a typical row has ~8: 4 % of the headline's exit lines owned 27 % of the column iterations.  So when a wave meets
+// windows longer than kSplitAt + 16 columns and at most 32 rows
 // have more than kSplitAt, pass 0 stops every window at kSplitAt and a pass 1 deals the remainders to Q = 2, 4 or 8 lanes per
 // long row (lane -> (row, part) through the LDS list; the row's window and coefficients are simply derived again by its new
 // lanes, from wave-uniform inputs, so they are the same numbers).  Same candidates, same decisions, fewer idle lanes.
@@ -281,54 +408,64 @@ __device__ __forceinline__ void walk_columns(const D& d, uint32_t* __restrict__ 
 #define ISX_SPLIT_AT 24
 #endif
 constexpr int kSplitAt = ISX_SPLIT_AT;
-template <bool CAPS, class D>
+constexpr int MODE_CAP = 1, MODE_BOX = 2;
+template <int MODE, class D>
 __device__ __forceinline__ void walk_rows(const D& d, uint32_t* __restrict__ hist, const double* __restrict__ rowt,
                                           const ColX* __restrict__ colx, const V3& P, const V3& V, int lane, int ilo,
-                                          int ihi, const CapWin& w, int* split = nullptr, int path = 0) {
+                                          int ihi, const CapWin& w, const BoxLine& bx, int* split, int path) {
   // parameter of the point of the line nearest to O = (0,0,portz), the centre of the detector sphere (walk_columns)
   const double t0 = -fma(P.x, V.x, fma(P.y, V.y, (P.z - d.portz) * V.z));
 #pragma unroll 1
   for (int i0 = ilo; i0 <= ihi; i0 += 64) {
-    int npass = 1, logq = 0, nlong = 0;
+    int nsweep = 1;
 #pragma unroll 1
-    for (int pass = 0; pass < npass; ++pass) {
-      int i = i0 + lane, part = 0;
-      bool have = i <= ihi;
-      if (CAPS && pass == 1) {
-        const int slot = lane >> logq;
-        part = lane & ((1 << logq) - 1);
-        have = slot < nlong;
-        i = have ? reinterpret_cast<volatile int*>(split)[slot] : 0;
-      }
-      int jlo = 0, cnt = 0;
-      double Sd = 0, Cd = 0, zd = 0, Ad = 0;
-      if (have) {
-        Sd = rowt[4 * i + 0]; Cd = rowt[4 * i + 1]; zd = rowt[4 * i + 2]; Ad = rowt[4 * i + 3];
-        if (!CAPS) { jlo = w.jlo_u; cnt = w.cnt_u; }
-        else {
-          const float zi = (float)zd, Ai = (float)Ad;
-          const float dzi = zi - w.Fz;
-          const float num = fmaf(Ai, Ai, fmaf(dzi, dzi, w.AF2)) - w.ch2;
-          const float den = 2.0f * Ai * w.AF;
-          const float slack = 2e-5f * (fmaf(Ai, Ai, w.AF2) + w.ch2);  // f32 rounding of num
-          if (num - slack <= -den) { jlo = 0; cnt = d.n_phi; }
-          else if (num - slack > den) { cnt = 0; }
-          else {
-            float K = (num - slack) * rcp_cull(den) - 2e-5f;
-            K = fminf(1.f, fmaxf(-1.f, K));
-            const float dl = acos_cull(K) + 1e-3f;
-            const float hw = dl * w.inv_dphi;
-            const int lo = (int)ceilf(w.jf - hw), hi = (int)floorf(w.jf + hw);
-            jlo = lo; cnt = hi - lo + 1;
-            if (cnt < 0) cnt = 0;
-            if (cnt >= d.n_phi) { jlo = 0; cnt = d.n_phi; }
+    for (int sweep = 0; sweep < nsweep; ++sweep) {
+      int npass = 1, logq = 0, nlong = 0;
+#pragma unroll 1
+      for (int pass = 0; pass < npass; ++pass) {
+        int i = i0 + lane, part = 0;
+        bool have = i <= ihi;
+        if (pass == 1) {
+          const int slot = lane >> logq;
+          part = lane & ((1 << logq) - 1);
+          have = slot < nlong;
+          i = have ? reinterpret_cast<volatile int*>(split)[slot] : 0;
+        }
+        int jlo = 0, cnt = 0;
+        bool second = false;
+        if (have) {
+          const float zi = (float)rowt[4 * i + 2], Ai = (float)rowt[4 * i + 3];
+          if (MODE == MODE_BOX) {
+            int j0, c0, j1, c1;
+            box_window(bx, zi - (float)d.portz, Ai, d.n_phi, w.inv_dphi, j0, c0, j1, c1);
+            second = c1 > 0;
+            jlo = sweep == 0 ? j0 : j1;
+            cnt = sweep == 0 ? c0 : c1;
+          } else {
+            const float dzi = zi - w.Fz;
+            const float num = fmaf(Ai, Ai, fmaf(dzi, dzi, w.AF2)) - w.ch2;
+            const float den = 2.0f * Ai * w.AF;
+            const float slack = 2e-5f * (fmaf(Ai, Ai, w.AF2) + w.ch2);  // f32 rounding of num
+            if (num - slack <= -den) { jlo = 0; cnt = d.n_phi; }
+            else if (num - slack > den) { cnt = 0; }
+            else {
+              float K = (num - slack) * rcp_cull(den) - 2e-5f;
+              K = fminf(1.f, fmaxf(-1.f, K));
+              const float dl = acos_cull(K) + 1e-3f;
+              const float hw = dl * w.inv_dphi;
+              const int lo = (int)ceilf(w.jf - hw), hi = (int)floorf(w.jf + hw);
+              jlo = lo; cnt = hi - lo + 1;
+              if (cnt < 0) cnt = 0;
+              if (cnt >= d.n_phi) { jlo = 0; cnt = d.n_phi; }
+            }
           }
         }
-      }
-      // the part of the window this lane walks in this pass: [start, start + len)
-      int start = 0, len = cnt;
-      if (CAPS && split != nullptr) {
-        if (pass == 0) {
+        if (MODE == MODE_BOX && sweep == 0 && pass == 0 && __ballot(second) != 0ull) nsweep = 2;
+        // the part of the window this lane walks in this pass: [start, start + len)
+        int start = 0, len = cnt;
+        if (split == nullptr) {
+          // (kernels without the wave-private list: whole windows, one pass)
+        } else if (pass == 0) {
           const unsigned long long lm = __ballot(cnt > kSplitAt);
           if (lm != 0ull && __ballot(cnt >= kSplitAt + 16) != 0ull) {
             nlong = (int)__popcll(lm);
@@ -351,9 +488,9 @@ __device__ __forceinline__ void walk_rows(const D& d, uint32_t* __restrict__ his
           len = len < 0 ? 0 : (len > chunk ? chunk : len);
           if (!have) len = 0;
         }
+        ISX_DIAG_ADD(11, 1); if (pass == 1) ISX_DIAG_ADD(10, 1);
+        walk_columns(d, hist, colx, P, V, t0, lane, i, rowt, jlo, start, len, path);
       }
-      ISX_DIAG_ADD(11, 1); if (pass == 1) ISX_DIAG_ADD(10, 1);
-      walk_columns(d, hist, colx, P, V, t0, lane, i, rowt, jlo, start, len, path);
     }
   }
 }
@@ -364,7 +501,7 @@ __device__ __forceinline__ void walk_rows(const D& d, uint32_t* __restrict__ his
 // else (mode 1) goes through bin_culled as before.  Same formulas, same margins as bin_culled.
 struct RecPre {
   float Fz, AF, jf, ch2;
-  int rows;   // ilo | ihi << 16 (fast path: cap around the lower piercing point only), or -1: general path
+  int rows;   // ilo | ihi << 16 (fast path: cap around the lower piercing point only), -1: general path, -2: cannot hit anything
 };
 struct GridConst { float Rf, rho, portz, inv_dphi, inv_dth; int n_theta; };   // wave-uniform, read once per trip
 __device__ __forceinline__ RecPre prep_record(const GridConst& k, const V3& P, const V3& V) {
@@ -377,6 +514,7 @@ __device__ __forceinline__ RecPre prep_record(const GridConst& k, const V3& P, c
   const float R2 = k.Rf * k.Rf;
   const float dO = sqrt_cull(dO2);
   const float a1 = dO + k.rho;
+  if (dO - k.rho > 1.001f * k.Rf) { o.rows = -2; return o; }   // farther than R + rho_d from O (box_line's own test)
   if (!(a1 < 0.999f * k.Rf)) return o;
   const float sF = sqrt_cull(R2 - dO2);
   const float smin = sqrt_cull(R2 - a1 * a1);
@@ -404,10 +542,13 @@ __device__ __forceinline__ RecPre prep_record(const GridConst& k, const V3& P, c
   return o;
 }
 
-template <class DG>
+// CAPS_TOO: lines that pass well inside S(O,R) take cap windows around their two piercing points (cheaper to set up than box
+// windows; the binning kernel of the pipeline).  The fused kernels, at their 128-VGPR limit, send every line that is not on
+// their fast path through the box windows: one copy less of the column walk, no scratch.  Same candidates' decisions either way.
+template <bool CAPS_TOO, class DG>
 __device__ inline void bin_culled(const DG& dd, uint32_t* __restrict__ hist,
                                       const double* __restrict__ rowt, const ColX* __restrict__ colx,
-                                      const V3 P, const V3 V, int lane, int* split = nullptr) {
+                                      const V3 P, const V3 V, int lane, int* split) {
   // one read of each constant (dd is a volatile LDS copy: nothing of it lives in SGPRs across the trace loop)
   struct { int n_theta, n_phi; double half_w2, rho_d, R, portz; const double* table; } d;
   d.n_theta = dd.n_theta; d.n_phi = dd.n_phi; d.half_w2 = dd.half_w2; d.rho_d = dd.rho_d; d.R = dd.R;
@@ -423,10 +564,11 @@ __device__ inline void bin_culled(const DG& dd, uint32_t* __restrict__ hist,
   const float a1 = dO + rho;
   CapWin w;
   w.inv_dphi = (float)d.n_phi * 0.15915494309f;            // 1/dphi
+  w.Fz = 0.f; w.AF2 = 0.f; w.AF = 0.f; w.jf = 0.f;
   const float inv_dth = (float)d.n_theta * 0.63661977237f;   // 1 / row spacing in theta
   // Normal case (a line that left through the port passes near O): every detector centre within rho_d of the line
   // lies within chord ch of one of the two points where the line pierces S(O,R) -> cap windows.
-  bool caps = a1 < 0.999f * Rf;
+  bool caps = CAPS_TOO && a1 < 0.999f * Rf;
   float sF = 0.f, ch = 0.f, omega = 0.f;
   w.ch2 = 0.f;
   if (caps) {
@@ -441,54 +583,17 @@ __device__ inline void bin_culled(const DG& dd, uint32_t* __restrict__ hist,
     omega = ch * rcp_cull(Rf) * 1.01f + 2e-3f;          // cap angular radius 2*asin(ch/2R), conservatively
   }
   if (!caps) {
-    // Grazing or nearly tangent line (caps would merge), or one that misses S(O,R): typical for the re-scattered rays
-    // of the BRDF source model, which start on the world box.  A hit needs dist(c,L) <= rho_d with |c-O| = R, hence
-    // dist(O,L) <= R + rho_d: farther out nothing can be hit.  Else whole rows, limited to the z-extent of the stretch
-    // of the line inside the shell R +- rho_d: a centre within rho_d of the line point X = H + s V has
-    // | |X-O| - R | <= rho_d, so s^2 <= (R+rho_d)^2 - dO^2, and its height differs from X's by at most rho_d, i.e.
-    // z_i - O_z = -R cos(theta_i) lies in [hz - dz, hz + dz].  Same exact decision as in the cap case.
-    if (dO - rho > 1.001f * Rf) { ISX_DIAG_ADD(3, 1); return; }
-    const float sm = sqrt_cull(fmaxf(0.f, fmaf(Rf + rho, Rf + rho, -dO2))) * 1.001f;
-    const float dz = fmaf(sm, fabsf((float)V.z), rho) * 1.001f + 1e-3f;
-    const float iR = rcp_cull(Rf);
-    const float clo = fminf(1.f, fmaxf(-1.f, -((float)hz - dz) * iR)), chi = fminf(1.f, fmaxf(-1.f, -((float)hz + dz) * iR));
-    const int ilo = max((int)floorf((acos_cull(clo) - 2e-3f) * inv_dth - 0.5f - 1e-2f), 0);
-    const int ihi = min((int)ceilf((acos_cull(chi) + 2e-3f) * inv_dth - 0.5f + 1e-2f), d.n_theta - 1);
-    // phi-window common to all rows: in the xy-plane every candidate lies within rho_d of the projected stretch
-    // [Xa, Xb] = H -+ sm V, a stadium; seen from the z-axis its angular hull is that of its two end discs plus the arc
-    // the segment sweeps between them (the tangents from an outside point to the hull of two discs touch a disc).
-    w.jlo_u = 0; w.cnt_u = d.n_phi;
-    {
-      const float Hx = (float)hx, Hy = (float)hy, Vx = (float)V.x, Vy = (float)V.y;   // O is on the z-axis: H_xy = h_xy
-      const float xa = fmaf(-sm, Vx, Hx), ya = fmaf(-sm, Vy, Hy), xb = fmaf(sm, Vx, Hx), yb = fmaf(sm, Vy, Hy);
-      const float vxy2 = fmaf(Vx, Vx, Vy * Vy);
-      // closest approach of the segment to the axis: parameter of the foot point, clamped to the stretch
-      const float tf = vxy2 > 1e-12f ? fminf(sm, fmaxf(-sm, -fmaf(Hx, Vx, Hy * Vy) * rcp_cull(vxy2))) : 0.f;
-      const float xf = fmaf(tf, Vx, Hx), yf = fmaf(tf, Vy, Hy);
-      const float dseg = sqrt_cull(fmaf(xf, xf, yf * yf));
-      const float rm = rho * 1.01f + 1e-2f;
-      if (dseg > rm * 1.05f) {                     // the stadium does not reach the axis: a proper interval
-        const float ra = sqrt_cull(fmaf(xa, xa, ya * ya)), rb = sqrt_cull(fmaf(xb, xb, yb * yb));   // both >= dseg > rm
-        const float al_a = 1.57079637f - acos_cull(fminf(1.f, rm * rcp_cull(ra))) + 2e-3f;   // asin(rm/ra), padded
-        const float al_b = 1.57079637f - acos_cull(fminf(1.f, rm * rcp_cull(rb))) + 2e-3f;
-        const float pa = atan2_cull(ya, xa);
-        float dl = atan2_cull(yb, xb) - pa;                // signed sweep a -> b, |sweep| < pi because the axis is outside
-        if (dl > 3.14159274f) dl -= 6.28318531f;
-        if (dl < -3.14159274f) dl += 6.28318531f;
-        const float lo = pa + fminf(-al_a, dl - al_b), hi = pa + fmaxf(al_a, dl + al_b);
-        const int j0 = (int)ceilf(lo * w.inv_dphi - 0.5f - 1e-2f), j1 = (int)floorf(hi * w.inv_dphi - 0.5f + 1e-2f);
-        const int c = j1 - j0 + 1;
-        if (c < d.n_phi) {
-          w.cnt_u = c < 0 ? 0 : c;
-          int jw = j0 % d.n_phi;
-          w.jlo_u = jw < 0 ? jw + d.n_phi : jw;
-        }
-      }
-    }
+    // Grazing or nearly tangent line (the caps would merge), or one that misses S(O,R): typical for the re-scattered rays of the
+    // BRDF source model, which start on the world box.  Per-row box windows around the stretch of the line that can reach
+    // the row (BoxLine above); same exact decision as on the cap path.
+    BoxLine bx;
+    int ilo, ihi;
+    if (!box_line(d, P, V, inv_dth, bx, ilo, ihi)) { ISX_DIAG_ADD(3, 1); return; }
     ISX_DIAG_ADD(2, 1);
-    walk_rows<false>(d, hist, rowt, colx, P, V, lane, ilo, ihi, w, nullptr, 2);
+    walk_rows<MODE_BOX>(d, hist, rowt, colx, P, V, lane, ilo, ihi, w, bx, split, 2);
     return;
   }
+  if (!CAPS_TOO) return;
   ISX_DIAG_ADD(1, 1);
 #pragma unroll 1
   for (int side = 0; side < 2; ++side) {
@@ -505,7 +610,7 @@ __device__ inline void bin_culled(const DG& dd, uint32_t* __restrict__ hist,
     const float thF = atan2_cull(w.AF, (float)d.portz - w.Fz);
     const int ilo = max((int)floorf((thF - omega) * inv_dth - 0.5f - 1e-3f), 0);
     const int ihi = min((int)ceilf((thF + omega) * inv_dth - 0.5f + 1e-3f), d.n_theta - 1);
-    walk_rows<true>(d, hist, rowt, colx, P, V, lane, ilo, ihi, w, split, 1);
+    walk_rows<MODE_CAP>(d, hist, rowt, colx, P, V, lane, ilo, ihi, w, BoxLine(), split, 1);
   }
 }
 
@@ -982,6 +1087,7 @@ __device__ __forceinline__ void persistent_body(const Geom& g_arg, const DetGrid
           if (bin_mode == 0) bin_brute(d, hist, P, V, lane);
           else if (bin_mode == 1) {
             const int rows = fast ? __builtin_amdgcn_readfirstlane(reci[src]) : -1;   // same address in every lane
+            if (rows == -2) { ISX_DIAG_ADD(3, 1); continue; }
             if (rows >= 0) {
               const float4 q4 = rec4[src];
               struct { int n_phi; double half_w2, portz; const double* table; } dfast;
@@ -990,9 +1096,9 @@ __device__ __forceinline__ void persistent_body(const Geom& g_arg, const DetGrid
               wfast.inv_dphi = (float)dfast.n_phi * 0.15915494309f;
               wfast.Fz = q4.x; wfast.AF = q4.y; wfast.AF2 = q4.y * q4.y; wfast.jf = q4.z; wfast.ch2 = q4.w;
               ISX_DIAG_ADD(0, 1);
-              walk_rows<true>(dfast, hist, rowt, colx, P, V, lane, rows & 0xffff, rows >> 16, wfast, spl, 0);
+              walk_rows<MODE_CAP>(dfast, hist, rowt, colx, P, V, lane, rows & 0xffff, rows >> 16, wfast, BoxLine(), spl, 0);
             } else {
-              bin_culled(d, hist, rowt, colx, P, V, lane, spl);
+              bin_culled<false>(d, hist, rowt, colx, P, V, lane, spl);
             }
           }
           // bin_mode 2: diagnostic only (trace without binning; results are NOT a flux map)
@@ -1065,6 +1171,12 @@ isx_trace_perpos_lean_kernel(const Geom g, const DetGrid d, const Work wk) { per
 // state: 0 B of LDS histogram), isx_bin_lines_kernel bins them.
 extern "C" __global__ void ISX_KERNEL_ATTR
 isx_trace_rec_kernel(const Geom g, const DetGrid d, const Work wk) { persistent_body<SINK_REC, true, 0>(g, d, wk); }
+// the same for the optional chord mode and for the BRDF source model (configs[2]): only the trace differs, the lines are binned
+// by the same isx_bin_lines_kernel
+extern "C" __global__ void ISX_KERNEL_ATTR
+isx_trace_rec_chord_kernel(const Geom g, const DetGrid d, const Work wk) { persistent_body<SINK_REC, true, 1>(g, d, wk); }
+extern "C" __global__ void ISX_KERNEL_ATTR
+isx_trace_rec_brdf_kernel(const Geom g, const DetGrid d, const Work wk) { persistent_body<SINK_REC, true, 0, true>(g, d, wk); }
 extern "C" __global__ void ISX_KERNEL_ATTR
 isx_trace_log_kernel(const Geom g, const DetGrid d, const Work wk) { persistent_body<SINK_LOG>(g, d, wk); }
 extern "C" __global__ void ISX_KERNEL_ATTR
@@ -1128,7 +1240,8 @@ isx_bin_lines_kernel(const DetGrid d_arg, const Work wk) {
       lp.x = a.x; lp.y = a.y; lp.z = b.x; lv.x = b.y; lv.y = c.x; lv.z = c.y;
       if (bin_mode == 1) pre = prep_record(k, lp, lv);
     }
-    unsigned long long em = __ballot(have);
+    unsigned long long em = __ballot(have && pre.rows != -2);   // (lines that cannot hit anything end here, 64 at a time)
+    ISX_DIAG_ADD(3, __popcll(__ballot(have && pre.rows == -2)));
     while (em) {
       const int src = __builtin_ctzll(em);
       em &= em - 1ull;
@@ -1148,9 +1261,9 @@ isx_bin_lines_kernel(const DetGrid d_arg, const Work wk) {
         wfast.jf = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, pre.jf), src));
         wfast.ch2 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, pre.ch2), src));
         ISX_DIAG_ADD(0, 1);
-        walk_rows<true>(dfast, hist, rowt, colx, P, V, lane, rows & 0xffff, rows >> 16, wfast, spl, 0);
+        walk_rows<MODE_CAP>(dfast, hist, rowt, colx, P, V, lane, rows & 0xffff, rows >> 16, wfast, BoxLine(), spl, 0);
       } else {
-        bin_culled(d, hist, rowt, colx, P, V, lane, spl);
+        bin_culled<true>(d, hist, rowt, colx, P, V, lane, spl);
       }
     }
   }

@@ -47,3 +47,29 @@ def test_acos_cull_error_below_1e4():
     x = np.concatenate([np.linspace(-1, 1, 2_000_001), 1 - np.logspace(-8, 0, 2000), -1 + np.logspace(-8, 0, 2000)])
     err = np.abs(acos_cull(x).astype(np.float64) - np.arccos(x.astype(f32).astype(np.float64)))
     assert err.max() < 1e-4
+
+
+def test_box_windows_contain_every_hit():
+    """The per-row box windows of the binning pre-selection (isx_kernels.hpp box_line / box_window, restated in float32 numpy
+    in tests/boxwin_np.py) against the exact test on all bins: exit lines of the headline and of the BRDF source model from the
+    oracle, random lines including horizontal / vertical / nearly horizontal ones, and two other detector grids.  No hit
+    outside its row's windows, no column in two windows of a row -- and the windows are worth having (few candidates)."""
+    import boxwin_np as bw
+    import oracle as orc
+    c, lp, d = bw.lines_for("brdf", 300)
+    r = bw.check(c, lp, d)
+    assert r["lines"] > 250 and r["missed"] == 0 and r["twice"] == 0
+    assert r["candidates"] < 4 * r["hits"]
+    c, lp, d = bw.lines_for("headline", 400)
+    r = bw.check(c, lp, d)
+    assert r["lines"] > 100 and r["missed"] == 0 and r["twice"] == 0
+    c = orc.default_config()
+    lp, d = bw.random_lines(c, 400)
+    r = bw.check(c, lp, d)
+    assert r["hits"] > 10000 and r["missed"] == 0 and r["twice"] == 0
+    for n_theta, n_phi, diam, dist in ((45, 20, 10.0, 100.0), (60, 120, 4.0, 150.0), (7, 3, 60.0, 80.0)):
+        c = orc.default_config()
+        c.n_theta, c.n_phi, c.det_diameter, c.det_distance = n_theta, n_phi, diam, dist
+        lp, d = bw.random_lines(c, 300, seed=n_theta)
+        r = bw.check(c, lp, d)
+        assert r["hits"] > 0 and r["missed"] == 0 and r["twice"] == 0, (n_theta, n_phi)

@@ -87,6 +87,45 @@ def test_two_kernel_pipeline_equals_the_fused_kernel(isx, orc):
         isx.set_option("pipeline", 1)
 
 
+def _brdf_cfg(mod):
+    c = mod.default_config()
+    c.source_model = 1; c.brdf[0], c.brdf[1], c.brdf[2] = 0.3, 0.4, 0.6
+    c.roughness_rad = 0.5; c.reflectance = 1.0; c.max_points = 10000; c.box_half = 200.0
+    return c
+
+
+@pytest.mark.parametrize("which", ["chord", "brdf"])
+def test_pipeline_of_the_chord_and_brdf_variants(isx, orc, which):
+    """The chord mode and the BRDF source model (configs[2]) take the same two-kernel pipeline (their own trace kernel, the
+    common binning kernel): same histogram and census as their fused kernels and as the oracle, chunked or not."""
+    def cfg(mod):
+        if which == "brdf":
+            return _brdf_cfg(mod)
+        c = mod.default_config(); c.trace_mode = 1
+        return c
+    n = 400_000 if which == "brdf" else 2_000_000
+    try:
+        isx.set_option("pipeline", 0)
+        ref, rst = isx.fluxmap(cfg(isx), n, SEED, 3)
+        assert isx.last_kernel_ms()[1] == 0
+        isx.set_option("pipeline", 1)
+        for chunk in (1 << 26, 100_003):
+            isx.set_option("pipeline_chunk", chunk)
+            h, st = isx.fluxmap(cfg(isx), n, SEED, 3)
+            assert isx.last_kernel_ms()[1] > 0 and isx.last_kernel_ms()[2] > 0
+            assert np.array_equal(h, ref), chunk
+            _census_equal(st, rst)
+        isx.set_option("pipeline_chunk", 1 << 26)
+        m = 20000
+        gh, gst = isx.fluxmap(cfg(isx), m, SEED)
+        oh, ost = orc.fluxmap(cfg(orc), m, SEED)
+        assert np.array_equal(gh, oh)
+        _census_equal(gst, ost)
+    finally:
+        isx.set_option("pipeline_chunk", 1 << 26)
+        isx.set_option("pipeline", 1)
+
+
 def test_config_of_another_abi_is_refused_on_the_device_path(isx):
     c = isx.default_config()
     c.struct_size = C.sizeof(isx.Config) - 8
@@ -98,21 +137,24 @@ def test_config_of_another_abi_is_refused_on_the_device_path(isx):
 
 
 def test_exit_log_capacity_rules(isx, orc):
-    """isx_exit_directions: a capacity above ISX_MAX_LOG_RECORDS is refused before anything is allocated, a
-    capacity above n_rays is treated as n_rays, and the log stays sorted and bit-equal to the oracle's."""
+    """isx_exit_directions: a capacity above n_rays is treated as n_rays (no 2^28-record buffer is allocated for
+    20 000 rays), the log stays sorted and bit-equal to the oracle's; the record limit applies to min(capacity, n_rays)."""
     c = isx.default_config()
     n = 20000
     ids = np.zeros(n, np.uint64); dirs = np.zeros((n, 3)); cnt = C.c_uint64(0); st = isx.Stats()
-    rc = isx.load().isx_exit_directions(C.byref(c), n, 5, 0, (1 << 28) + 1, ids.ctypes.data_as(C.POINTER(C.c_uint64)),
-                                        dirs.ctypes.data_as(C.POINTER(C.c_double)), C.byref(cnt), C.byref(st))
-    assert rc == isx.abi.ERR_TOO_LARGE
-    rc = isx.load().isx_exit_directions(C.byref(c), n, 5, 0, 1 << 27, ids.ctypes.data_as(C.POINTER(C.c_uint64)),
-                                        dirs.ctypes.data_as(C.POINTER(C.c_double)), C.byref(cnt), C.byref(st))
-    assert rc == 0 and 0 < cnt.value <= n and cnt.value == st.counted_below_z
-    k = cnt.value
-    assert np.all(np.diff(ids[:k].astype(np.int64)) > 0)
+    for cap in ((1 << 28) + 1, 1 << 27, n):
+        cnt.value = 0
+        rc = isx.load().isx_exit_directions(C.byref(c), n, 5, 0, cap, ids.ctypes.data_as(C.POINTER(C.c_uint64)),
+                                            dirs.ctypes.data_as(C.POINTER(C.c_double)), C.byref(cnt), C.byref(st))
+        assert rc == 0 and 0 < cnt.value <= n and cnt.value == st.counted_below_z
+        k = cnt.value
+        assert np.all(np.diff(ids[:k].astype(np.int64)) > 0)
     oids, odirs, ocnt = orc.exit_directions(orc.default_config(), n, 5)
     assert ocnt == k and np.array_equal(oids[:k], ids[:k]) and np.array_equal(odirs[:k].view(np.uint64), dirs[:k].view(np.uint64))
+    # n_rays itself above the limit with a capacity above it: refused before anything is allocated or traced
+    rc = isx.load().isx_exit_directions(C.byref(c), (1 << 28) + 1, 5, 0, (1 << 28) + 1, ids.ctypes.data_as(C.POINTER(C.c_uint64)),
+                                        dirs.ctypes.data_as(C.POINTER(C.c_double)), C.byref(cnt), C.byref(st))
+    assert rc == isx.abi.ERR_TOO_LARGE
 
 
 def _disc_cfg(mod):

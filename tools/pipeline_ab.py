@@ -1,11 +1,18 @@
-"""A/B of the fused flux kernel vs the two-kernel pipeline (GPU box)."""
+"""A/B of the fused flux kernel vs the two-kernel pipeline (GPU box):  python tools/pipeline_ab.py [flux|chord|brdf]"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 import altair_raytracing_amd as isx
 isx.load(); isx.init(0)
+which = sys.argv[1] if len(sys.argv) > 1 else "flux"
 c = isx.default_config()
+if which == "chord":
+    c.trace_mode = 1
+elif which == "brdf":
+    c.source_model = isx.SOURCE_BRDF; c.brdf[0], c.brdf[1], c.brdf[2] = 0.3, 0.4, 0.6
+    c.roughness_rad = 0.5; c.reflectance = 1.0; c.max_points = 10000; c.box_half = 200.0
 n = 50_000_000
+print("configuration:", which, flush=True)
 res = {}
 for mode in (0, 1):
     isx.set_option("pipeline", mode)
