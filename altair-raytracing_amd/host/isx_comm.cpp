@@ -320,17 +320,22 @@ int fluxmap_all(const isx_config* cfg, uint64_t n_rays, uint64_t seed, uint64_t 
   return rc;
 }
 
-int fluxmap_per_position_all(const isx_config* cfg, uint64_t rays_per_position, int32_t fold, uint64_t n_groups, uint64_t seed,
-                             uint64_t first_ray, uint64_t* hits, isx_stats* st) {
+int fluxmap_per_position_range_all(const isx_config* cfg, uint64_t rays_per_position, int32_t fold, uint64_t first_group,
+                                   uint64_t n_groups, uint64_t seed, uint64_t first_ray, uint64_t* hits, isx_stats* st) {
   Comm& c = comm();
-  if (!c.active()) return isx_fluxmap_per_position(cfg, rays_per_position, fold, 0, n_groups, seed, first_ray, hits, st);
+  if (!c.active()) return isx_fluxmap_per_position(cfg, rays_per_position, fold, first_group, n_groups, seed, first_ray, hits, st);
   uint64_t g0, ng;
   c.shard(n_groups, g0, ng);   // whole detector groups per rank: group g keeps its rays [first_ray + g*rays_per_position, ...)
   isx_stats local{};
-  int rc = isx_fluxmap_per_position(cfg, rays_per_position, fold, g0, ng, seed, first_ray, hits, &local);
+  int rc = isx_fluxmap_per_position(cfg, rays_per_position, fold, first_group + g0, ng, seed, first_ray, hits, &local);
   rc = c.reduce(rc, hits, (size_t)cfg->n_theta * cfg->n_phi, &local);
   if (rc == ISX_OK && st) *st = local;
   return rc;
+}
+
+int fluxmap_per_position_all(const isx_config* cfg, uint64_t rays_per_position, int32_t fold, uint64_t n_groups, uint64_t seed,
+                             uint64_t first_ray, uint64_t* hits, isx_stats* st) {
+  return fluxmap_per_position_range_all(cfg, rays_per_position, fold, 0, n_groups, seed, first_ray, hits, st);
 }
 
 int fluxmap_series_all(const isx_config* cfgs, int32_t n_cfg, uint64_t n_rays, uint64_t seed, uint64_t first_ray, uint64_t* hits,

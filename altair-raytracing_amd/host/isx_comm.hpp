@@ -59,6 +59,10 @@ std::string outputPath(const std::string& base);
 int fluxmap_all(const isx_config* cfg, uint64_t n_rays, uint64_t seed, uint64_t first_ray, uint64_t* hits, isx_stats* st);
 int fluxmap_per_position_all(const isx_config* cfg, uint64_t rays_per_position, int32_t fold, uint64_t n_groups, uint64_t seed,
                              uint64_t first_ray, uint64_t* hits, isx_stats* st);
+// the same for the groups [first_group, first_group + n_groups) only (the other bins of `hits` come back 0): one batch of a
+// sweep that writes its rows as it goes (fluxAtObserverOptimize.C:575-579)
+int fluxmap_per_position_range_all(const isx_config* cfg, uint64_t rays_per_position, int32_t fold, uint64_t first_group,
+                                   uint64_t n_groups, uint64_t seed, uint64_t first_ray, uint64_t* hits, isx_stats* st);
 int fluxmap_series_all(const isx_config* cfgs, int32_t n_cfg, uint64_t n_rays, uint64_t seed, uint64_t first_ray, uint64_t* hits,
                        isx_stats* st);
 int disc_sweep_all(const isx_config* cfg, const double* centers_axes, int32_t n_disc, double radius, double half_thick,

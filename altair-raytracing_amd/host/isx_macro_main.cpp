@@ -2,7 +2,8 @@
 //   isx_macro <file>::<function> [key=value ...]
 // e.g. isx_macro fluxAtObserverFast::sweepDetectorTraceOnce folder=out srcZ=-75 dirY=0 thetaMax=170
 // (what `root -l -b -q 'fluxAtObserverFast.C+' -e 'sweepDetectorTraceOnce(...)'` did in the reference).
-// Environment: ISX_DEVICE, ISX_SEED, ISX_RAYS (override the macro's hard-coded ray count), ISX_QUIET.
+// Environment: ISX_DEVICE, ISX_SEED, ISX_RAYS (override the macro's hard-coded ray count), ISX_QUIET, ISX_FLUSH_ROWS (theta rows
+// per launch of the per-position sweep, written and flushed as they are produced).
 #include <sys/stat.h>
 
 #include <cctype>

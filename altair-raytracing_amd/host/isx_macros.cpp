@@ -37,6 +37,7 @@ RunOptions& options() {
     if (const char* s = std::getenv("ISX_DEVICE")) r.device = std::atoi(s);
     if (const char* s = std::getenv("ISX_RAYS")) r.rays_override = std::atol(s);
     if (const char* s = std::getenv("ISX_QUIET")) r.quiet = std::atoi(s) != 0;
+    if (const char* s = std::getenv("ISX_FLUSH_ROWS")) r.flush_rows = std::atoi(s);
     return r;
   }();
   return o;
@@ -173,10 +174,11 @@ std::string fluxmap_header(const FluxMapMeta& m, const std::string& generated) {
   return o.str();
 }
 
-std::string fluxmap_rows(const uint64_t* hits, long n, int nTheta, int nPhi, int fold) {
+std::string fluxmap_rows(const uint64_t* hits, long n, int nTheta, int nPhi, int fold, int row0, int nRows) {
   std::ostringstream o;
   o << std::fixed << std::setprecision(6);
-  for (int i = 0; i < nTheta; i++) {
+  const int rowEnd = nRows < 0 ? nTheta : std::min(nTheta, row0 + nRows);
+  for (int i = row0; i < rowEnd; i++) {
     const double theta = (i + 0.5) * 90.0 / nTheta;
     if (fold == 2) {  // fluxAtObserverFast.C:693-720: (theta,phi1) then (theta,phi1+180)
       for (int j = 0; j < nPhi / 2; j++) {
@@ -667,15 +669,31 @@ void sweepDetector(bool notify, const char* saveFolder, int /*threads: ignored, 
   c.n_theta = nThetaBins; c.n_phi = nPhiBins; c.det_diameter = detector.width; c.det_distance = 100 * cm;
   c.exit_port_z = exitPortZ;
   std::vector<uint64_t> hits((size_t)totalPositions);
-  isx_stats st;
+  isx_stats st{};
   const uint64_t total = (uint64_t)n * (uint64_t)totalPositions;
-  const int rc = fluxmap_per_position_all(&c, (uint64_t)n, 1, (uint64_t)totalPositions, options().seed, take_rays(total),
-                                          hits.data(), &st);
-  if (rc != ISX_OK) {
-    err() << "Error: isx_fluxmap_per_position: " << isx_strerror(rc) << std::endl;
-    return;
+  const uint64_t first = take_rays(total);
+  // The reference writes and flushes every row as it is produced (:575-579), so a run of hours leaves its rows behind if it
+  // dies.  A map takes 0.3 s here; one made long (ISX_RAYS) is cut into batches of whole theta rows -- ISX_FLUSH_ROWS, default
+  // as many rows as hold about 4e9 rays -- each ONE launch, written and flushed before the next starts.  Position g keeps its
+  // rays [first + g n, +n) whatever the batching, so the rows are the same rows.
+  int rowsPerBatch = options().flush_rows;
+  if (rowsPerBatch < 1) rowsPerBatch = (int)std::max<uint64_t>(1, 4000000000ull / ((uint64_t)n * (uint64_t)nPhiBins));
+  rowsPerBatch = std::min(rowsPerBatch, nThetaBins);
+  for (int row0 = 0; row0 < nThetaBins; row0 += rowsPerBatch) {
+    const int nRows = std::min(rowsPerBatch, nThetaBins - row0);
+    isx_stats part{};
+    const int rc = fluxmap_per_position_range_all(&c, (uint64_t)n, 1, (uint64_t)row0 * nPhiBins, (uint64_t)nRows * nPhiBins,
+                                                  options().seed, first, hits.data(), &part);
+    if (rc != ISX_OK) {   // (the status is the job's: every rank leaves here together)
+      err() << "Error: isx_fluxmap_per_position: " << isx_strerror(rc) << " (theta rows " << row0 << "... not written)" << std::endl;
+      return;
+    }
+    csvFile << fluxmap_rows(hits.data(), n, nThetaBins, nPhiBins, 1, row0, nRows);
+    csvFile.flush();
+    st.launched += part.launched; st.exited += part.exited; st.counted_below_z += part.counted_below_z;
+    st.absorbed += part.absorbed; st.suspended += part.suspended; st.bin_increments += part.bin_increments;
+    st.wall_hits += part.wall_hits; st.t_kernel_ms += part.t_kernel_ms;
   }
-  csvFile << fluxmap_rows(hits.data(), n, nThetaBins, nPhiBins);
   const double realTime = now_s() - t0;
   // the stream is still in fixed/6 mode in the reference when the footer is written (:575,:668)
   csvFile << std::fixed << std::setprecision(6);

@@ -51,6 +51,8 @@ struct RunOptions {
   int device = 0;                  // env ISX_DEVICE
   long rays_override = -1;         // env ISX_RAYS: replaces the macros' hard-coded n (tests)
   bool quiet = false;              // env ISX_QUIET
+  int flush_rows = 0;              // env ISX_FLUSH_ROWS: theta rows per launch of the per-position sweep, written and flushed
+                                   // before the next launch starts (0 = as many as hold ~4e9 rays: one launch for the reference's n)
 };
 RunOptions& options();
 // Binds libisx to options().device on first use; false (and a message on cerr) if no GPU.
@@ -75,7 +77,7 @@ struct FluxMapMeta {
 // header exactly as fluxAtObserverOptimize.C:504-518 / fluxAtObserverFast.C:1117-1132
 std::string fluxmap_header(const FluxMapMeta& m, const std::string& generated);
 // rows "theta,phi,fraction" fixed/6, theta-major (fold 2: twofold row order j, j+nPhi/2)
-std::string fluxmap_rows(const uint64_t* hits, long n, int nTheta, int nPhi, int fold = 1);
+std::string fluxmap_rows(const uint64_t* hits, long n, int nTheta, int nPhi, int fold = 1, int row0 = 0, int nRows = -1);
 
 // --- offline analysis of a flux-map CSV, the numeric part of flux_at_observer/flux_analysis.py
 // (process_file :11-57, per-theta mean + standard error :182-199, fit a*cos(b*theta)+c :60-62,200-209,

@@ -223,8 +223,8 @@ def test_multirank_launch_stops_instead_of_hanging(cli, tmp_path):
 
 
 # --------------------------------------------------------------------------------------------- GPU
-def _run(cli, cwd, entry, *args, rays=None, seed=None):
-    env = dict(os.environ, ISX_QUIET="1")
+def _run(cli, cwd, entry, *args, rays=None, seed=None, **extra_env):
+    env = dict(os.environ, ISX_QUIET="1", **extra_env)
     if rays is not None:
         env["ISX_RAYS"] = str(rays)
     if seed is not None:
@@ -275,6 +275,25 @@ def test_per_position_and_twofold_entry_points(cli, isx, tmp_path):
     assert list(rows[:4, 1]) == [2.0, 182.0, 6.0, 186.0]
     order = np.array([[i * 90 + j, i * 90 + j + 45] for i in range(180) for j in range(45)]).reshape(-1)
     assert np.array_equal(rows[:, 2], np.array([float(f"{h / 200.0:.6f}") for h in hits.reshape(-1)[order]]))
+
+
+@pytest.mark.gpu
+def test_per_position_sweep_written_in_flushed_row_batches(cli, isx, tmp_path):
+    """fluxAtObserverOptimize.C:575-579 writes and flushes every row as it is produced.  Here: ISX_FLUSH_ROWS theta rows per
+    launch, written before the next launch starts -- the same rows and the same footer as the one-launch file, also when the
+    batch size does not divide 180."""
+    files = {}
+    for rows_per_batch in ("0", "7", "180", "1"):
+        _run(cli, tmp_path, "fluxAtObserverOptimize::sweepDetector", f"folder=b{rows_per_batch}", "srcZ=-75", "dirY=0", rays=60, seed=11,
+             ISX_FLUSH_ROWS=rows_per_batch)
+        files[rows_per_batch] = parse_fluxmap(tmp_path / f"b{rows_per_batch}" / "fluxmap_60rays_180x90_src-60_0_-75.csv")
+    meta0, header0, rows0 = files["0"]
+    hits, st = isx.fluxmap_per_position(isx.default_config(), 60, 11, 1)
+    assert np.array_equal(rows0[:, 2], np.array([float(f"{h / 60.0:.6f}") for h in hits.reshape(-1)]))
+    for k in ("7", "180", "1"):
+        meta, header, rows = files[k]
+        assert header == header0 and np.array_equal(rows, rows0), k
+        assert meta["Total ray hits"] == meta0["Total ray hits"] == f"{int(hits.sum())} out of {60 * 16200}"
 
 
 @pytest.mark.gpu
