@@ -484,6 +484,15 @@ def test_cull_is_conservative_on_random_geometries(isx, orc):
         culled, sc = isx.fluxmap(c, n, 1000 + k)
         assert np.array_equal(brute, culled), (k, [getattr(c, f) for f in ("theta_max_deg", "n_theta", "n_phi", "det_diameter", "det_distance", "exit_port_z")])
         assert sb.bin_increments == sc.bin_increments == int(culled.sum())
+        # the fused kernels send every line off their fast path through the box windows (the binning kernel of the default
+        # two-kernel pipeline keeps cap windows for lines well inside the detector sphere): same map from both
+        isx.set_option("pipeline", 0)
+        try:
+            fused, sf = isx.fluxmap(c, n, 1000 + k)
+        finally:
+            isx.set_option("pipeline", 1)
+        assert np.array_equal(fused, culled), k
+        assert sf.bin_increments == sc.bin_increments
         with_hits += int(sc.bin_increments > 1000)
         if k % 8 == 0:
             co = orc.default_config()
