@@ -350,7 +350,7 @@ int enqueue(int sink, const isx_config* c, uint64_t n, uint64_t seed, uint64_t f
     const int pblock = S.trace_block, pwaves = pblock / 64;
     const size_t lds_trace = 16 + 64 + sizeof(Geom) + sizeof(DetGrid);
     const size_t lds_bin = (((size_t)d.nbins * 4 + 15) & ~(size_t)15) + (size_t)(4 * d.n_theta) * 8 + (size_t)(2 * d.n_phi) * sizeof(ColX) +
-                           sizeof(DetGrid) + (size_t)pwaves * 64 * 4 + 16;
+                           sizeof(DetGrid) + (size_t)pwaves * 128 * 4 + 16;
     if (lds_bin <= S.lds_limit) {
       const uint64_t chunk = n < S.pipe_chunk ? n : S.pipe_chunk;
       const int cgrid = pick_grid(chunk, pblock, S.trace_blocks_per_cu);

@@ -312,9 +312,12 @@ __device__ __forceinline__ void box_window(const BoxLine& b, float zrel0, float 
 // |dot32| < 2e-4 + 5u Md also leaves tier 1 (the reference rejects |dot| < 1e-10; tier 2 keeps its 1e-4 guard).
 typedef float isx_f2 __attribute__((ext_vector_type(2)));
 template <class D>
-__device__ __forceinline__ void walk_columns(const D& d, uint32_t* __restrict__ hist, const ColX* __restrict__ colx, const V3& P,
-                                             const V3& V, double t0, int lane, int i, const double* __restrict__ rowt, int jlo,
-                                             int start, int len, int path) {
+__device__ __forceinline__ void walk_columns(const D& d, uint32_t* __restrict__ hist, const ColX* __restrict__ colx, const V3& P0,
+                                             const V3& V0, double t0, int lane, int i, const double* __restrict__ rowt, int jlo,
+                                             int start, int len, int path, const double* refetch = nullptr) {
+  // refetch (packed walk of the binning kernel: per-lane lines): the line is read again from the workspace by the rare
+  // binary64 / reference-order tiers instead of living in 12 VGPRs through the column loop
+  const V3 &P = P0, &V = V0;
   isx_f2 k0a = {0.f, 0.f}, k1a = {0.f, 0.f}, k2a = {0.f, 0.f};   // (dot, num)
   isx_f2 k0b = {0.f, 0.f}, k1b = {0.f, 0.f}, k2b = {0.f, 0.f};   // (-2 dv, dd - (w/2)^2)
   float band32 = 0.f, dmin32 = 0.f;
@@ -363,6 +366,12 @@ __device__ __forceinline__ void walk_columns(const D& d, uint32_t* __restrict__ 
         int ir = i;
         asm volatile("" : "+v"(ir));
         const double sd = rowt[4 * ir + 0], cd = rowt[4 * ir + 1], zz = rowt[4 * ir + 2], ad = rowt[4 * ir + 3];
+        V3 P, V;
+        if (refetch != nullptr) {
+          const double2* src = reinterpret_cast<const double2*>(refetch + (ir - i));   // (ir - i = 0, behind the barrier: no CSE with the first read)
+          const double2 a = src[0], b = src[1], c = src[2];
+          P.x = a.x; P.y = a.y; P.z = b.x; V.x = b.y; V.y = c.x; V.z = c.y;
+        } else { P = P0; V = V0; }
         const double pz = P.z - zz;
         const double dot = fma(sd * V.y, cph, fma(-(sd * V.x), sph, -(cd * V.z)));
         const double num = fma(sd * P.y, cph, fma(-(sd * P.x), sph, -(cd * pz)));
@@ -390,6 +399,26 @@ __device__ __forceinline__ void walk_columns(const D& d, uint32_t* __restrict__ 
       cp++;
     }
     if (hit) atomicAdd(reinterpret_cast<uint32_t*>(reinterpret_cast<unsigned char*>(hist) + boff), 1u);
+  }
+}
+
+// the column window of row (z_i, A_i) inside the cap `w` (the start may be negative: walk_columns wraps it)
+__device__ __forceinline__ void cap_window(const CapWin& w, float zi, float Ai, int n_phi, int& jlo, int& cnt) {
+  const float dzi = zi - w.Fz;
+  const float num = fmaf(Ai, Ai, fmaf(dzi, dzi, w.AF2)) - w.ch2;
+  const float den = 2.0f * Ai * w.AF;
+  const float slack = 2e-5f * (fmaf(Ai, Ai, w.AF2) + w.ch2);  // f32 rounding of num
+  if (num - slack <= -den) { jlo = 0; cnt = n_phi; }
+  else if (num - slack > den) { jlo = 0; cnt = 0; }
+  else {
+    float K = (num - slack) * rcp_cull(den) - 2e-5f;
+    K = fminf(1.f, fmaxf(-1.f, K));
+    const float dl = acos_cull(K) + 1e-3f;
+    const float hw = dl * w.inv_dphi;
+    const int lo = (int)ceilf(w.jf - hw), hi = (int)floorf(w.jf + hw);
+    jlo = lo; cnt = hi - lo + 1;
+    if (cnt < 0) cnt = 0;
+    if (cnt >= n_phi) { jlo = 0; cnt = n_phi; }
   }
 }
 
@@ -442,22 +471,7 @@ __device__ __forceinline__ void walk_rows(const D& d, uint32_t* __restrict__ his
             jlo = sweep == 0 ? j0 : j1;
             cnt = sweep == 0 ? c0 : c1;
           } else {
-            const float dzi = zi - w.Fz;
-            const float num = fmaf(Ai, Ai, fmaf(dzi, dzi, w.AF2)) - w.ch2;
-            const float den = 2.0f * Ai * w.AF;
-            const float slack = 2e-5f * (fmaf(Ai, Ai, w.AF2) + w.ch2);  // f32 rounding of num
-            if (num - slack <= -den) { jlo = 0; cnt = d.n_phi; }
-            else if (num - slack > den) { cnt = 0; }
-            else {
-              float K = (num - slack) * rcp_cull(den) - 2e-5f;
-              K = fminf(1.f, fmaxf(-1.f, K));
-              const float dl = acos_cull(K) + 1e-3f;
-              const float hw = dl * w.inv_dphi;
-              const int lo = (int)ceilf(w.jf - hw), hi = (int)floorf(w.jf + hw);
-              jlo = lo; cnt = hi - lo + 1;
-              if (cnt < 0) cnt = 0;
-              if (cnt >= d.n_phi) { jlo = 0; cnt = d.n_phi; }
-            }
+            cap_window(w, zi, Ai, d.n_phi, jlo, cnt);
           }
         }
         if (MODE == MODE_BOX && sweep == 0 && pass == 0 && __ballot(second) != 0ull) nsweep = 2;
@@ -611,6 +625,100 @@ __device__ inline void bin_culled(const DG& dd, uint32_t* __restrict__ hist,
     const int ilo = max((int)floorf((thF - omega) * inv_dth - 0.5f - 1e-3f), 0);
     const int ihi = min((int)ceilf((thF + omega) * inv_dth - 0.5f + 1e-3f), d.n_theta - 1);
     walk_rows<MODE_CAP>(d, hist, rowt, colx, P, V, lane, ilo, ihi, w, BoxLine(), split, 1);
+  }
+}
+
+// ---- the fast-path lines of a batch of 64, their rows PACKED over the lanes (binning kernel).  A line of the headline
+// configuration owns ~48 detector rows, so "lane = row, one line at a time" leaves a quarter of the wave idle through the window
+// set-up, the coefficient set-up and the column walk.  Here the rows of all fast-path lines of the batch form one list (line l
+// owns the slots [excl_l, incl_l) of it: a wave scan of the row counts) and the wave takes 64 slots at a time, whatever lines
+// they belong to: lane -> slot -> (owner line, row).  The owner is found without a search: every line that owns a slot of
+// the pass marks its first slot there in wave-private LDS, and a lane's owner is the nearest mark at or below it (ballot +
+// count-leading-zeros).  The owner's cap comes through ds_bpermute, its line from the workspace again; the rest (window, split pass for long windows,
+// coefficients, column walk, exact decision) is the code of walk_rows / walk_columns with per-lane instead of wave-uniform
+// line data -- the same candidates, each once, so the same histogram.
+__device__ __forceinline__ double shfl_f64(double x, int src) {
+  const long long b = __double_as_longlong(x);
+  const int lo = __shfl((int)(b & 0xffffffffll), src, 64), hi = __shfl((int)(b >> 32), src, 64);
+  return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+}
+template <class D>
+__device__ __forceinline__ void walk_lines_packed(const D& d, uint32_t* __restrict__ hist, const double* __restrict__ rowt,
+                                                  const ColX* __restrict__ colx, const double* __restrict__ lines,
+                                                  const RecPre& pre, int nrow, int excl, int incl, int total, float inv_dphi,
+                                                  int lane, int* mark, int* split) {
+#pragma unroll 1
+  for (int base = 0; base < total; base += 64) {
+    int npass = 1, logq = 0, nlong = 0;
+#pragma unroll 1
+    for (int pass = 0; pass < npass; ++pass) {
+      int owner = 0, i = 0, part = 0;
+      bool have = false;
+      if (pass == 0) {
+        const int g = base + lane;
+        have = g < total;
+        volatile int* mk = mark;
+        mk[lane] = 0;
+        __builtin_amdgcn_wave_barrier();
+        if (nrow > 0 && excl < base + 64 && incl > base) mk[(excl > base ? excl : base) - base] = lane + 1;
+        __builtin_amdgcn_wave_barrier();
+        const int m = mk[lane];
+        const unsigned long long low = __ballot(m != 0) & (~0ull >> (63 - lane));   // marks at or below this lane
+        const int pos = 63 - __builtin_clzll(low | 1ull);                           // (slot `base` always carries one)
+        owner = mk[pos] - 1;
+        if (!have || owner < 0) { owner = 0; have = false; }
+        const int o_excl = __shfl(excl, owner, 64), o_rows = __shfl(pre.rows, owner, 64);
+        i = (o_rows & 0xffff) + (g - o_excl);
+      } else {
+        const int slot = lane >> logq;
+        part = lane & ((1 << logq) - 1);
+        have = slot < nlong;
+        const int e = have ? reinterpret_cast<volatile int*>(split)[slot] : 0;
+        owner = e & 63;
+        i = e >> 8;
+      }
+      if (!have) i = 0;
+      // the owner's line and cap (every lane takes part in the exchange)
+      CapWin w;
+      w.inv_dphi = inv_dphi;
+      w.Fz = __shfl(pre.Fz, owner, 64); w.AF = __shfl(pre.AF, owner, 64); w.AF2 = w.AF * w.AF;
+      w.jf = __shfl(pre.jf, owner, 64); w.ch2 = __shfl(pre.ch2, owner, 64);
+      V3 P, V;   // (read again from the batch's 3 KB of exit lines: lanes of one owner share the cache lines)
+      {
+        const double2* src = reinterpret_cast<const double2*>(lines + 6 * owner);
+        const double2 a = src[0], b = src[1], c = src[2];
+        P.x = a.x; P.y = a.y; P.z = b.x; V.x = b.y; V.y = c.x; V.z = c.y;
+      }
+      int jlo = 0, cnt = 0;
+      if (have) cap_window(w, (float)rowt[4 * i + 2], (float)rowt[4 * i + 3], d.n_phi, jlo, cnt);
+      int start = 0, len = cnt;
+      if (pass == 0) {
+        const unsigned long long lm = __ballot(cnt > kSplitAt);
+        if (lm != 0ull && __ballot(cnt >= kSplitAt + 16) != 0ull) {
+          nlong = (int)__popcll(lm);
+          logq = nlong <= 8 ? 3 : (nlong <= 16 ? 2 : (nlong <= 32 ? 1 : 0));
+          if (logq > 0) {
+            npass = 2;
+            if (cnt > kSplitAt) {
+              const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(lm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)lm, 0u));
+              reinterpret_cast<volatile int*>(split)[rank] = owner | (i << 8);
+              len = kSplitAt;
+            }
+            __builtin_amdgcn_wave_barrier();
+          }
+        }
+      } else {
+        const int rem = cnt - kSplitAt;
+        const int chunk = (rem + (1 << logq) - 1) >> logq;
+        start = kSplitAt + part * chunk;
+        len = rem - part * chunk;
+        len = len < 0 ? 0 : (len > chunk ? chunk : len);
+        if (!have) len = 0;
+      }
+      ISX_DIAG_ADD(11, 1); if (pass == 1) ISX_DIAG_ADD(10, 1);
+      const double t0 = -fma(P.x, V.x, fma(P.y, V.y, (P.z - d.portz) * V.z));
+      walk_columns(d, hist, colx, P, V, t0, lane, i, rowt, jlo, start, len, 0, lines + 6 * owner);
+    }
   }
 }
 
@@ -1214,7 +1322,8 @@ isx_bin_lines_kernel(const DetGrid d_arg, const Work wk) {
   __syncthreads();
   typedef __attribute__((address_space(3))) DetGrid LdsDetGrid;
   const volatile LdsDetGrid& d = *(const volatile LdsDetGrid*)d_lds;
-  int* spl = split_all + (tid >> 6) * 64;
+  int* spl = split_all + (tid >> 6) * 128;   // per wave: 64 ints of long-row list + 64 ints of owner marks
+  int* mrk = spl + 64;
 
   const uint64_t wave = (uint64_t)blockIdx.x * (uint64_t)wpb + (uint64_t)(tid >> 6);
   const uint64_t nwaves = (uint64_t)gridDim.x * (uint64_t)wpb;
@@ -1222,14 +1331,16 @@ isx_bin_lines_kernel(const DetGrid d_arg, const Work wk) {
   const uint64_t base = wave * q + (wave < rem ? wave : rem);   // ray offset of the wave's range = first slot of its slice
   const uint32_t n_lines = d_arg.rec_counts[wave];
   const double* rec = d_arg.rec_lines + 6ull * base;
-  GridConst k;
-  k.Rf = (float)d_arg.R; k.rho = (float)d_arg.rho_d; k.portz = (float)d_arg.portz; k.n_theta = d_arg.n_theta;
-  k.inv_dphi = (float)d_arg.n_phi * 0.15915494309f;
-  k.inv_dth = (float)k.n_theta * 0.63661977237f;
   const int bin_mode = d_arg.bin_mode;
 #pragma unroll 1
   for (uint32_t b0 = 0; b0 < n_lines; b0 += 64u) {
     const bool have = b0 + (uint32_t)lane < n_lines;
+    // (wave-uniform constants of the per-line preparation, derived again for every batch from the LDS copy of the grid: kept
+    //  across the walks below they would sit in VGPRs -- gfx950 has no scalar float unit -- and push three values to scratch)
+    GridConst k;
+    k.Rf = (float)d.R; k.rho = (float)d.rho_d; k.portz = (float)d.portz; k.n_theta = d.n_theta;
+    k.inv_dphi = (float)d.n_phi * 0.15915494309f;
+    k.inv_dth = (float)k.n_theta * 0.63661977237f;
     V3 lp, lv;
     lp.x = lp.y = lp.z = 0.0; lv.x = lv.y = 0.0; lv.z = -1.0;
     RecPre pre;
@@ -1240,32 +1351,43 @@ isx_bin_lines_kernel(const DetGrid d_arg, const Work wk) {
       lp.x = a.x; lp.y = a.y; lp.z = b.x; lv.x = b.y; lv.y = c.x; lv.z = c.y;
       if (bin_mode == 1) pre = prep_record(k, lp, lv);
     }
-    unsigned long long em = __ballot(have && pre.rows != -2);   // (lines that cannot hit anything end here, 64 at a time)
-    ISX_DIAG_ADD(3, __popcll(__ballot(have && pre.rows == -2)));
+    struct { int n_phi; double half_w2, portz; const double* table; } dfast;
+    dfast.n_phi = d.n_phi; dfast.half_w2 = d.half_w2; dfast.portz = d_arg.portz; dfast.table = d.table;
+    if (bin_mode == 0) {   // brute-force reference-order test of every bin (tests)
+      unsigned long long em = __ballot(have);
+      while (em) {
+        const int src = __builtin_ctzll(em);
+        em &= em - 1ull;
+        V3 P, V;
+        P.x = readlane_f64(lp.x, src); P.y = readlane_f64(lp.y, src); P.z = readlane_f64(lp.z, src);
+        V.x = readlane_f64(lv.x, src); V.y = readlane_f64(lv.y, src); V.z = readlane_f64(lv.z, src);
+        bin_brute(d, hist, P, V, lane);
+      }
+      continue;
+    }
+    // (lines that cannot hit anything -- pre.rows == -2 -- end here, 64 at a time)
+    { const int n_far = (int)__popcll(__ballot(have && pre.rows == -2)); (void)n_far; ISX_DIAG_ADD(3, n_far); }
+    // lines off the fast path: one at a time, lane = row (cap or box windows)
+    unsigned long long em = __ballot(have && pre.rows == -1);
     while (em) {
       const int src = __builtin_ctzll(em);
       em &= em - 1ull;
       V3 P, V;
       P.x = readlane_f64(lp.x, src); P.y = readlane_f64(lp.y, src); P.z = readlane_f64(lp.z, src);
       V.x = readlane_f64(lv.x, src); V.y = readlane_f64(lv.y, src); V.z = readlane_f64(lv.z, src);
-      if (bin_mode == 0) { bin_brute(d, hist, P, V, lane); continue; }
-      const int rows = __builtin_amdgcn_readlane(pre.rows, src);
-      if (rows >= 0) {
-        struct { int n_phi; double half_w2, portz; const double* table; } dfast;
-        dfast.n_phi = d.n_phi; dfast.half_w2 = d.half_w2; dfast.portz = d_arg.portz; dfast.table = d.table;
-        CapWin wfast;
-        wfast.inv_dphi = k.inv_dphi;
-        wfast.Fz = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, pre.Fz), src));
-        wfast.AF = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, pre.AF), src));
-        wfast.AF2 = wfast.AF * wfast.AF;
-        wfast.jf = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, pre.jf), src));
-        wfast.ch2 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, pre.ch2), src));
-        ISX_DIAG_ADD(0, 1);
-        walk_rows<MODE_CAP>(dfast, hist, rowt, colx, P, V, lane, rows & 0xffff, rows >> 16, wfast, BoxLine(), spl, 0);
-      } else {
-        bin_culled<true>(d, hist, rowt, colx, P, V, lane, spl);
-      }
+      bin_culled<true>(d, hist, rowt, colx, P, V, lane, spl);
     }
+    // fast-path lines: their rows packed over the lanes
+    const int nrow = (have && pre.rows >= 0) ? ((pre.rows >> 16) - (pre.rows & 0xffff) + 1) : 0;
+    int incl = nrow;
+#pragma unroll
+    for (int dlt = 1; dlt < 64; dlt <<= 1) {
+      const int o = __shfl_up(incl, dlt, 64);
+      if (lane >= dlt) incl += o;
+    }
+    const int total = __builtin_amdgcn_readlane(incl, 63);
+    { const int n_fast = (int)__popcll(__ballot(nrow > 0)); (void)n_fast; ISX_DIAG_ADD(0, n_fast); }
+    walk_lines_packed(dfast, hist, rowt, colx, rec + 6ull * b0, pre, nrow, incl - nrow, incl, total, k.inv_dphi, lane, mrk, spl);
   }
   __syncthreads();
   unsigned long long flushed = 0;
