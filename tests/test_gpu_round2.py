@@ -308,6 +308,45 @@ def test_every_bin_of_the_reference_maps(isx, k):
     assert TOTAL_WINDOW[0] < ratio < TOTAL_WINDOW[1], (info["name"], ratio)
 
 
+def test_reference_maps_differ_from_this_build_by_a_smooth_function_of_theta_only(isx):
+    """The sharpest statement the reference's data allows (profiles/r02_parity_scan.md section 6): against this build's bin
+    probabilities known 'exactly' (2e9-ray trace-once map: every ray tested against every bin), each of the seven 8.1e8-ray maps
+    of the reference has chi2/dof 1.03-1.08; after ONE smooth factor of the detector angle theta (6th-order polynomial, 7
+    parameters, |f - 1| < 3 %) it is 1.00 +- 0.011 -- the bins scatter binomially, nothing depends on phi, no overdispersion.
+    A change of the model that moved the maps in any other way (a phi structure, a rim effect, a different port) fails here."""
+    N = 2_000_000_000
+    worst = []
+    for k, (info, ref) in enumerate(m for m in _ref_maps() if m[0]["kind"] == "per_position" and m[0]["complete"]):
+        c = isx.default_config()
+        c.theta_max_deg = info["port_deg"]
+        for a in range(3):
+            c.src[a] = info["source_position"][a]
+            c.dir[a] = info["source_direction"][a]
+        n = info["rays_per_position"]
+        h = np.zeros(16200, np.int64)
+        for part in range(2):
+            hh, _ = isx.fluxmap(c, N // 2, 4242 + k, part * (N // 2))
+            h += hh.astype(np.int64).reshape(-1)
+        p = (h / N).reshape(180, 90)
+        r = ref.astype(np.int64).reshape(180, 90)
+        use = p * n >= 5
+        var = n * p * (1 - p) * (1 + n / N)
+        row = np.array([r[i][use[i]].sum() / (n * p[i][use[i]]).sum() if use[i].any() else 1.0 for i in range(180)])
+        w = np.array([(n * p[i][use[i]]).sum() for i in range(180)])
+        th = (np.arange(180) + 0.5) / 180.0
+        ok = w > 0
+        f = np.polyval(np.polyfit(th[ok], row[ok], 6, w=np.sqrt(w[ok])), th)
+        chi2_0 = float((((r - n * p) ** 2 / np.where(var > 0, var, 1))[use]).sum() / use.sum())
+        chi2_f = float((((r - n * p * f[:, None]) ** 2 / np.where(var > 0, var * f[:, None], 1))[use]).sum() / (use.sum() - 7))
+        print(f"{info['name']}: chi2/dof {chi2_0:.4f} -> {chi2_f:.4f} after f(theta), f in [{f[w > 0.05 * w.max()].min():.4f}, {f[w > 0.05 * w.max()].max():.4f}]")
+        assert 1.01 < chi2_0 < 1.12, (info["name"], chi2_0)            # the residual is there ...
+        assert 0.955 < chi2_f < 1.045, (info["name"], chi2_f)          # ... and it is a smooth factor of theta, nothing else (4 sigma)
+        big = w > 0.05 * w.max()                                       # (rows that carry hits: the last degrees before 90 carry almost none)
+        assert 0.96 < f[big].min() and f[big].max() < 1.04, (info["name"], f[big].min(), f[big].max())
+        worst.append(chi2_f)
+    assert abs(np.mean(worst) - 1.0) < 0.02, worst                     # seven maps together: 1.00 +- 0.0043
+
+
 @pytest.mark.xfail(strict=True, reason="known residual vs the reference's 8.1e8-ray maps: totals 0.3-1.0 % low "
                                        "(profiles/r02_parity_scan.md); the bar is 0.15 %")
 def test_totals_of_the_reference_maps_within_0p15_percent(isx):
