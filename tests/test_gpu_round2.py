@@ -68,12 +68,12 @@ def test_two_kernel_pipeline_equals_the_fused_kernel(isx, orc):
         assert np.array_equal(gh, oh) and np.array_equal(gh, small_ref)
         _census_equal(gst, ost)
         _census_equal(gst, small_st)
-        for block, bpc in ((256, 8), (1024, 1), (512, 2)):
+        for block, bpc in ((256, 8), (1024, 1), (512, 2), (512, 4), (512, 13)):
             isx.set_option("trace_block", block); isx.set_option("trace_blocks_per_cu", bpc)
             h, st = isx.fluxmap(c, 3_000_000, SEED, 17)
             assert np.array_equal(h, ref), (block, bpc)
             _census_equal(st, rst)
-        isx.set_option("trace_block", 512); isx.set_option("trace_blocks_per_cu", 4)
+        isx.set_option("trace_block", 512); isx.set_option("trace_blocks_per_cu", 8)
         isx.set_option("grid_blocks", 1)
         h1, st1 = isx.fluxmap(c, 50000, SEED, 5)
         isx.set_option("grid_blocks", 0)
@@ -82,7 +82,7 @@ def test_two_kernel_pipeline_equals_the_fused_kernel(isx, orc):
         _census_equal(st1, st2)
     finally:
         isx.set_option("grid_blocks", 0)
-        isx.set_option("trace_block", 512); isx.set_option("trace_blocks_per_cu", 4)
+        isx.set_option("trace_block", 512); isx.set_option("trace_blocks_per_cu", 8)
         isx.set_option("pipeline_chunk", 1 << 26)
         isx.set_option("pipeline", 1)
 

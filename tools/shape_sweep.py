@@ -13,8 +13,8 @@ elif which == "brdf":
     c.roughness_rad = 0.5; c.reflectance = 1.0; c.max_points = 10000; c.box_half = 200.0
 n = 50_000_000
 print(f"== {which}: total ms (trace + bin) by trace_block x trace_blocks_per_cu", flush=True)
-for block in (512, 1024):
-    for bpc in (1, 2, 3, 4, 5, 6, 7, 8):
+for block in (512,):
+    for bpc in (8, 12, 16, 24):
         if block * bpc > 6144 or block * bpc < 1024:
             continue
         isx.set_option("trace_block", block); isx.set_option("trace_blocks_per_cu", bpc)
@@ -25,4 +25,4 @@ for block in (512, 1024):
             k = isx.last_kernel_ms()
             best = min(best, (st.t_kernel_ms, k[1], k[2]))
         print(f"block {block:5d} x {bpc:2d} per CU ({block * bpc // 256:2d} waves/SIMD asked): {best[0]:7.2f} = {best[1]:6.2f} + {best[2]:6.2f}", flush=True)
-isx.set_option("trace_block", 512); isx.set_option("trace_blocks_per_cu", 4)
+isx.set_option("trace_block", 512); isx.set_option("trace_blocks_per_cu", 8)
