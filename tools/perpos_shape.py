@@ -1,3 +1,4 @@
+"""Per-position map (8.1e8 rays) and exit-dz histogram times by workgroups per CU of the trace-only kernels (GPU box)."""
 import os, sys
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
 import altair_raytracing_amd as isx
