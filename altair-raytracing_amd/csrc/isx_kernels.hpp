@@ -309,7 +309,13 @@ __device__ __forceinline__ void box_window(const BoxLine& b, float zrel0, float 
 //   2. binary64: the same sign with the 2.1e-9 relative band of round 1 (coefficients derived again from the row constants --
 //      they are no longer resident, which frees 18 VGPRs);
 //   3. the reference's own operation sequence (check_intersection) from the detector table.
-// |dot32| < 2e-4 + 5u Md also leaves tier 1 (the reference rejects |dot| < 1e-10; tier 2 keeps its 1e-4 guard).
+// The reference rejects |dot| < 1e-10 before anything else.  Tier 1 needs no test of its own for that: outside the band the sign
+// of g32 is the sign of the exact g (the bound above does not depend on dot); with |dot| < 1e-10 a NEGATIVE exact g needs
+// |num| < 2e-10 Mv, hence |g| < 1e-15, and |g32| <= |g| + 18u S exceeds the band 1.3e-6 S only if S < 4.3e-9 -- rows with
+// S < 1e-6 are not decided by tier 1 at all (band = inf) -- so tier 1 never says "hit" there, and "miss" is the reference's
+// answer.  For 1e-10 <= |dot| the reference's own float evaluation has the sign of the exact g whenever |g| > 1e-15 (dd dot^2 +
+// num^2), nine orders of magnitude inside the band.  (Tier 2 keeps its |dot| < 1e-4 guard.)  One compare and one register
+// less per column step; a -DISX_DIAG build re-checks every tier-1 decision against the reference-order test.
 typedef float isx_f2 __attribute__((ext_vector_type(2)));
 template <class D>
 __device__ __forceinline__ void walk_columns(const D& d, uint32_t* __restrict__ hist, const ColX* __restrict__ colx, const V3& P0,
@@ -320,7 +326,7 @@ __device__ __forceinline__ void walk_columns(const D& d, uint32_t* __restrict__ 
   const V3 &P = P0, &V = V0;
   isx_f2 k0a = {0.f, 0.f}, k1a = {0.f, 0.f}, k2a = {0.f, 0.f};   // (dot, num)
   isx_f2 k0b = {0.f, 0.f}, k1b = {0.f, 0.f}, k2b = {0.f, 0.f};   // (-2 dv, dd - (w/2)^2)
-  float band32 = 0.f, dmin32 = 0.f;
+  float band32 = 0.f;
   if (len > 0) {
     const double Sd = rowt[4 * i + 0], Cd = rowt[4 * i + 1], zd = rowt[4 * i + 2], Ad = rowt[4 * i + 3];
     const double qx = fma(t0, V.x, P.x), qy = fma(t0, V.y, P.y), qz = fma(t0, V.z, P.z);   // Pq: same line, nearest to O
@@ -335,28 +341,33 @@ __device__ __forceinline__ void walk_columns(const D& d, uint32_t* __restrict__ 
     k0b.y = (float)f0; k1b.y = (float)f1; k2b.y = (float)f2;
     const double Md = fabs(a0) + (fabs(a1) + fabs(a2)), Mn = fabs(b0) + (fabs(b1) + fabs(b2));
     const double Mv = fabs(e0) + (fabs(e1) + fabs(e2)), Mf = fabs(f0) + (fabs(f1) + fabs(f2));
-    band32 = (float)(1.3e-6 * fma(Md, fma(Md, Mf, Mn * Mv), Mn * Mn)) * 1.000001f + 1e-30f;
-    dmin32 = (float)fma(3.0e-7, Md, 2.0e-4);
+    const double S = fma(Md, fma(Md, Mf, Mn * Mv), Mn * Mn);
+    // (a row whose magnitudes all vanish -- the line through the row's own centre point on the axis -- is left to the binary64 tier)
+    band32 = S >= 1e-6 ? (float)(1.3e-6 * S) * 1.000001f + 1e-30f : __builtin_inff();
     if (jlo < 0) jlo += d.n_phi;   // start column in [0, n_phi); the window then runs to < 2 n_phi
   }
   const ColX* cp = colx + (jlo + start);
   const uint32_t rowoff = (uint32_t)(i * d.n_phi) * 4u;
+  // the row's bins through an LDS-typed pointer: one add per column step (row base + column offset), no generic address
+  typedef __attribute__((address_space(3))) uint32_t LdsU32;
+  typedef __attribute__((address_space(3))) unsigned char LdsByte;
+  LdsByte* const rowbins = reinterpret_cast<LdsByte*>((__attribute__((address_space(3))) void*)hist) + rowoff;
   if (len > 0) ISX_DIAG_ADD_LANES(7 + path, len);
   for (int k = 0;; ++k) {                    // until the widest (part of a) window of the wave is done
     const bool act = k < len;
     if (__ballot(act) == 0ull) break;
     ISX_DIAG_ADD(4 + path, 1);
-    bool hit = false;
-    uint32_t boff = 0;
     if (act) {
+      bool hit = false;
       const float c32 = cp->c32, s32 = cp->s32;
-      boff = rowoff + cp->off4;
+      const uint32_t o4 = cp->off4;
+      LdsByte* const bin = rowbins + o4;
       const isx_f2 cc = {c32, c32}, ss = {s32, s32};
       const isx_f2 ta = __builtin_elementwise_fma(k1a, cc, __builtin_elementwise_fma(k2a, ss, k0a));   // (dot, num)
       const isx_f2 tb = __builtin_elementwise_fma(k1b, cc, __builtin_elementwise_fma(k2b, ss, k0b));   // (-2dv, ddw)
       const float g = fmaf(ta.x, fmaf(ta.x, tb.y, ta.y * tb.x), ta.y * ta.y);
       hit = g < 0.f;
-      if (!(fabsf(g) > band32) || !(fabsf(ta.x) >= dmin32)) {
+      if (!(fabsf(g) > band32)) {
         // tier 2: binary64 about the original point, exactly the test of round 1
         ISX_DIAG_ADD_LANES(12, 1);
         const double cph = cp->c, sph = cp->s;
@@ -387,18 +398,24 @@ __device__ __forceinline__ void walk_columns(const D& d, uint32_t* __restrict__ 
         hit = diff < 0.0;
         if (fabs(dot) < 1e-4 || fabs(diff) <= bandc) {   // tier 3: too close to call, exact reference-order test
           ISX_DIAG_ADD_LANES(13, 1);
-          hit = check_intersection(d.table + 6 * (size_t)(boff >> 2), d.half_w2, P, V);
+          // (the table pointer passes a compiler barrier here: as a loop invariant its VGPR copy for the flat load
+          //  would be made at kernel start and kept -- or spilled -- through everything)
+          const double* tab = d.table;
+          asm volatile("" : "+v"(tab));
+          hit = check_intersection(tab + 6 * (size_t)((uint32_t)(bin - reinterpret_cast<LdsByte*>((__attribute__((address_space(3))) void*)hist)) >> 2), d.half_w2, P, V);
         }
       }
 #ifdef ISX_DIAG
       {   // tuning builds: a decision taken by tier 1 must be the reference's
-        const bool ref = check_intersection(d.table + 6 * (size_t)(boff >> 2), d.half_w2, P, V);
+        const bool ref = check_intersection(d.table + 6 * (size_t)((uint32_t)(bin - reinterpret_cast<LdsByte*>((__attribute__((address_space(3))) void*)hist)) >> 2), d.half_w2, P, V);
         if (ref != hit) ISX_DIAG_ADD_LANES(14, 1);
       }
 #endif
       cp++;
+      // (inside the active branch, through an LDS-typed pointer: no zero-initialised offset to carry out of it, no generic
+      //  address to rebuild -- two VALU instructions less per column step)
+      if (hit) __hip_atomic_fetch_add(reinterpret_cast<LdsU32*>(bin), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     }
-    if (hit) atomicAdd(reinterpret_cast<uint32_t*>(reinterpret_cast<unsigned char*>(hist) + boff), 1u);
   }
 }
 
@@ -1325,7 +1342,8 @@ isx_bin_lines_kernel(const DetGrid d_arg, const Work wk) {
   int* spl = split_all + (tid >> 6) * 128;   // per wave: 64 ints of long-row list + 64 ints of owner marks
   int* mrk = spl + 64;
 
-  const uint64_t wave = (uint64_t)blockIdx.x * (uint64_t)wpb + (uint64_t)(tid >> 6);
+  // (wave-uniform by construction: through readfirstlane so that the slice pointer lives in scalar registers)
+  const uint64_t wave = (uint64_t)blockIdx.x * (uint64_t)wpb + (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane(tid >> 6);
   const uint64_t nwaves = (uint64_t)gridDim.x * (uint64_t)wpb;
   const uint64_t q = wk.n / nwaves, rem = wk.n % nwaves;
   const uint64_t base = wave * q + (wave < rem ? wave : rem);   // ray offset of the wave's range = first slot of its slice
@@ -1391,9 +1409,11 @@ isx_bin_lines_kernel(const DetGrid d_arg, const Work wk) {
   }
   __syncthreads();
   unsigned long long flushed = 0;
+  unsigned long long* ghist = wk.hist;
+  asm volatile("" : "+s"(ghist));   // (same: no VGPR copy of this pointer held from the prologue)
   for (int b = tid; b < nbins; b += nthr) {
     const uint32_t c = hist[b];
-    if (c) { atomicAdd(&wk.hist[b], (unsigned long long)c); flushed += c; }
+    if (c) { atomicAdd(&ghist[b], (unsigned long long)c); flushed += c; }
   }
   if (flushed) atomicAdd(&wk.stats[5], flushed);
 }
