@@ -111,7 +111,13 @@ def main():
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29517")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        # ISX_BENCH_BACKEND=gloo: rehearsal of the N > 1 path with several ranks on ONE GPU (RCCL refuses two ranks on a device);
+        # the driver's launches never set it
+        backend = os.environ.get("ISX_BENCH_BACKEND", "nccl")
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     import altair_raytracing_amd as isx
     isx.load()
@@ -127,7 +133,10 @@ def main():
 
     def barrier():
         if use_dist:
-            dist.barrier(device_ids=[dev_index])
+            if dist.get_backend() == "nccl":
+                dist.barrier(device_ids=[dev_index])
+            else:
+                dist.barrier()
         torch.cuda.synchronize()
 
     # --- ONE HIP runtime per process: torch's wheel bundles libamdhip64.so with the SONAME libisx.so asks for

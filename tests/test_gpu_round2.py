@@ -389,3 +389,38 @@ def test_bench_distributed_path_in_a_fresh_process(isx):
     h, st = isx.fluxmap(isx.default_config(), count, SEED, first)
     assert out["hist_sum_last_step"] == int(h.sum())
     assert out["census_last_step"]["counted_below_z"] == st.counted_below_z
+
+
+def test_bench_two_ranks_share_the_gpu_over_gloo(isx):
+    """The driver's N = 2 launch line (`python -m torch.distributed.run --nproc-per-node 2 bench.py --gpus 2 ...`) on the one GPU
+    of this box, with gloo instead of RCCL (ISX_BENCH_BACKEND: RCCL refuses two ranks on one device): both ranks trace their
+    slices of every step, ONE all-reduce sums the histograms, rank 0 prints ONE line -- whose last-step histogram sum and
+    census must be those of the two slices traced in this process."""
+    import subprocess
+    import sys
+    rays, steps, warmup = 1_500_000, 2, 1
+    env = dict(os.environ, ISX_BENCH_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "ISX_FORCE_DIST"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+                        "127.0.0.1", "--master-port", "29541", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", str(steps),
+                        "--warmup", str(warmup), "--rays", str(rays), "--cpu-rays", "0"], env=env, capture_output=True, text=True,
+                       timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip().startswith("{")]
+    assert len(lines) == 1, r.stdout
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["steps"] == steps and out["scaling"] == "weak"
+    assert out["config"]["rccl_world_size"] == 2 and out["config"]["torch_backend"] == "gloo"
+    s_last = warmup + steps - 1
+    total, counted0 = 0, 0
+    for rank in range(2):
+        first, count = isx.step_slice(s_last, rank, 2, rays)
+        h, st = isx.fluxmap(isx.default_config(), count, SEED, first)
+        total += int(h.sum())
+        if rank == 0:
+            counted0 = st.counted_below_z
+    assert out["hist_sum_last_step"] == total                           # the all-reduced histogram
+    assert out["census_last_step"]["counted_below_z"] == counted0       # (rank 0's own census)
+    # whole-job throughput: both ranks' rays over the slowest rank's time
+    assert abs(out["value"] - 2 * rays / (out["ms_per_step"] * 1e3)) < 1e-6 * out["value"]
