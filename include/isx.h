@@ -174,8 +174,9 @@ int isx_last_kernel_ms(double* single_ms, double* trace_ms, double* bin_ms);
  * "grid_blocks" (0 = auto); "pipeline" 1 (default): the lean flux maps (headline, chord mode, BRDF source) run as two kernels -- a trace kernel writes
  * the exit lines (48 B per counted ray) to an HBM workspace, a binning kernel reads them ("pipeline_chunk" = rays per pair,
  * default 2^26 = at most 3.2 GB of workspace) -- 0: one fused trace+bin kernel; "sched_mask", "sched_min": batching of the
- * generic boundary search (every (mask+1)-th loop trip or when `min` lanes wait); "trace_block" (256/512/1024) and
- * "trace_blocks_per_cu": workgroup shape of the kernels that keep no LDS histogram.  None of them changes any result. */
+ * generic boundary search (every (mask+1)-th loop trip or when `min` lanes wait); "trace_block" (256/512/1024, default 512) and
+ * "trace_blocks_per_cu" (1..32, default 8): workgroup size and workgroups per CU in the grid of the kernels that keep no LDS
+ * histogram.  None of them changes any result. */
 int isx_set_option(const char* key, int64_t value);
 
 /* Device-side probe of the numeric contract (tests): out[i] = op(a[i],b[i],c[i]) with
