@@ -419,6 +419,15 @@ __device__ __forceinline__ void walk_columns(const D& d, uint32_t* __restrict__ 
   }
 }
 
+// angular radius of a cap of chord `ch` on the sphere of radius R: 2 asin(ch / 2R), padded (acos_cull: 1e-4 rad).  (Until
+// round 2 this was ch/R * 1.01 + 2e-3, which is below 2 asin(ch/2R) once ch > 0.55 R: detectors with rho_d > R/2 lost rows --
+// found by tools/soak_cull.py on 300 random geometries, 7 of them with rho_d/R >= 0.53; no BASELINE configuration has
+// rho_d/R above 0.2.)
+__device__ __forceinline__ float cap_angle(float ch, float iR) {
+  const float x = fminf(1.f, 0.5f * ch * iR);
+  return 2.0f * (1.57079637f - acos_cull(x)) + 3e-3f;
+}
+
 // the column window of row (z_i, A_i) inside the cap `w` (the start may be negative: walk_columns wraps it)
 __device__ __forceinline__ void cap_window(const CapWin& w, float zi, float Ai, int n_phi, int& jlo, int& cnt) {
   const float dzi = zi - w.Fz;
@@ -555,7 +564,7 @@ __device__ __forceinline__ RecPre prep_record(const GridConst& k, const V3& P, c
   const float ch2 = fmaf(ext, ext, k.rho * k.rho) * 1.0001f + 1e-3f;
   if (!(4.0f * (R2 - dO2) > 4.04f * ch2)) return o;
   const float ch = sqrt_cull(ch2);
-  const float omega = ch * rcp_cull(k.Rf) * 1.01f + 2e-3f;
+  const float omega = cap_angle(ch, rcp_cull(k.Rf));
   const double s0 = (double)sF - wv, s1 = -(double)sF - wv;
   const float Fz0 = (float)fma(s0, V.z, P.z), Fz1 = (float)fma(s1, V.z, P.z);
   // fast path: the cap of side 0 reaches detector rows, the cap of side 1 lies above all of them
@@ -611,7 +620,7 @@ __device__ inline void bin_culled(const DG& dd, uint32_t* __restrict__ hist,
     w.ch2 = fmaf(ext, ext, rho * rho) * 1.0001f + 1e-3f;
     caps = 4.0f * (R2 - dO2) > 4.04f * w.ch2;
     ch = sqrt_cull(w.ch2);
-    omega = ch * rcp_cull(Rf) * 1.01f + 2e-3f;          // cap angular radius 2*asin(ch/2R), conservatively
+    omega = cap_angle(ch, rcp_cull(Rf));
   }
   if (!caps) {
     // Grazing or nearly tangent line (the caps would merge), or one that misses S(O,R): typical for the re-scattered rays of the

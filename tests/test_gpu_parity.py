@@ -509,6 +509,63 @@ def test_cull_is_conservative_on_random_geometries(isx, orc):
     assert with_hits >= 30, with_hits
 
 
+def test_cull_with_detectors_as_large_as_their_sphere(isx):
+    """Regression (round 2, found by tools/soak_cull.py): the angular radius of a cap of chord ch was taken as ch/R * 1.01,
+    which is below 2 asin(ch/2R) once ch > 0.55 R -- detector rows were lost for detectors with rho_d > R/2 (7 of 300 random
+    geometries; every BASELINE configuration has rho_d/R <= 0.2).  The seven geometries that failed, plus 40 random ones with
+    rho_d/R between 0.45 and 3, 1e5 rays each: culled == brute through the pipeline and through the fused kernels."""
+    failed = [(164.25311676177378, 113, 14, 40.0, 30.0, -100.0, 0, 1), (168.01598778680042, 82, 171, 40.0, 30.0, -120.0, 0, 1),
+              (169.68505196275942, 175, 61, 40.0, 30.0, -120.0, 1, 0), (158.57581155717358, 199, 71, 40.0, 30.0, -99.0, 1, 0),
+              (165.4082500712795, 89, 164, 40.0, 30.0, -120.0, 0, 1), (176.66119347190593, 131, 87, 190.0, 180.0, -99.0, 1, 0),
+              (153.82489457688416, 139, 67, 40.0, 30.0, -99.0, 0, 0)]
+    rng = np.random.default_rng(31415)
+    cases, seeds = [], []
+    for (tm, nt, nph, dia, dist, pz, sm, tmode), k0 in zip(failed, (41, 131, 133, 166, 194, 214, 231)):
+        seeds.append(5000 + k0)      # (the seeds of the soak run that found them)
+        c = isx.default_config()
+        c.theta_max_deg, c.n_theta, c.n_phi, c.det_diameter, c.det_distance, c.exit_port_z = tm, nt, nph, dia, dist, pz
+        c.source_model, c.trace_mode = sm, tmode
+        c.max_points = 3000
+        cases.append(c)
+    for k in range(40):
+        c = isx.default_config()
+        c.theta_max_deg = float(rng.uniform(150, 178))
+        c.reflectance = float(rng.choice([0.9, 0.97, 0.99, 1.0])); c.max_points = 3000
+        c.src[0], c.src[1], c.src[2] = float(rng.uniform(-70, 70)), float(rng.uniform(-30, 30)), float(rng.uniform(-85, 40))
+        c.dir[0], c.dir[1], c.dir[2] = float(rng.uniform(1, 6)), float(rng.uniform(-3, 3)), float(rng.uniform(-2, 2))
+        c.n_theta, c.n_phi = int(rng.integers(1, 200)), int(rng.integers(1, 180))
+        if c.n_theta * c.n_phi > 36000:
+            c.n_phi = 36000 // c.n_theta
+        c.det_distance = float(rng.choice([30.0, 60.0, 100.0, 180.0]))
+        c.det_diameter = float(c.det_distance * 2 * rng.choice([0.45, 0.55, 0.67, 0.8, 0.95, 1.05, 1.5, 3.0]))
+        c.exit_port_z = float(rng.choice([-100.0, -120.0, -99.0]))
+        c.box_half = float(rng.choice([200.0, 300.0]))
+        if k % 3 == 1:
+            c.source_model = 1
+        elif k % 3 == 2:
+            c.trace_mode = 1
+        cases.append(c)
+        seeds.append(9000 + k)
+    with_hits = 0
+    for k, c in enumerate(cases):
+        n = 100000
+        isx.set_option("bin_mode", 0)
+        try:
+            brute, sb = isx.fluxmap(c, n, seeds[k])
+        finally:
+            isx.set_option("bin_mode", 1)
+        culled, sc = isx.fluxmap(c, n, seeds[k])
+        isx.set_option("pipeline", 0)
+        try:
+            fused, sf = isx.fluxmap(c, n, seeds[k])
+        finally:
+            isx.set_option("pipeline", 1)
+        assert np.array_equal(brute, culled), (k, c.det_diameter, c.det_distance, c.n_theta, c.n_phi)
+        assert np.array_equal(brute, fused), (k, c.det_diameter, c.det_distance, c.n_theta, c.n_phi)
+        with_hits += int(sc.bin_increments > 1000)
+    assert with_hits > 30
+
+
 def test_exit_direction_log_bit_exact(isx, orc):
     """Un-binned exit log (3dRayLog.txt): ids and directions equal the oracle's, in ray order; overflow is reported."""
     def mk(mod):
