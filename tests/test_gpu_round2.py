@@ -424,3 +424,55 @@ def test_bench_two_ranks_share_the_gpu_over_gloo(isx):
     assert out["census_last_step"]["counted_below_z"] == counted0       # (rank 0's own census)
     # whole-job throughput: both ranks' rays over the slowest rank's time
     assert abs(out["value"] - 2 * rays / (out["ms_per_step"] * 1e3)) < 1e-6 * out["value"]
+
+
+def test_random_configurations_equal_the_oracle(isx, orc):
+    """36 random configurations over every field the path reads and every model switch (pencil / BRDF source, explicit / chord
+    trace, Lambertian / rough specular / cos^2-lobe surface, last-segment / origin-compat hit line; wall radii, port angle, port
+    plane, box, grid, detector size up to 1.2 sphere radii, ray limit, random first ray index): flux map and census bit-equal to
+    the oracle's, and per-position maps (both folds) + the exit-dz histogram for the configurations that have them.
+    (`tools/soak_oracle.py` is the long version: 180 configurations, clean.)"""
+    rng = np.random.default_rng(20261004)
+    census = ("launched", "exited", "counted_below_z", "absorbed", "suspended", "bin_increments", "wall_hits")
+    for k in range(36):
+        v = dict(theta_max_deg=float(rng.uniform(150, 178)), reflectance=float(rng.choice([0.9, 0.97, 0.99, 1.0])),
+                 max_points=int(rng.choice([50, 400, 3000])), box_half=float(rng.choice([200.0, 300.0])),
+                 n_theta=int(rng.integers(1, 120)), n_phi=2 * int(rng.integers(1, 70)),
+                 det_distance=float(rng.choice([30.0, 100.0, 180.0])), exit_port_z=float(rng.choice([-100.0, -120.0, -99.0])),
+                 r_in=float(rng.choice([100.1, 60.0])))
+        v["r_out"] = v["r_in"] + float(rng.choice([0.9, 5.0]))
+        v["det_diameter"] = float(v["det_distance"] * 2 * rng.choice([0.02, 0.2, 0.5, 0.8, 1.2]))
+        mode = k % 6
+        if mode == 1:
+            v["source_model"] = 1
+        elif mode == 2:
+            v["trace_mode"] = 1
+        elif mode == 3:
+            v.update(lambertian=0, roughness_rad=float(rng.choice([0.05, 0.3])), reflectance=0.9)
+        elif mode == 4:
+            v["surface_model"] = 1
+        elif mode == 5:
+            v["hit_line_mode"] = 1
+        src = [float(rng.uniform(-0.6, 0.6) * v["r_in"]), float(rng.uniform(-0.3, 0.3) * v["r_in"]), float(rng.uniform(-0.8, 0.4) * v["r_in"])]
+        dr = [float(rng.uniform(1, 6)), float(rng.uniform(-3, 3)), float(rng.uniform(-2, 2))]
+        ci, co = isx.default_config(), orc.default_config()
+        for c in (ci, co):
+            for f, x in v.items():
+                setattr(c, f, x)
+            for a in range(3):
+                c.src[a] = src[a]
+                c.dir[a] = dr[a]
+        n, first = 20000, int(rng.integers(0, 1 << 48))
+        gh, gst = isx.fluxmap(ci, n, 100 + k, first)
+        oh, ost = orc.fluxmap(co, n, 100 + k, first)
+        assert np.array_equal(gh, oh), (k, v)
+        for f in census:
+            assert getattr(gst, f) == getattr(ost, f), (k, f, v)
+        if mode in (0, 2):
+            for fold in (1, 2):
+                gp, _ = isx.fluxmap_per_position(ci, 7, 300 + k, fold)
+                op, _ = orc.fluxmap_per_position(co, 7, 300 + k, fold)
+                assert np.array_equal(gp, op), (k, fold, v)
+            gd, _ = isx.exit_dz_hist(ci, n, 400 + k)
+            od, _ = orc.exit_dz_hist(co, n, 400 + k)
+            assert np.array_equal(gd, od), (k, v)
