@@ -12,6 +12,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <algorithm>
+#include <map>
 #include <vector>
 
 using namespace isx;
@@ -37,13 +38,19 @@ struct State {
   unsigned long long* d_stats = nullptr;  // [8]
   double* d_aux = nullptr;                // caller-supplied detector / disc lists of the current call (grown, never shrunk)
   size_t cap_aux = 0;
-  // two-kernel pipeline of the headline flux map: exit lines in HBM (48 B per traced ray of a chunk) + lines per wave
+  // two-kernel pipeline of the headline flux map: exit lines in HBM, in regions of kRegion 48-byte slots + lines per region
   double* d_rec = nullptr;
-  size_t cap_rec = 0;                     // rays
   uint32_t* d_rec_counts = nullptr;
-  size_t cap_rec_counts = 0;              // waves
+  size_t cap_regions = 0;
   int pipeline = 1;                       // 1 (default): trace kernel -> HBM -> binning kernel (lean flux map); 0: fused kernel
-  uint64_t pipe_chunk = 1ull << 26;       // rays per trace/bin pair (3.2 GB of exit-line workspace at most)
+  uint64_t pipe_chunk = 1ull << 26;       // rays per trace/bin pair (3.4 GB of exit-line workspace at most)
+  // work-queue counters of the launches (Work::ctr): a ring of Q_WORDS-word blocks, one per launch, zeroed on the stream
+  // right before its launch
+  uint32_t* d_ctr = nullptr;
+  size_t ctr_next = 0;
+  static constexpr size_t kCtrRing = 256;
+  int ray_sub = 0;                        // rays a wave takes off the queue at a time (0: by launch size)
+  int bin_block = 512, bin_blocks_per_cu = 0;   // binning kernel: workgroup size, workgroups per CU in the grid (0: what is resident)
   // options
   int bin_mode = 1;
   int blocks_per_cu = 1;   // 1024-thread blocks: 16 waves/CU, 4 per SIMD
@@ -55,9 +62,13 @@ struct State {
   struct Span { size_t a, b; int kind; };   // kind 0: single-kernel launch, 1: trace kernel of the pipeline, 2: its binning kernel
   std::vector<Span> spans;
   double last_ms[3] = {0, 0, 0};           // per kind, of the launches collected by the last collect_stats()
-  // workgroup shape of the kernels that keep no LDS histogram: 512 threads (6 waves per SIMD at <= 80 VGPRs), 8 workgroups per CU in
-  // the grid -- three are resident at a time, the later ones even out the tail (measured 4 -> 8: -2..3 % on every configuration)
-  int trace_block = 512, trace_blocks_per_cu = 8;
+  // workgroup shape of the kernels that keep no LDS histogram: 512 threads (6 waves per SIMD at <= 80 VGPRs); the grid is what
+  // is resident (the waves share one ray queue, so late workgroups have nothing to even out); trace_blocks_per_cu > 0 overrides
+  int trace_block = 512, trace_blocks_per_cu = 0;
+  // hipFuncSetAttribute(MaxDynamicSharedMemorySize) is made once per kernel and size, not once per launch
+  bool attr_set[1] = {false};
+  size_t attr_bin_lds = 0;
+  std::map<const void*, size_t> attr_lds;
 } S;
 
 // Scratch device allocation of one call: freed on every return path.
@@ -237,6 +248,31 @@ int pick_grid(uint64_t n, int block = kBlock, int blocks_per_cu = 0) {
   return want < (uint64_t)full ? (int)want : full;
 }
 
+// workgroups of `fn` (workgroup size `block`, `lds` bytes of dynamic LDS) that are resident on one CU at a time
+template <class F>
+int resident_per_cu(F fn, int block, size_t lds) {
+  int nb = 0;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, fn, block, lds) != hipSuccess || nb < 1) nb = 1;
+  return nb;
+}
+
+// rays a wave takes off the launch's queue at a time: results never depend on it (a ray's history is a function of its index)
+uint32_t pick_sub(uint64_t n) {
+  if (S.ray_sub > 0) return (uint32_t)S.ray_sub;
+  return n >= (1ull << 22) ? 1024u : 256u;
+}
+
+// the next block of queue counters, zeroed on the stream ahead of the launch that uses it
+int next_ctr(uint32_t** ctr) {
+  uint32_t* c = S.d_ctr + (S.ctr_next++ % State::kCtrRing) * Q_WORDS;
+  HIPCHK(hipMemsetAsync(c, 0, Q_WORDS * sizeof(uint32_t), S.stream));
+  *ctr = c;
+  return ISX_OK;
+}
+
+// one launch addresses its rays by 31-bit offsets from its first ray: larger jobs are cut into launches of this many rays
+constexpr uint64_t kLaunchMax = 1ull << 30;
+
 int ensure_pipeline(size_t rays, size_t waves);
 
 // enqueue one persistent kernel accumulating into d_hist (device) and S.d_stats
@@ -314,6 +350,7 @@ int enqueue(int sink, const isx_config* c, uint64_t n, uint64_t seed, uint64_t f
   if (n == 0) return ISX_OK;
   Work wk;
   wk.seed = seed; wk.first = first; wk.n = n; wk.hist = d_hist; wk.stats = d_stats ? d_stats : S.d_stats;
+  wk.ctr = nullptr; wk.sub = 0; wk.pad = 0;
   // the lean kernel serves the headline configuration; anything else takes the full-featured variant
   const bool lean_surface = c->lambertian && c->surface_model == ISX_SURFACE_ROBAST && c->hit_line_mode == ISX_HITLINE_LAST_SEGMENT;
   const bool lean = lean_surface && c->source_model == ISX_SOURCE_PENCIL;
@@ -332,11 +369,10 @@ int enqueue(int sink, const isx_config* c, uint64_t n, uint64_t seed, uint64_t f
     default: fn = lean_explicit ? isx_trace_log_lean_kernel : isx_trace_log_kernel; break;
   }
   // Workgroup shape.  The kernels that keep the 64.8 KB LDS histogram run one 1024-thread workgroup per CU (4 waves per SIMD,
-  // 128 VGPRs).  The lean trace-only kernels need 75-90 VGPRs and almost no LDS: as 512-thread workgroups, four to a CU, they
-  // reach 6 waves per SIMD (measured: 18.8 -> 17.5 ms for 5e7 rays, 299 -> 282 ms for the 8.1e8-ray per-position map).
+  // 128 VGPRs).  The lean trace-only kernels need 75-90 VGPRs and almost no LDS: as 512-thread workgroups they reach 5-6 waves
+  // per SIMD (measured: 18.8 -> 17.5 ms for 5e7 rays, 299 -> 282 ms for the 8.1e8-ray per-position map).
   const bool small = lean_explicit && (sink == SINK_PERPOS || sink == SINK_DISCPOS || sink == SINK_DZ || sink == SINK_LOG);
   const int block = small ? S.trace_block : kBlock;
-  const int bpc = small ? S.trace_blocks_per_cu : 0;
   auto span = [&](int kind, hipEvent_t* first_ev) -> int {   // [previous event, new event) is one kernel of `kind`
     hipEvent_t e;
     if (first_ev) { int r = get_event(first_ev); if (r) return r; HIPCHK(hipEventRecord(*first_ev, S.stream)); return ISX_OK; }
@@ -349,40 +385,48 @@ int enqueue(int sink, const isx_config* c, uint64_t n, uint64_t seed, uint64_t f
   // ---- two-kernel pipeline (lean flux maps: headline, chord mode, BRDF source): trace kernel -> exit lines in HBM -> binning kernel, chunk by chunk
   if (sink == SINK_FLUX && (lean || brdf) && S.pipeline && S.bin_mode != 0) {
     const KernelFn rec_fn = chord ? isx_trace_rec_chord_kernel : brdf ? isx_trace_rec_brdf_kernel : isx_trace_rec_kernel;
-    const int pblock = S.trace_block, pwaves = pblock / 64;
+    const int pblock = S.trace_block, bblock = S.bin_block;
     const size_t lds_trace = 16 + 64 + sizeof(Geom) + sizeof(DetGrid);
     const size_t lds_bin = (((size_t)d.nbins * 4 + 15) & ~(size_t)15) + (size_t)(4 * d.n_theta) * 8 + (size_t)(2 * d.n_phi) * sizeof(ColX) +
-                           sizeof(DetGrid) + (size_t)pwaves * 128 * 4 + 16;
+                           sizeof(DetGrid) + (size_t)(bblock / 64) * 128 * 4 + 16;
     if (lds_bin <= S.lds_limit) {
       const uint64_t chunk = n < S.pipe_chunk ? n : S.pipe_chunk;
-      const int cgrid = pick_grid(chunk, pblock, S.trace_blocks_per_cu);
-      // same rule as the single-kernel launches (isx.h): at most 2^32-1 rays of one call per workgroup, 2^31-1 per wave
-      {
-        const int ngrid = pick_grid(n, pblock, S.trace_blocks_per_cu);
-        if ((n + (uint64_t)ngrid - 1) / (uint64_t)ngrid > 0xffffffffull) return ISX_ERR_TOO_LARGE;
+      if (!S.attr_set[0]) {   // (once per library lifetime: the sizes do not depend on the call)
+        HIPCHK(hipFuncSetAttribute((const void*)isx_trace_rec_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_trace));
+        HIPCHK(hipFuncSetAttribute((const void*)isx_trace_rec_chord_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_trace));
+        HIPCHK(hipFuncSetAttribute((const void*)isx_trace_rec_brdf_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_trace));
+        S.attr_set[0] = true;
       }
-      if (chunk / ((uint64_t)cgrid * pwaves) >= 0x7fffffffull) return ISX_ERR_TOO_LARGE;
-      rc = ensure_pipeline((size_t)chunk, (size_t)cgrid * pwaves);
+      if (S.attr_bin_lds != lds_bin) {
+        HIPCHK(hipFuncSetAttribute((const void*)isx_bin_lines_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bin));
+        S.attr_bin_lds = lds_bin;
+      }
+      // grids: what is resident, fewer for a small chunk (>= 16 rays per lane; a region of exit lines per binning wave)
+      const int tres = S.trace_blocks_per_cu > 0 ? S.trace_blocks_per_cu : resident_per_cu(rec_fn, pblock, lds_trace);
+      const int bres = S.bin_blocks_per_cu > 0 ? S.bin_blocks_per_cu : resident_per_cu(isx_bin_lines_kernel, bblock, lds_bin);
+      const int cgrid = pick_grid(chunk, pblock, tres);
+      rc = ensure_pipeline((size_t)chunk, (size_t)cgrid * (pblock / 64));
       if (rc) return rc;
-      HIPCHK(hipFuncSetAttribute((const void*)rec_fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_trace));
-      HIPCHK(hipFuncSetAttribute((const void*)isx_bin_lines_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bin));
       rc = span(0, &e0); if (rc) return rc;
       for (uint64_t off = 0; off < n; off += chunk) {
         const uint64_t cnt = n - off < chunk ? n - off : chunk;
         Work w2 = wk;
-        w2.first = first + off; w2.n = cnt;
-        const int gc = pick_grid(cnt, pblock, S.trace_blocks_per_cu);
-        const int g2 = gc < cgrid ? gc : cgrid;
+        w2.first = first + off; w2.n = cnt; w2.sub = pick_sub(cnt);
+        rc = next_ctr(&w2.ctr); if (rc) return rc;
+        const int gc = pick_grid(cnt, pblock, tres);
         DetGrid dt = d;              // the trace kernel keeps no histogram
         dt.nbins = 1; dt.n_theta = 0; dt.n_phi = 0;
         dt.rec_lines = S.d_rec; dt.rec_counts = S.d_rec_counts;
-        hipLaunchKernelGGL(rec_fn, dim3(g2), dim3(pblock), lds_trace, S.stream, g, dt, w2);
+        hipLaunchKernelGGL(rec_fn, dim3(gc), dim3(pblock), lds_trace, S.stream, g, dt, w2);
         HIPCHK(hipGetLastError());
         rc = span(1, nullptr); if (rc) return rc;
         if (S.bin_mode != 2) {       // bin_mode 2: diagnostic, trace only
           DetGrid db = d;
           db.rec_lines = S.d_rec; db.rec_counts = S.d_rec_counts;
-          hipLaunchKernelGGL(isx_bin_lines_kernel, dim3(g2), dim3(pblock), lds_bin, S.stream, db, w2);   // same shape: wave w bins what wave w traced
+          const uint64_t bwant = cnt / (uint64_t)(kRegion * (bblock / 64)) + 1;   // (an upper bound of the regions per workgroup >= 1)
+          const int bfull = S.cu_count * bres;
+          const int gb = S.grid_blocks > 0 ? S.grid_blocks : (bwant < (uint64_t)bfull ? (int)bwant : bfull);
+          hipLaunchKernelGGL(isx_bin_lines_kernel, dim3(gb), dim3(bblock), lds_bin, S.stream, db, w2);
           HIPCHK(hipGetLastError());
           rc = span(2, nullptr); if (rc) return rc;
         }
@@ -390,14 +434,19 @@ int enqueue(int sink, const isx_config* c, uint64_t n, uint64_t seed, uint64_t f
       return ISX_OK;
     }
   }
-  const int grid = pick_grid(n, block, bpc);
-  // a block counts in 32-bit LDS bins: at most 2^32-1 rays per block; a wave addresses its rays by 31-bit offsets
-  if ((n + (uint64_t)grid - 1) / (uint64_t)grid > 0xffffffffull) return ISX_ERR_TOO_LARGE;
-  if (n / ((uint64_t)grid * (uint64_t)(block / 64)) >= 0x7fffffffull) return ISX_ERR_TOO_LARGE;
-  HIPCHK(hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  if (S.attr_lds[(const void*)fn] != lds) {
+    HIPCHK(hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    S.attr_lds[(const void*)fn] = lds;
+  }
+  const int bpc = small ? (S.trace_blocks_per_cu > 0 ? S.trace_blocks_per_cu : resident_per_cu(fn, block, lds)) : 0;
   rc = span(0, &e0); if (rc) return rc;
-  hipLaunchKernelGGL(fn, dim3(grid), dim3(block), lds, S.stream, g, d, wk);
-  HIPCHK(hipGetLastError());
+  for (uint64_t off = 0; off < n; off += kLaunchMax) {
+    Work w2 = wk;
+    w2.first = first + off; w2.n = n - off < kLaunchMax ? n - off : kLaunchMax; w2.sub = pick_sub(w2.n);
+    rc = next_ctr(&w2.ctr); if (rc) return rc;
+    hipLaunchKernelGGL(fn, dim3(pick_grid(w2.n, block, bpc)), dim3(block), lds, S.stream, g, d, w2);
+    HIPCHK(hipGetLastError());
+  }
   return span(0, nullptr);
 }
 
@@ -416,21 +465,18 @@ int upload_aux(const double* host, size_t n_doubles) {
   return ISX_OK;
 }
 
-// workspace of the two-kernel pipeline for a chunk of `rays` rays traced by `waves` waves
+// workspace of the two-kernel pipeline for a chunk of `rays` rays traced by `waves` waves: every region but a wave's last is
+// closed with more than kRegion - 64 lines in it, and a launch cannot have more lines than rays (isx_kernels.hpp: kRegion)
 int ensure_pipeline(size_t rays, size_t waves) {
-  if (rays > S.cap_rec) {
+  const size_t regions = rays / (kRegion - 63) + waves + 1;
+  if (regions > S.cap_regions) {
     HIPCHK(hipStreamSynchronize(S.stream));
     if (S.d_rec) HIPCHK(hipFree(S.d_rec));
-    S.d_rec = nullptr; S.cap_rec = 0;
-    HIPCHK(hipMalloc(&S.d_rec, rays * 6 * sizeof(double)));
-    S.cap_rec = rays;
-  }
-  if (waves > S.cap_rec_counts) {
-    HIPCHK(hipStreamSynchronize(S.stream));
     if (S.d_rec_counts) HIPCHK(hipFree(S.d_rec_counts));
-    S.d_rec_counts = nullptr; S.cap_rec_counts = 0;
-    HIPCHK(hipMalloc(&S.d_rec_counts, waves * sizeof(uint32_t)));
-    S.cap_rec_counts = waves;
+    S.d_rec = nullptr; S.d_rec_counts = nullptr; S.cap_regions = 0;
+    HIPCHK(hipMalloc(&S.d_rec, regions * kRegion * 6 * sizeof(double)));
+    HIPCHK(hipMalloc(&S.d_rec_counts, regions * sizeof(uint32_t)));
+    S.cap_regions = regions;
   }
   return ISX_OK;
 }
@@ -531,6 +577,7 @@ int isx_init(int device) {
   e = hipStreamCreateWithFlags(&S.stream, hipStreamNonBlocking);
   if (e == hipSuccess) e = hipMalloc(&S.d_stats, 8 * sizeof(unsigned long long));
   if (e == hipSuccess) e = hipMemset(S.d_stats, 0, 8 * sizeof(unsigned long long));
+  if (e == hipSuccess) e = hipMalloc(&S.d_ctr, State::kCtrRing * Q_WORDS * sizeof(uint32_t));
   if (e != hipSuccess) { isx_shutdown(); S.last_hip = (int)e; return ISX_ERR_HIP; }
   if (const char* m = std::getenv("ISX_BIN_MODE")) {
     const int v = std::atoi(m);
@@ -555,7 +602,10 @@ void isx_shutdown(void) {
   S.d_aux = nullptr; S.cap_aux = 0;
   if (S.d_rec) (void)hipFree(S.d_rec);
   if (S.d_rec_counts) (void)hipFree(S.d_rec_counts);
-  S.d_rec = nullptr; S.cap_rec = 0; S.d_rec_counts = nullptr; S.cap_rec_counts = 0;
+  S.d_rec = nullptr; S.d_rec_counts = nullptr; S.cap_regions = 0;
+  if (S.d_ctr) (void)hipFree(S.d_ctr);
+  S.d_ctr = nullptr; S.ctr_next = 0;
+  S.attr_set[0] = false; S.attr_bin_lds = 0; S.attr_lds.clear();
   S.d_table = S.d_rowtab = S.d_coltab = nullptr;
   S.d_hist = S.d_stats = nullptr;
   S.cap_bins = S.cap_rows = S.cap_cols = S.cap_hist = 0;
@@ -579,8 +629,11 @@ int isx_set_option(const char* key, int64_t value) {
   if (!std::strcmp(key, "blocks_per_cu")) { if (value < 1 || value > 8) return ISX_ERR_BAD_ARG; S.blocks_per_cu = (int)value; return ISX_OK; }
   if (!std::strcmp(key, "sched_mask")) { if (value < 0 || value > 255) return ISX_ERR_BAD_ARG; S.sched_mask = (int)value; return ISX_OK; }
   if (!std::strcmp(key, "sched_min")) { if (value < 1 || value > 65) return ISX_ERR_BAD_ARG; S.sched_min = (int)value; return ISX_OK; }
-  if (!std::strcmp(key, "trace_blocks_per_cu")) { if (value < 1 || value > 32) return ISX_ERR_BAD_ARG; S.trace_blocks_per_cu = (int)value; return ISX_OK; }
-  if (!std::strcmp(key, "trace_block")) { if (value != 256 && value != 512 && value != 1024) return ISX_ERR_BAD_ARG; S.trace_block = (int)value; return ISX_OK; }
+  if (!std::strcmp(key, "trace_blocks_per_cu")) { if (value < 0 || value > 32) return ISX_ERR_BAD_ARG; S.trace_blocks_per_cu = (int)value; return ISX_OK; }
+  if (!std::strcmp(key, "trace_block")) { if (value != 64 && value != 128 && value != 256 && value != 512 && value != 1024) return ISX_ERR_BAD_ARG; S.trace_block = (int)value; return ISX_OK; }
+  if (!std::strcmp(key, "bin_blocks_per_cu")) { if (value < 0 || value > 32) return ISX_ERR_BAD_ARG; S.bin_blocks_per_cu = (int)value; return ISX_OK; }
+  if (!std::strcmp(key, "bin_block")) { if (value != 256 && value != 512 && value != 1024) return ISX_ERR_BAD_ARG; S.bin_block = (int)value; return ISX_OK; }
+  if (!std::strcmp(key, "ray_sub")) { if (value < 0 || value > (1 << 20)) return ISX_ERR_BAD_ARG; S.ray_sub = (int)value; return ISX_OK; }
   if (!std::strcmp(key, "pipeline")) { if (value < 0 || value > 1) return ISX_ERR_BAD_ARG; S.pipeline = (int)value; return ISX_OK; }
   if (!std::strcmp(key, "pipeline_chunk")) { if (value < 4096 || value > (1ll << 32)) return ISX_ERR_BAD_ARG; S.pipe_chunk = (uint64_t)value; return ISX_OK; }
   if (!std::strcmp(key, "grid_blocks")) { if (value < 0 || value > 65535) return ISX_ERR_BAD_ARG; S.grid_blocks = (int)value; return ISX_OK; }
@@ -895,11 +948,11 @@ int isx_exit_dz_hist(const isx_config* cfg, uint64_t n_rays, uint64_t seed, uint
 
 #ifdef ISX_DIAG
 // tuning builds only (not declared in isx.h): read and clear the binning diagnostics of isx_kernels.hpp
-int isx_diag_read(uint64_t* out16) {
-  if (!S.init || !out16) return ISX_ERR_BAD_ARG;
+int isx_diag_read(uint64_t* out32) {
+  if (!S.init || !out32) return ISX_ERR_BAD_ARG;
   HIPCHK(hipStreamSynchronize(S.stream));
-  HIPCHK(hipMemcpyFromSymbol(out16, HIP_SYMBOL(isx::g_diag), 16 * sizeof(unsigned long long)));
-  unsigned long long z[16] = {0};
+  HIPCHK(hipMemcpyFromSymbol(out32, HIP_SYMBOL(isx::g_diag), 32 * sizeof(unsigned long long)));
+  unsigned long long z[32] = {0};
   HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(isx::g_diag), z, sizeof(z)));
   return ISX_OK;
 }

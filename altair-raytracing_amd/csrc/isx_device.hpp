@@ -34,6 +34,12 @@ struct Geom {
   double r_in;
   unsigned long long rho_thr;  // absorb test on the raw Philox word: (w + 0.5) 2^-32 < rho  <=>  w < rho_thr (exact, see prepare_geom)
   double inv_thr;              // 1 / rho_thr: the surviving word, rescaled, is the azimuth's uniform
+  // The pencil source starts every ray at the same point in the same direction, so the first boundary is one point for the
+  // whole launch: the persistent kernels find it once per workgroup (next_hit_s1<true> on the source itself, the arithmetic
+  // every ray would repeat) and keep it in their LDS copy of this block.  q0_ok = 0: rule S1 does not apply to the source
+  // (it lies outside the ball, or its first hit falls into the port opening): fresh rays then take the generic search.
+  double q0[3];
+  int q0_ok, pad3;
 };
 
 // The handful of constants the hot loop needs; kept in SGPRs.  Everything else of Geom is read

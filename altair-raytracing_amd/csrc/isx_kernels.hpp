@@ -60,22 +60,46 @@ struct DetGrid {
 // [0] lines via the per-lane fast path, [1] via bin_culled caps, [2] via the whole-row fallback, [3] skipped (miss),
 // [4..6] column-loop iterations (wave level) of those three paths, [7..9] candidates (lane level), [10] split passes,
 // [11] row passes
+// [16..]: where the trace loop's time and lanes go (tools/diag_trace.py): wave cycles (s_memtime) per region of a loop trip --
+// [16] refill, [17] step-0 boundary search, [18] generic-search flush, [19] step-0 interaction, [20] steps 1..N-1, [21] census +
+// re-scatter, [22] sink -- then [23] trips, [24] lanes running / [25] parked after the refill, [26] trips after the wave's range
+// ran out ("drain"), [27] lanes running in those, [28] rays ended, [29] flushes, [30] lanes flushed, [31] lanes refilled
 #ifdef ISX_DIAG
-__device__ unsigned long long g_diag[16];
+__device__ unsigned long long g_diag[32];
 #define ISX_DIAG_ADD(k, v) do { if (lane == 0) atomicAdd(&g_diag[k], (unsigned long long)(v)); } while (0)
 #define ISX_DIAG_ADD_LANES(k, v) atomicAdd(&g_diag[k], (unsigned long long)(v))
+#define ISX_TD_DECL unsigned long long td_[16] = {0}; unsigned long long tdc_ = clock64()
+#define ISX_TD_MARK(k) do { const unsigned long long c_ = clock64(); td_[k] += c_ - tdc_; tdc_ = c_; } while (0)
+#define ISX_TD_ADD(k, v) do { td_[k] += (unsigned long long)(v); } while (0)
+#define ISX_TD_FLUSH() do { if (lane == 0) for (int k_ = 0; k_ < 16; ++k_) atomicAdd(&g_diag[16 + k_], td_[k_]); } while (0)
 #else
 #define ISX_DIAG_ADD(k, v) do { } while (0)
 #define ISX_DIAG_ADD_LANES(k, v) do { } while (0)
+#define ISX_TD_DECL do { } while (0)
+#define ISX_TD_MARK(k) do { } while (0)
+#define ISX_TD_ADD(k, v) do { } while (0)
+#define ISX_TD_FLUSH() do { } while (0)
 #endif
 
 enum : int { SINK_FLUX = 0, SINK_DZ = 1, SINK_DISC = 2, SINK_PERPOS = 3, SINK_LOG = 4, SINK_DISCPOS = 5, SINK_REC = 6 };
 
 struct Work {
-  uint64_t seed, first, n;
+  uint64_t seed, first, n;    // one launch traces rays [first, first + n), n < 2^31 (a lane keeps a 31-bit offset from `first`)
   unsigned long long* hist;   // [nbins] global accumulators (+=)
   unsigned long long* stats;  // [8]: launched, exited, counted, absorbed, suspended, increments, wall_hits
+  // Work queue of the launch (zeroed by the host before it): the persistent waves take `sub` rays at a time off ctr[Q_RAYS]
+  // whenever their lanes run dry, so every wave keeps refilling until the LAUNCH has no rays left -- with one fixed slice per
+  // wave, a wave spent its last ~45 loop trips (18 % of them at 1200 rays per wave) waiting for its longest rays with a dozen
+  // live lanes.  ctr[Q_REGIONS]: exit-line regions handed out (SINK_REC), ctr[Q_BIN]: regions taken by the binning kernel.
+  uint32_t* ctr;
+  uint32_t sub, pad;
 };
+enum : int { Q_RAYS = 0, Q_REGIONS = 1, Q_BIN = 2, Q_WORDS = 4 };
+// SINK_REC: a wave appends its exit lines to a private REGION of kRegion slots of the workspace and reserves the next one
+// (one atomic on ctr[Q_REGIONS]) when a trip's lines no longer fit; rec_counts[region] = lines in it.  A region is closed with
+// at least kRegion - 63 lines unless it is a wave's last, so a launch of n rays on W waves needs at most
+// n / (kRegion - 63) + W + 1 regions (isx_api.hip: ensure_pipeline).
+constexpr uint32_t kRegion = 1024;
 
 #ifndef ISX_BLOCK
 #define ISX_BLOCK 1024
@@ -953,8 +977,19 @@ __device__ __forceinline__ void persistent_body(const Geom& g_arg, const DetGrid
     }
   }
   if (tid < 8) sstat[tid] = 0ull;
-  if (tid == 64) *g_lds = g_arg;
-  if (tid == 128) *d_lds = d_arg;
+  if (tid == (nthr > 64 ? 64 : 0)) {
+    *g_lds = g_arg;
+    // the first boundary of every fresh ray (Geom::q0): one evaluation per workgroup instead of one per ray
+    const Hot h0 = make_hot(g_arg);
+    V3 s0, d0, q0;
+    s0.x = g_arg.src[0]; s0.y = g_arg.src[1]; s0.z = g_arg.src[2];
+    d0.x = g_arg.dir0[0]; d0.y = g_arg.dir0[1]; d0.z = g_arg.dir0[2];
+    q0 = s0;
+    const bool ok = next_hit_s1<true>(h0, g_arg, s0, d0, K_NONE, q0);
+    g_lds->q0[0] = q0.x; g_lds->q0[1] = q0.y; g_lds->q0[2] = q0.z;
+    g_lds->q0_ok = ok ? 1 : 0;
+  }
+  if (tid == (nthr > 128 ? 128 : 0)) *d_lds = d_arg;
   __syncthreads();
   typedef __attribute__((address_space(3))) Geom LdsGeom;        // explicit LDS address space: ds_read, not flat_load
   typedef __attribute__((address_space(3))) DetGrid LdsDetGrid;
@@ -965,19 +1000,11 @@ __device__ __forceinline__ void persistent_body(const Geom& g_arg, const DetGrid
   const uint64_t seed = wk.seed;
 
   const int lane = tid & 63;
-  uint64_t next, end;
-  {
-    const uint64_t wave = (uint64_t)blockIdx.x * (uint64_t)wpb + (uint64_t)(tid >> 6);
-    const uint64_t nwaves = (uint64_t)gridDim.x * (uint64_t)wpb;
-    // contiguous ray range of this wave: [next,end)
-    const uint64_t q = wk.n / nwaves, rem = wk.n % nwaves;
-    next = wk.first + wave * q + (wave < rem ? wave : rem);
-    end = next + q + (wave < rem ? 1 : 0);
-    // wave-uniform by construction: keep them in SGPRs
-    next = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(next >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)next);
-    end = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(end >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)end);
-  }
-  const uint64_t range_first = next, range_end = end;
+  // the part of the launch's ray range this wave is refilling from: offsets [next, end) from wk.first (wave-uniform: SGPRs);
+  // `more`: the launch's queue may hold further sub-ranges
+  uint32_t next = 0, end = 0;
+  bool more = true;
+  const uint64_t range_first = wk.first;
 
   Ray r;
   ray_start(g, r, 0);
@@ -989,27 +1016,42 @@ __device__ __forceinline__ void persistent_body(const Geom& g_arg, const DetGrid
   uint32_t n_wall = 0;                                                           // per lane: mirror interactions of its finished rays
   uint32_t n_exited = 0, n_counted = 0, n_susp = 0, n_ended = 0;                 // per wave (ballot counts: scalar registers)
   unsigned long long n_inc = 0;                                                  // per wave (SINK_LOG; the histogram sinks count at flush)
-  uint32_t n_rec = 0;                                                            // per wave (SINK_REC): exit lines written so far
+  uint32_t n_taken = 0;                                                          // per wave: rays taken off the queue
+  uint32_t reg_slot = 0, reg_left = 0, reg_id = 0xffffffffu;                     // per wave (SINK_REC): cursor in the open region
+  ISX_TD_DECL;
 
   for (;;) {
     // ---- refill dead lanes from this wave's range
     const unsigned long long dead = __ballot(!(run || parked));
     if (dead) {
+      if (!(next < end) && more) {   // this wave's sub-range is used up: the next one off the launch's queue
+        uint32_t s = 0;
+        if (lane == 0) s = atomicAdd(&wk.ctr[Q_RAYS], 1u);
+        s = (uint32_t)__builtin_amdgcn_readfirstlane((int)s);
+        const uint64_t b = (uint64_t)s * (uint64_t)wk.sub;
+        if (b < wk.n) {
+          const uint64_t e = b + (uint64_t)wk.sub;
+          next = (uint32_t)b; end = (uint32_t)(e < wk.n ? e : wk.n);
+        } else more = false;
+      }
       if (next < end) {
-        // `left` rays remain in [next, end); only differences are formed, so a range that ends at 2^64-1 cannot wrap
-        // the cursor (next never passes end)
-        const uint64_t left = end - next;
+        const uint32_t left = end - next;
         const uint32_t rank =
             __builtin_amdgcn_mbcnt_hi((uint32_t)(dead >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)dead, 0u));
-        if (!(run || parked) && (uint64_t)rank < left) {
-          ray_start(g, r, (uint32_t)(next - range_first) + rank);
+        if (!(run || parked) && rank < left) {
+          ray_start(g, r, next + rank);
           run = true;
         }
-        const uint64_t take = (uint64_t)__popcll(dead);
-        next += take < left ? take : left;
+        const uint32_t want = (uint32_t)__popcll(dead);
+        const uint32_t take = want < left ? want : left;
+        ISX_TD_ADD(15, take);
+        next += take; n_taken += take;
       }
-      if (__ballot(run || parked) == 0ull) break;
+      if (__ballot(run || parked) == 0ull) break;   // (nothing left in the queue either: a wave with dead lanes and `more` set has just asked)
     }
+    ISX_TD_MARK(0);
+    ISX_TD_ADD(7, 1); ISX_TD_ADD(8, __popcll(__ballot(run))); ISX_TD_ADD(9, __popcll(__ballot(parked)));
+    if (!(next < end) && !more) { ISX_TD_ADD(10, 1); ISX_TD_ADD(11, __popcll(__ballot(run))); }
     // ---- one boundary + interaction per live lane.  The hot boundary search (rule S1) runs every
     // iteration; the generic search (port transits, rim, box: ~0.75 % of lane-steps but ~40 % of
     // wave-iterations if run eagerly) is BATCHED: a lane that needs it parks until several lanes
@@ -1027,23 +1069,31 @@ __device__ __forceinline__ void persistent_body(const Geom& g_arg, const DetGrid
       if (st != 0) { run = false; pend = st; }   // census / re-scatter once per trip (below), not per bounce
     };
     // hot boundary search of one lane: true if it arrived on the inner mirror patch, else the lane parks
-    auto hot_search = [&](V3& q, auto first) -> bool {
+    auto hot_search = [&](V3& q) -> bool {
       if (CH != 0 && r.tgt) return chord_arrive<true>(h, r, q);
-      return next_hit_s1<decltype(first)::value>(h, g, r.p, r.v, r.on, q);
+      return next_hit_s1<false>(h, g, r.p, r.v, r.on, q);
     };
     {
       V3 q;
       int kind = K_NONE;
       bool arrived = false;
       if (run) {
-        if (hot_search(q, std::true_type())) { kind = K_INNER; arrived = true; }
+        // a fresh ray (rays enter on step 0 only) goes straight to the launch's common first boundary (Geom::q0); a
+        // re-scattered one that starts on the world box (on == K_NONE as well) is outside the ball: generic search
+        const bool fresh = r.on == K_NONE && r.j == 0u && !r.scattered();
+        if (fresh) {
+          if (g.q0_ok) { q.x = g.q0[0]; q.y = g.q0[1]; q.z = g.q0[2]; kind = K_INNER; arrived = true; }
+          else { parked = true; run = false; }
+        } else if (hot_search(q)) { kind = K_INNER; arrived = true; }
         else { parked = true; run = false; }
       }
+      ISX_TD_MARK(1);
       const unsigned long long pm = __ballot(parked);
       if (pm) {
         const int sched_min = g.sched_min, sched_mask = g.sched_mask;   // rare: read from the LDS copy
         const bool flush = ((int)__popcll(pm) >= sched_min) || ((iter & (uint32_t)sched_mask) == (uint32_t)sched_mask) ||
                            (__ballot(run) == 0ull);
+        if (flush) { ISX_TD_ADD(13, 1); ISX_TD_ADD(14, __popcll(pm)); }
         if (flush && parked) {
           if (CH != 0 && r.tgt) chord_leave(r);   // a chord whose end point lies in the port opening (chord_arrive<DEFER>)
           kind = next_hit_generic(g, r.p, r.v, r.on, q);
@@ -1053,18 +1103,21 @@ __device__ __forceinline__ void persistent_body(const Geom& g_arg, const DetGrid
         }
       }
       iter++;
+      ISX_TD_MARK(2);
       if (arrived) arrive(kind, q, std::integral_constant<int, PH_EVEN>());
+      ISX_TD_MARK(3);
     }
     // extra bounces per loop trip (hot search only): amortises refill / flush / exit bookkeeping
     static_steps<1, kStepsPerTrip>([&](auto rep) {
       V3 q;
       bool arrived = false;
       if (run) {
-        if (hot_search(q, std::false_type())) arrived = true;
+        if (hot_search(q)) arrived = true;
         else { parked = true; run = false; }
       }
       if (arrived) arrive(K_INNER, q, std::integral_constant<int, (decltype(rep)::value & 1) ? PH_ODD : PH_EVEN>());
     });
+    ISX_TD_MARK(4);
     // ---- census of the rays that ended in this trip (a dead lane stays dead until the next refill, so each ended
     // ray is seen exactly once, with its final point and direction still in place)
     if (RESC && pend != 0 && h.source_model == 1 && !r.scattered()) {
@@ -1089,8 +1142,10 @@ __device__ __forceinline__ void persistent_body(const Geom& g_arg, const DetGrid
         n_exited += (uint32_t)__popcll(__ballot(exited));
         n_counted += (uint32_t)__popcll(__ballot(below));
         n_susp += (uint32_t)__popcll(__ballot(pend == ST_SUSPENDED));
+        ISX_TD_ADD(12, __popcll(me));
       }
     }
+    ISX_TD_MARK(5);
     if (SINK == SINK_LOG) {
       // wave-aggregated append: one atomic on the cursor per wave-step, 32-byte records
       const unsigned long long m = __ballot(bin_me);
@@ -1114,12 +1169,20 @@ __device__ __forceinline__ void persistent_body(const Geom& g_arg, const DetGrid
     } else if (SINK == SINK_REC) {
       const unsigned long long m = __ballot(bin_me);
       if (m) {
+        const uint32_t cnt = (uint32_t)__popcll(m);
+        if (cnt > reg_left) {   // close the open region, reserve the next one (kRegion above)
+          if (lane == 0 && reg_id != 0xffffffffu) d_arg.rec_counts[reg_id] = kRegion - reg_left;
+          uint32_t id = 0;
+          if (lane == 0) id = atomicAdd(&wk.ctr[Q_REGIONS], 1u);
+          reg_id = (uint32_t)__builtin_amdgcn_readfirstlane((int)id);
+          reg_slot = 0; reg_left = kRegion;
+        }
         if (bin_me) {
           const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
-          double2* dst = reinterpret_cast<double2*>(d_arg.rec_lines + 6ull * ((range_first - wk.first) + (uint64_t)(n_rec + rank)));
+          double2* dst = reinterpret_cast<double2*>(d_arg.rec_lines + 6ull * ((uint64_t)reg_id * kRegion + (uint64_t)(reg_slot + rank)));
           dst[0] = make_double2(r.p.x, r.p.y); dst[1] = make_double2(r.p.z, r.v.x); dst[2] = make_double2(r.v.y, r.v.z);
         }
-        n_rec += (uint32_t)__popcll(m);
+        reg_slot += cnt; reg_left -= cnt;
       }
     } else if (SINK == SINK_PERPOS) {
       // per-lane: the ray's own detector group only (one or two exact tests)
@@ -1239,18 +1302,19 @@ __device__ __forceinline__ void persistent_body(const Geom& g_arg, const DetGrid
         }
       }
     }
+    ISX_TD_MARK(6);
   }
+  ISX_TD_FLUSH();
 
   // ---- census + histogram flush
-  if (SINK == SINK_REC && lane == 0)
-    d_arg.rec_counts[(uint64_t)blockIdx.x * (uint64_t)wpb + (uint64_t)(tid >> 6)] = n_rec;
+  if (SINK == SINK_REC && lane == 0 && reg_id != 0xffffffffu) d_arg.rec_counts[reg_id] = kRegion - reg_left;
   atomicAdd(&sstat[6], (unsigned long long)n_wall);
   if (lane == 0) {
     atomicAdd(&sstat[1], (unsigned long long)n_exited);
     atomicAdd(&sstat[2], (unsigned long long)n_counted);
     atomicAdd(&sstat[3], (unsigned long long)(n_ended - n_exited - n_susp));  // absorbed
     atomicAdd(&sstat[4], (unsigned long long)n_susp);
-    atomicAdd(&sstat[0], (unsigned long long)(range_end - range_first));       // launched = this wave's range
+    atomicAdd(&sstat[0], (unsigned long long)n_taken);                         // launched
     atomicAdd(&sstat[5], n_inc);
   }
   __syncthreads();
@@ -1317,10 +1381,11 @@ extern "C" __global__ void ISX_KERNEL_ATTR
 isx_trace_log_lean_kernel(const Geom g, const DetGrid d, const Work wk) { persistent_body<SINK_LOG, true, 0>(g, d, wk); }
 
 // ------------------------------------------------------------------ binning kernel of the two-kernel pipeline
-// Same launch shape as the trace kernel that filled rec_lines: wave w bins the lines of the trace wave w (slice of the ray
-// range, count in rec_counts[w]), 64 at a time: lane = line for the per-line preparation (prep_record), then every line is
-// broadcast and binned by the whole wave exactly as in the fused kernel (walk_rows / bin_culled: same cull, same exact
-// decision, so the histogram is the same).  No ray state lives here.
+// Persistent waves take the regions of exit lines the trace kernel filled (kRegion slots each, rec_counts[region] lines in
+// them) off the launch's queue, ctr[Q_BIN], and bin them 64 lines at a time: lane = line for the per-line preparation
+// (prep_record), then the fast-path lines' rows packed over the lanes (walk_lines_packed) and every other line broadcast
+// and binned by the whole wave exactly as in the fused kernel (walk_rows / bin_culled: same cull, same exact decision, so
+// the histogram is the same).  No ray state lives here; the grid is what is resident (isx_api.hip), one histogram flush each.
 #ifndef ISX_BIN_WAVES_PER_EU
 #define ISX_BIN_WAVES_PER_EU 4
 #endif
@@ -1335,7 +1400,7 @@ isx_bin_lines_kernel(const DetGrid d_arg, const Work wk) {
   DetGrid* d_lds = reinterpret_cast<DetGrid*>(colx + 2 * d_arg.n_phi);
   int* split_all = reinterpret_cast<int*>(d_lds + 1);
   const int tid = threadIdx.x, lane = tid & 63;
-  const int nthr = (int)blockDim.x, wpb = nthr >> 6;   // launched with the trace kernel's shape
+  const int nthr = (int)blockDim.x;
   for (int b = tid; b < nbins; b += nthr) hist[b] = 0u;
   for (int b = tid; b < 4 * d_arg.n_theta; b += nthr) rowt[b] = d_arg.rowtab[b];
   for (int b = tid; b < 2 * d_arg.n_phi; b += nthr) {
@@ -1344,77 +1409,81 @@ isx_bin_lines_kernel(const DetGrid d_arg, const Work wk) {
     e.c = d_arg.coltab[2 * j]; e.s = d_arg.coltab[2 * j + 1]; e.off4 = (uint32_t)j * 4u; e.c32 = (float)e.c; e.s32 = (float)e.s; e.pad = 0u;
     colx[b] = e;
   }
-  if (tid == 128) *d_lds = d_arg;
+  if (tid == (nthr > 128 ? 128 : 0)) *d_lds = d_arg;
   __syncthreads();
   typedef __attribute__((address_space(3))) DetGrid LdsDetGrid;
   const volatile LdsDetGrid& d = *(const volatile LdsDetGrid*)d_lds;
   int* spl = split_all + (tid >> 6) * 128;   // per wave: 64 ints of long-row list + 64 ints of owner marks
   int* mrk = spl + 64;
 
-  // (wave-uniform by construction: through readfirstlane so that the slice pointer lives in scalar registers)
-  const uint64_t wave = (uint64_t)blockIdx.x * (uint64_t)wpb + (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane(tid >> 6);
-  const uint64_t nwaves = (uint64_t)gridDim.x * (uint64_t)wpb;
-  const uint64_t q = wk.n / nwaves, rem = wk.n % nwaves;
-  const uint64_t base = wave * q + (wave < rem ? wave : rem);   // ray offset of the wave's range = first slot of its slice
-  const uint32_t n_lines = d_arg.rec_counts[wave];
-  const double* rec = d_arg.rec_lines + 6ull * base;
   const int bin_mode = d_arg.bin_mode;
+  const uint32_t n_regions = wk.ctr[Q_REGIONS];   // (the trace kernel of this launch has completed)
 #pragma unroll 1
-  for (uint32_t b0 = 0; b0 < n_lines; b0 += 64u) {
-    const bool have = b0 + (uint32_t)lane < n_lines;
-    // (wave-uniform constants of the per-line preparation, derived again for every batch from the LDS copy of the grid: kept
-    //  across the walks below they would sit in VGPRs -- gfx950 has no scalar float unit -- and push three values to scratch)
-    GridConst k;
-    k.Rf = (float)d.R; k.rho = (float)d.rho_d; k.portz = (float)d.portz; k.n_theta = d.n_theta;
-    k.inv_dphi = (float)d.n_phi * 0.15915494309f;
-    k.inv_dth = (float)k.n_theta * 0.63661977237f;
-    V3 lp, lv;
-    lp.x = lp.y = lp.z = 0.0; lv.x = lv.y = 0.0; lv.z = -1.0;
-    RecPre pre;
-    pre.Fz = pre.AF = pre.jf = pre.ch2 = 0.f; pre.rows = -1;
-    if (have) {
-      const double2* src = reinterpret_cast<const double2*>(rec + 6ull * (b0 + (uint32_t)lane));
-      const double2 a = src[0], b = src[1], c = src[2];
-      lp.x = a.x; lp.y = a.y; lp.z = b.x; lv.x = b.y; lv.y = c.x; lv.z = c.y;
-      if (bin_mode == 1) pre = prep_record(k, lp, lv);
-    }
-    struct { int n_phi; double half_w2, portz; const double* table; } dfast;
-    dfast.n_phi = d.n_phi; dfast.half_w2 = d.half_w2; dfast.portz = d_arg.portz; dfast.table = d.table;
-    if (bin_mode == 0) {   // brute-force reference-order test of every bin (tests)
-      unsigned long long em = __ballot(have);
+  for (;;) {
+    // (wave-uniform: through readfirstlane so that the region pointer lives in scalar registers)
+    uint32_t region = 0;
+    if (lane == 0) region = atomicAdd(&wk.ctr[Q_BIN], 1u);
+    region = (uint32_t)__builtin_amdgcn_readfirstlane((int)region);
+    if (region >= n_regions) break;
+    const uint32_t n_lines = (uint32_t)__builtin_amdgcn_readfirstlane((int)d_arg.rec_counts[region]);
+    const double* rec = d_arg.rec_lines + 6ull * ((uint64_t)region * kRegion);
+#pragma unroll 1
+    for (uint32_t b0 = 0; b0 < n_lines; b0 += 64u) {
+      const bool have = b0 + (uint32_t)lane < n_lines;
+      // (wave-uniform constants of the per-line preparation, derived again for every batch from the LDS copy of the grid: kept
+      //  across the walks below they would sit in VGPRs -- gfx950 has no scalar float unit -- and push three values to scratch)
+      GridConst k;
+      k.Rf = (float)d.R; k.rho = (float)d.rho_d; k.portz = (float)d.portz; k.n_theta = d.n_theta;
+      k.inv_dphi = (float)d.n_phi * 0.15915494309f;
+      k.inv_dth = (float)k.n_theta * 0.63661977237f;
+      V3 lp, lv;
+      lp.x = lp.y = lp.z = 0.0; lv.x = lv.y = 0.0; lv.z = -1.0;
+      RecPre pre;
+      pre.Fz = pre.AF = pre.jf = pre.ch2 = 0.f; pre.rows = -1;
+      if (have) {
+        const double2* src = reinterpret_cast<const double2*>(rec + 6ull * (b0 + (uint32_t)lane));
+        const double2 a = src[0], b = src[1], c = src[2];
+        lp.x = a.x; lp.y = a.y; lp.z = b.x; lv.x = b.y; lv.y = c.x; lv.z = c.y;
+        if (bin_mode == 1) pre = prep_record(k, lp, lv);
+      }
+      struct { int n_phi; double half_w2, portz; const double* table; } dfast;
+      dfast.n_phi = d.n_phi; dfast.half_w2 = d.half_w2; dfast.portz = d_arg.portz; dfast.table = d.table;
+      if (bin_mode == 0) {   // brute-force reference-order test of every bin (tests)
+        unsigned long long em = __ballot(have);
+        while (em) {
+          const int src = __builtin_ctzll(em);
+          em &= em - 1ull;
+          V3 P, V;
+          P.x = readlane_f64(lp.x, src); P.y = readlane_f64(lp.y, src); P.z = readlane_f64(lp.z, src);
+          V.x = readlane_f64(lv.x, src); V.y = readlane_f64(lv.y, src); V.z = readlane_f64(lv.z, src);
+          bin_brute(d, hist, P, V, lane);
+        }
+        continue;
+      }
+      // (lines that cannot hit anything -- pre.rows == -2 -- end here, 64 at a time)
+      { const int n_far = (int)__popcll(__ballot(have && pre.rows == -2)); (void)n_far; ISX_DIAG_ADD(3, n_far); }
+      // lines off the fast path: one at a time, lane = row (cap or box windows)
+      unsigned long long em = __ballot(have && pre.rows == -1);
       while (em) {
         const int src = __builtin_ctzll(em);
         em &= em - 1ull;
         V3 P, V;
         P.x = readlane_f64(lp.x, src); P.y = readlane_f64(lp.y, src); P.z = readlane_f64(lp.z, src);
         V.x = readlane_f64(lv.x, src); V.y = readlane_f64(lv.y, src); V.z = readlane_f64(lv.z, src);
-        bin_brute(d, hist, P, V, lane);
+        bin_culled<true>(d, hist, rowt, colx, P, V, lane, spl);
       }
-      continue;
-    }
-    // (lines that cannot hit anything -- pre.rows == -2 -- end here, 64 at a time)
-    { const int n_far = (int)__popcll(__ballot(have && pre.rows == -2)); (void)n_far; ISX_DIAG_ADD(3, n_far); }
-    // lines off the fast path: one at a time, lane = row (cap or box windows)
-    unsigned long long em = __ballot(have && pre.rows == -1);
-    while (em) {
-      const int src = __builtin_ctzll(em);
-      em &= em - 1ull;
-      V3 P, V;
-      P.x = readlane_f64(lp.x, src); P.y = readlane_f64(lp.y, src); P.z = readlane_f64(lp.z, src);
-      V.x = readlane_f64(lv.x, src); V.y = readlane_f64(lv.y, src); V.z = readlane_f64(lv.z, src);
-      bin_culled<true>(d, hist, rowt, colx, P, V, lane, spl);
-    }
-    // fast-path lines: their rows packed over the lanes
-    const int nrow = (have && pre.rows >= 0) ? ((pre.rows >> 16) - (pre.rows & 0xffff) + 1) : 0;
-    int incl = nrow;
+      // fast-path lines: their rows packed over the lanes
+      const int nrow = (have && pre.rows >= 0) ? ((pre.rows >> 16) - (pre.rows & 0xffff) + 1) : 0;
+      int incl = nrow;
 #pragma unroll
-    for (int dlt = 1; dlt < 64; dlt <<= 1) {
-      const int o = __shfl_up(incl, dlt, 64);
-      if (lane >= dlt) incl += o;
+      for (int dlt = 1; dlt < 64; dlt <<= 1) {
+        const int o = __shfl_up(incl, dlt, 64);
+        if (lane >= dlt) incl += o;
+      }
+      const int total = __builtin_amdgcn_readlane(incl, 63);
+      { const int n_fast = (int)__popcll(__ballot(nrow > 0)); (void)n_fast; ISX_DIAG_ADD(0, n_fast); }
+      walk_lines_packed(dfast, hist, rowt, colx, rec + 6ull * b0, pre, nrow, incl - nrow, incl, total, k.inv_dphi, lane, mrk, spl);
     }
-    const int total = __builtin_amdgcn_readlane(incl, 63);
-    { const int n_fast = (int)__popcll(__ballot(nrow > 0)); (void)n_fast; ISX_DIAG_ADD(0, n_fast); }
-    walk_lines_packed(dfast, hist, rowt, colx, rec + 6ull * b0, pre, nrow, incl - nrow, incl, total, k.inv_dphi, lane, mrk, spl);
   }
   __syncthreads();
   unsigned long long flushed = 0;

@@ -28,20 +28,23 @@ def _census_equal(a, b):
 
 
 def test_refill_cursor_at_the_end_of_the_index_space(isx, orc):
-    """A wave whose last refill finds more dead lanes than remaining rays must not run past the end of its range --
-    also when that end is 2^64-1.  One block (16 waves), 65 rays per wave = one more than the lane count, and a few other
-    shapes; every one bit-equal to the oracle."""
+    """A wave whose last refill finds more dead lanes than remaining rays must not run past the end of the launch's range --
+    also when that end is 2^64-1.  One block, sub-ranges of 65 rays (one more than the lane count) and of other sizes, with
+    the pipeline and with the fused kernel; every one bit-equal to the oracle."""
     isx.set_option("grid_blocks", 1)
     try:
-        for n in (16 * 65, 16 * 64 + 1, 17, 16 * 129 + 5, 3000):
-            first = (1 << 64) - 1 - n
-            gh, gst = isx.fluxmap(isx.default_config(), n, SEED, first)
-            oh, ost = orc.fluxmap(orc.default_config(), n, SEED, first)
-            assert np.array_equal(gh, oh), n
-            _census_equal(gst, ost)
-            assert gst.launched == n
+        for pipeline in (1, 0):
+            isx.set_option("pipeline", pipeline)
+            for n, sub in ((16 * 65, 65), (16 * 64 + 1, 64), (17, 0), (16 * 129 + 5, 129), (3000, 1), (3000, 0)):
+                isx.set_option("ray_sub", sub)
+                first = (1 << 64) - 1 - n
+                gh, gst = isx.fluxmap(isx.default_config(), n, SEED, first)
+                oh, ost = orc.fluxmap(orc.default_config(), n, SEED, first)
+                assert np.array_equal(gh, oh), (n, sub)
+                _census_equal(gst, ost)
+                assert gst.launched == n
     finally:
-        isx.set_option("grid_blocks", 0)
+        isx.set_option("grid_blocks", 0); isx.set_option("ray_sub", 0); isx.set_option("pipeline", 1)
 
 
 def test_two_kernel_pipeline_equals_the_fused_kernel(isx, orc):
@@ -68,12 +71,20 @@ def test_two_kernel_pipeline_equals_the_fused_kernel(isx, orc):
         assert np.array_equal(gh, oh) and np.array_equal(gh, small_ref)
         _census_equal(gst, ost)
         _census_equal(gst, small_st)
-        for block, bpc in ((256, 8), (1024, 1), (512, 2), (512, 4), (512, 13)):
+        for block, bpc in ((64, 0), (128, 5), (256, 8), (1024, 1), (512, 2), (512, 4), (512, 13)):
             isx.set_option("trace_block", block); isx.set_option("trace_blocks_per_cu", bpc)
             h, st = isx.fluxmap(c, 3_000_000, SEED, 17)
             assert np.array_equal(h, ref), (block, bpc)
             _census_equal(st, rst)
-        isx.set_option("trace_block", 512); isx.set_option("trace_blocks_per_cu", 8)
+        isx.set_option("trace_block", 512); isx.set_option("trace_blocks_per_cu", 0)
+        # the work queues: rays per grab, shape of the binning kernel (round 3: the waves of a launch share one ray queue and
+        # one queue of exit-line regions; nothing of that may show in a result)
+        for sub, bblock, bbpc in ((64, 512, 0), (100, 256, 1), (7777, 1024, 1), (1 << 20, 512, 3)):
+            isx.set_option("ray_sub", sub); isx.set_option("bin_block", bblock); isx.set_option("bin_blocks_per_cu", bbpc)
+            h, st = isx.fluxmap(c, 3_000_000, SEED, 17)
+            assert np.array_equal(h, ref), (sub, bblock, bbpc)
+            _census_equal(st, rst)
+        isx.set_option("ray_sub", 0); isx.set_option("bin_block", 512); isx.set_option("bin_blocks_per_cu", 0)
         isx.set_option("grid_blocks", 1)
         h1, st1 = isx.fluxmap(c, 50000, SEED, 5)
         isx.set_option("grid_blocks", 0)
@@ -82,7 +93,8 @@ def test_two_kernel_pipeline_equals_the_fused_kernel(isx, orc):
         _census_equal(st1, st2)
     finally:
         isx.set_option("grid_blocks", 0)
-        isx.set_option("trace_block", 512); isx.set_option("trace_blocks_per_cu", 8)
+        isx.set_option("trace_block", 512); isx.set_option("trace_blocks_per_cu", 0)
+        isx.set_option("ray_sub", 0); isx.set_option("bin_block", 512); isx.set_option("bin_blocks_per_cu", 0)
         isx.set_option("pipeline_chunk", 1 << 26)
         isx.set_option("pipeline", 1)
 

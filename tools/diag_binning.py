@@ -8,9 +8,9 @@ L = isx.load(); isx.init(0)
 if os.environ.get('ISX_PIPELINE'): isx.set_option('pipeline', int(os.environ['ISX_PIPELINE']))
 L.isx_diag_read.argtypes = [C.POINTER(C.c_uint64)]
 def diag():
-    a = (C.c_uint64 * 16)()
+    a = (C.c_uint64 * 32)()
     assert L.isx_diag_read(a) == 0
-    return np.array(a[:], dtype=np.uint64)
+    return np.array(a[:16], dtype=np.uint64)
 def run(name, c, n):
     diag()
     h, st = isx.fluxmap(c, n, 5)

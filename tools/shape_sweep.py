@@ -25,4 +25,4 @@ for block in (512,):
             k = isx.last_kernel_ms()
             best = min(best, (st.t_kernel_ms, k[1], k[2]))
         print(f"block {block:5d} x {bpc:2d} per CU ({block * bpc // 256:2d} waves/SIMD asked): {best[0]:7.2f} = {best[1]:6.2f} + {best[2]:6.2f}", flush=True)
-isx.set_option("trace_block", 512); isx.set_option("trace_blocks_per_cu", 8)
+isx.set_option("trace_block", 512); isx.set_option("trace_blocks_per_cu", 0)
