@@ -39,9 +39,15 @@ struct State {
   double* d_aux = nullptr;                // caller-supplied detector / disc lists of the current call (grown, never shrunk)
   size_t cap_aux = 0;
   // two-kernel pipeline of the headline flux map: exit lines in HBM, in regions of kRegion 48-byte slots + lines per region
-  double* d_rec = nullptr;
-  uint32_t* d_rec_counts = nullptr;
-  size_t cap_regions = 0;
+  static constexpr int kRecBufs = 3;      // workspaces: chunk k uses buffer k mod 3 (the overlapped pipeline keeps up to 3 in flight)
+  double* d_rec[kRecBufs] = {nullptr, nullptr, nullptr};
+  uint32_t* d_rec_counts[kRecBufs] = {nullptr, nullptr, nullptr};
+  size_t cap_regions[kRecBufs] = {0, 0, 0};
+  // overlap > 1: a flux-map call is cut into that many chunks and the binning kernel of chunk k runs on a second stream
+  // while the trace kernel of chunk k+1 runs on the first
+  int overlap = 0;
+  int overlap_trace_streams = 1;          // 2: consecutive trace kernels alternate between two streams (chunk k+1 fills the tail of chunk k)
+  hipStream_t stream2 = nullptr, stream3 = nullptr;
   int pipeline = 1;                       // 1 (default): trace kernel -> HBM -> binning kernel (lean flux map); 0: fused kernel
   uint64_t pipe_chunk = 1ull << 26;       // rays per trace/bin pair (3.4 GB of exit-line workspace at most)
   // work-queue counters of the launches (Work::ctr): a ring of Q_WORDS-word blocks, one per launch, zeroed on the stream
@@ -51,6 +57,7 @@ struct State {
   static constexpr size_t kCtrRing = 256;
   int ray_sub = 0;                        // rays a wave takes off the queue at a time (0: by launch size)
   int bin_block = 512, bin_blocks_per_cu = 0;   // binning kernel: workgroup size, workgroups per CU in the grid (0: what is resident)
+  int bin_slots = 1;                            // 1: isx_bin_slots_kernel (slot queues by window length) where the grid allows it
   // options
   int bin_mode = 1;
   int blocks_per_cu = 1;   // 1024-thread blocks: 16 waves/CU, 4 per SIMD
@@ -67,7 +74,6 @@ struct State {
   int trace_block = 512, trace_blocks_per_cu = 0;
   // hipFuncSetAttribute(MaxDynamicSharedMemorySize) is made once per kernel and size, not once per launch
   bool attr_set[1] = {false};
-  size_t attr_bin_lds = 0;
   std::map<const void*, size_t> attr_lds;
 } S;
 
@@ -273,7 +279,7 @@ int next_ctr(uint32_t** ctr) {
 // one launch addresses its rays by 31-bit offsets from its first ray: larger jobs are cut into launches of this many rays
 constexpr uint64_t kLaunchMax = 1ull << 30;
 
-int ensure_pipeline(size_t rays, size_t waves);
+int ensure_pipeline(size_t rays, size_t waves, int buf = 0);
 
 // enqueue one persistent kernel accumulating into d_hist (device) and S.d_stats
 struct PerPos { uint64_t map_first = 0, rays_per_group = 0; int fold = 1; const double* d_table = nullptr; double width = 0; };
@@ -385,10 +391,17 @@ int enqueue(int sink, const isx_config* c, uint64_t n, uint64_t seed, uint64_t f
   // ---- two-kernel pipeline (lean flux maps: headline, chord mode, BRDF source): trace kernel -> exit lines in HBM -> binning kernel, chunk by chunk
   if (sink == SINK_FLUX && (lean || brdf) && S.pipeline && S.bin_mode != 0) {
     const KernelFn rec_fn = chord ? isx_trace_rec_chord_kernel : brdf ? isx_trace_rec_brdf_kernel : isx_trace_rec_kernel;
-    const int pblock = S.trace_block, bblock = S.bin_block;
     const size_t lds_trace = 16 + 64 + sizeof(Geom) + sizeof(DetGrid);
-    const size_t lds_bin = (((size_t)d.nbins * 4 + 15) & ~(size_t)15) + (size_t)(4 * d.n_theta) * 8 + (size_t)(2 * d.n_phi) * sizeof(ColX) +
-                           sizeof(DetGrid) + (size_t)(bblock / 64) * 128 * 4 + 16;
+    const size_t lds_tables = (((size_t)d.nbins * 4 + 15) & ~(size_t)15) + (size_t)(4 * d.n_theta) * 8 + (size_t)(2 * d.n_phi) * sizeof(ColX) +
+                              sizeof(DetGrid) + 16;
+    // the binning kernel with slot queues (1024-thread workgroups: 61 KB of queues next to the histogram) if the grid fits its
+    // 32-bit slot records and the LDS; else the one without
+    const bool slots = S.bin_slots && S.bin_mode == 1 && d.n_theta <= 256 && d.n_phi <= 255 &&
+                       lds_tables + (size_t)(kBlock / 64) * kSlotWaveWords * 4 <= S.lds_limit;
+    typedef void (*BinFn)(const DetGrid, const Work);
+    const BinFn bin_fn = slots ? isx_bin_slots_kernel : isx_bin_lines_kernel;
+    const int pblock = S.trace_block, bblock = slots ? kBlock : S.bin_block;
+    const size_t lds_bin = lds_tables + (slots ? (size_t)(bblock / 64) * kSlotWaveWords * 4 : (size_t)(bblock / 64) * 128 * 4);
     if (lds_bin <= S.lds_limit) {
       const uint64_t chunk = n < S.pipe_chunk ? n : S.pipe_chunk;
       if (!S.attr_set[0]) {   // (once per library lifetime: the sizes do not depend on the call)
@@ -397,39 +410,81 @@ int enqueue(int sink, const isx_config* c, uint64_t n, uint64_t seed, uint64_t f
         HIPCHK(hipFuncSetAttribute((const void*)isx_trace_rec_brdf_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_trace));
         S.attr_set[0] = true;
       }
-      if (S.attr_bin_lds != lds_bin) {
-        HIPCHK(hipFuncSetAttribute((const void*)isx_bin_lines_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bin));
-        S.attr_bin_lds = lds_bin;
+      if (S.attr_lds[(const void*)bin_fn] != lds_bin) {
+        HIPCHK(hipFuncSetAttribute((const void*)bin_fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bin));
+        S.attr_lds[(const void*)bin_fn] = lds_bin;
       }
       // grids: what is resident, fewer for a small chunk (>= 16 rays per lane; a region of exit lines per binning wave)
       const int tres = S.trace_blocks_per_cu > 0 ? S.trace_blocks_per_cu : resident_per_cu(rec_fn, pblock, lds_trace);
-      const int bres = S.bin_blocks_per_cu > 0 ? S.bin_blocks_per_cu : resident_per_cu(isx_bin_lines_kernel, bblock, lds_bin);
+      const int bres = S.bin_blocks_per_cu > 0 ? S.bin_blocks_per_cu : resident_per_cu(bin_fn, bblock, lds_bin);
+      // one trace launch + one binning launch of `cnt` rays from `off`, through workspace `buf`, on streams st / sb
+      auto launch_pair = [&](uint64_t off, uint64_t cnt, int buf, hipStream_t st, hipStream_t sb, hipEvent_t traced) -> int {
+        Work w2 = wk;
+        w2.first = first + off; w2.n = cnt; w2.sub = pick_sub(cnt);
+        int r = next_ctr(&w2.ctr); if (r) return r;
+        DetGrid dt = d;              // the trace kernel keeps no histogram
+        dt.nbins = 1; dt.n_theta = 0; dt.n_phi = 0;
+        dt.rec_lines = S.d_rec[buf]; dt.rec_counts = S.d_rec_counts[buf];
+        hipLaunchKernelGGL(rec_fn, dim3(pick_grid(cnt, pblock, tres)), dim3(pblock), lds_trace, st, g, dt, w2);
+        HIPCHK(hipGetLastError());
+        if (traced) { HIPCHK(hipEventRecord(traced, st)); HIPCHK(hipStreamWaitEvent(sb, traced, 0)); }
+        else { r = span(1, nullptr); if (r) return r; }
+        if (S.bin_mode != 2) {       // bin_mode 2: diagnostic, trace only
+          DetGrid db = d;
+          db.rec_lines = S.d_rec[buf]; db.rec_counts = S.d_rec_counts[buf];
+          const uint64_t bwant = cnt / (uint64_t)(kRegion * (bblock / 64)) + 1;   // (an upper bound of the regions per workgroup >= 1)
+          const int bfull = S.cu_count * bres;
+          const int gb = S.grid_blocks > 0 ? S.grid_blocks : (bwant < (uint64_t)bfull ? (int)bwant : bfull);
+          hipLaunchKernelGGL(bin_fn, dim3(gb), dim3(bblock), lds_bin, sb, db, w2);
+          HIPCHK(hipGetLastError());
+          if (!traced) { r = span(2, nullptr); if (r) return r; }
+        }
+        return ISX_OK;
+      };
       const int cgrid = pick_grid(chunk, pblock, tres);
+      if (S.overlap > 1 && S.bin_mode == 1 && n >= (uint64_t)S.overlap * 65536) {
+        // ---- overlapped: chunk k is binned on the second stream while chunk k+1 is traced on the first; chunk k+3 reuses the
+        // workspace of chunk k.  (Timing: one wall-clock span around everything; the kernels' own times overlap.)
+        if (!S.stream2) HIPCHK(hipStreamCreateWithFlags(&S.stream2, hipStreamNonBlocking));
+        if (!S.stream3) HIPCHK(hipStreamCreateWithFlags(&S.stream3, hipStreamNonBlocking));
+        const uint64_t per = ((n + (uint64_t)S.overlap - 1) / (uint64_t)S.overlap + 63) & ~63ull;
+        const uint64_t oc = per < S.pipe_chunk ? per : S.pipe_chunk;
+        const int ogrid = pick_grid(oc, pblock, tres);
+        for (int b = 0; b < State::kRecBufs; ++b) { rc = ensure_pipeline((size_t)oc, (size_t)ogrid * (pblock / 64), b); if (rc) return rc; }
+        rc = span(0, &e0); if (rc) return rc;
+        std::vector<hipEvent_t> binned;
+        HIPCHK(hipStreamWaitEvent(S.stream3, e0, 0));             // (what the caller enqueued before this call comes first)
+        int k = 0;
+        for (uint64_t off = 0; off < n; off += oc, ++k) {
+          hipEvent_t traced, done;
+          rc = get_event(&traced); if (rc) return rc;
+          rc = get_event(&done); if (rc) return rc;
+          const hipStream_t st = (S.overlap_trace_streams == 2 && (k & 1)) ? S.stream3 : S.stream;
+          if (k >= State::kRecBufs) HIPCHK(hipStreamWaitEvent(st, binned[k - State::kRecBufs], 0));
+          {   // the queue counters are zeroed on the stream that launches the trace kernel
+            const hipStream_t keep = S.stream;
+            S.stream = st;
+            rc = launch_pair(off, n - off < oc ? n - off : oc, k % State::kRecBufs, st, S.stream2, traced);
+            S.stream = keep;
+            if (rc) return rc;
+          }
+          HIPCHK(hipEventRecord(done, S.stream2));
+          binned.push_back(done);
+        }
+        HIPCHK(hipStreamWaitEvent(S.stream, binned.back(), 0));   // the caller's stream sees the finished histogram
+        hipEvent_t e1;
+        rc = get_event(&e1); if (rc) return rc;
+        HIPCHK(hipEventRecord(e1, S.stream));
+        size_t ia = 0, ib = 0;
+        for (size_t i = 0; i < S.ev_used; ++i) { if (S.ev_pool[i] == e0) ia = i; if (S.ev_pool[i] == e1) ib = i; }
+        S.spans.push_back({ia, ib, 0});
+        return ISX_OK;
+      }
       rc = ensure_pipeline((size_t)chunk, (size_t)cgrid * (pblock / 64));
       if (rc) return rc;
       rc = span(0, &e0); if (rc) return rc;
       for (uint64_t off = 0; off < n; off += chunk) {
-        const uint64_t cnt = n - off < chunk ? n - off : chunk;
-        Work w2 = wk;
-        w2.first = first + off; w2.n = cnt; w2.sub = pick_sub(cnt);
-        rc = next_ctr(&w2.ctr); if (rc) return rc;
-        const int gc = pick_grid(cnt, pblock, tres);
-        DetGrid dt = d;              // the trace kernel keeps no histogram
-        dt.nbins = 1; dt.n_theta = 0; dt.n_phi = 0;
-        dt.rec_lines = S.d_rec; dt.rec_counts = S.d_rec_counts;
-        hipLaunchKernelGGL(rec_fn, dim3(gc), dim3(pblock), lds_trace, S.stream, g, dt, w2);
-        HIPCHK(hipGetLastError());
-        rc = span(1, nullptr); if (rc) return rc;
-        if (S.bin_mode != 2) {       // bin_mode 2: diagnostic, trace only
-          DetGrid db = d;
-          db.rec_lines = S.d_rec; db.rec_counts = S.d_rec_counts;
-          const uint64_t bwant = cnt / (uint64_t)(kRegion * (bblock / 64)) + 1;   // (an upper bound of the regions per workgroup >= 1)
-          const int bfull = S.cu_count * bres;
-          const int gb = S.grid_blocks > 0 ? S.grid_blocks : (bwant < (uint64_t)bfull ? (int)bwant : bfull);
-          hipLaunchKernelGGL(isx_bin_lines_kernel, dim3(gb), dim3(bblock), lds_bin, S.stream, db, w2);
-          HIPCHK(hipGetLastError());
-          rc = span(2, nullptr); if (rc) return rc;
-        }
+        rc = launch_pair(off, n - off < chunk ? n - off : chunk, 0, S.stream, S.stream, nullptr); if (rc) return rc;
       }
       return ISX_OK;
     }
@@ -467,16 +522,17 @@ int upload_aux(const double* host, size_t n_doubles) {
 
 // workspace of the two-kernel pipeline for a chunk of `rays` rays traced by `waves` waves: every region but a wave's last is
 // closed with more than kRegion - 64 lines in it, and a launch cannot have more lines than rays (isx_kernels.hpp: kRegion)
-int ensure_pipeline(size_t rays, size_t waves) {
+int ensure_pipeline(size_t rays, size_t waves, int buf) {
   const size_t regions = rays / (kRegion - 63) + waves + 1;
-  if (regions > S.cap_regions) {
+  if (regions > S.cap_regions[buf]) {
     HIPCHK(hipStreamSynchronize(S.stream));
-    if (S.d_rec) HIPCHK(hipFree(S.d_rec));
-    if (S.d_rec_counts) HIPCHK(hipFree(S.d_rec_counts));
-    S.d_rec = nullptr; S.d_rec_counts = nullptr; S.cap_regions = 0;
-    HIPCHK(hipMalloc(&S.d_rec, regions * kRegion * 6 * sizeof(double)));
-    HIPCHK(hipMalloc(&S.d_rec_counts, regions * sizeof(uint32_t)));
-    S.cap_regions = regions;
+    if (S.stream2) HIPCHK(hipStreamSynchronize(S.stream2));
+    if (S.d_rec[buf]) HIPCHK(hipFree(S.d_rec[buf]));
+    if (S.d_rec_counts[buf]) HIPCHK(hipFree(S.d_rec_counts[buf]));
+    S.d_rec[buf] = nullptr; S.d_rec_counts[buf] = nullptr; S.cap_regions[buf] = 0;
+    HIPCHK(hipMalloc(&S.d_rec[buf], regions * kRegion * 6 * sizeof(double)));
+    HIPCHK(hipMalloc(&S.d_rec_counts[buf], regions * sizeof(uint32_t)));
+    S.cap_regions[buf] = regions;
   }
   return ISX_OK;
 }
@@ -589,6 +645,8 @@ int isx_init(int device) {
 void isx_shutdown(void) {
   if (!S.init) return;
   if (S.stream) (void)hipStreamSynchronize(S.stream);
+  if (S.stream2) { (void)hipStreamSynchronize(S.stream2); (void)hipStreamDestroy(S.stream2); S.stream2 = nullptr; }
+  if (S.stream3) { (void)hipStreamSynchronize(S.stream3); (void)hipStreamDestroy(S.stream3); S.stream3 = nullptr; }
   for (hipEvent_t e : S.ev_pool) (void)hipEventDestroy(e);
   S.ev_pool.clear();
   S.ev_used = 0;
@@ -600,12 +658,14 @@ void isx_shutdown(void) {
   if (S.d_stats) (void)hipFree(S.d_stats);
   if (S.d_aux) (void)hipFree(S.d_aux);
   S.d_aux = nullptr; S.cap_aux = 0;
-  if (S.d_rec) (void)hipFree(S.d_rec);
-  if (S.d_rec_counts) (void)hipFree(S.d_rec_counts);
-  S.d_rec = nullptr; S.d_rec_counts = nullptr; S.cap_regions = 0;
+  for (int b = 0; b < State::kRecBufs; ++b) {
+    if (S.d_rec[b]) (void)hipFree(S.d_rec[b]);
+    if (S.d_rec_counts[b]) (void)hipFree(S.d_rec_counts[b]);
+    S.d_rec[b] = nullptr; S.d_rec_counts[b] = nullptr; S.cap_regions[b] = 0;
+  }
   if (S.d_ctr) (void)hipFree(S.d_ctr);
   S.d_ctr = nullptr; S.ctr_next = 0;
-  S.attr_set[0] = false; S.attr_bin_lds = 0; S.attr_lds.clear();
+  S.attr_set[0] = false; S.attr_lds.clear();
   S.d_table = S.d_rowtab = S.d_coltab = nullptr;
   S.d_hist = S.d_stats = nullptr;
   S.cap_bins = S.cap_rows = S.cap_cols = S.cap_hist = 0;
@@ -633,6 +693,9 @@ int isx_set_option(const char* key, int64_t value) {
   if (!std::strcmp(key, "trace_block")) { if (value != 64 && value != 128 && value != 256 && value != 512 && value != 1024) return ISX_ERR_BAD_ARG; S.trace_block = (int)value; return ISX_OK; }
   if (!std::strcmp(key, "bin_blocks_per_cu")) { if (value < 0 || value > 32) return ISX_ERR_BAD_ARG; S.bin_blocks_per_cu = (int)value; return ISX_OK; }
   if (!std::strcmp(key, "bin_block")) { if (value != 256 && value != 512 && value != 1024) return ISX_ERR_BAD_ARG; S.bin_block = (int)value; return ISX_OK; }
+  if (!std::strcmp(key, "overlap_trace_streams")) { if (value < 1 || value > 2) return ISX_ERR_BAD_ARG; S.overlap_trace_streams = (int)value; return ISX_OK; }
+  if (!std::strcmp(key, "overlap")) { if (value < 0 || value > 64) return ISX_ERR_BAD_ARG; S.overlap = (int)value; return ISX_OK; }
+  if (!std::strcmp(key, "bin_slots")) { if (value < 0 || value > 1) return ISX_ERR_BAD_ARG; S.bin_slots = (int)value; return ISX_OK; }
   if (!std::strcmp(key, "ray_sub")) { if (value < 0 || value > (1 << 20)) return ISX_ERR_BAD_ARG; S.ray_sub = (int)value; return ISX_OK; }
   if (!std::strcmp(key, "pipeline")) { if (value < 0 || value > 1) return ISX_ERR_BAD_ARG; S.pipeline = (int)value; return ISX_OK; }
   if (!std::strcmp(key, "pipeline_chunk")) { if (value < 4096 || value > (1ll << 32)) return ISX_ERR_BAD_ARG; S.pipe_chunk = (uint64_t)value; return ISX_OK; }

@@ -87,14 +87,16 @@ struct Work {
   uint64_t seed, first, n;    // one launch traces rays [first, first + n), n < 2^31 (a lane keeps a 31-bit offset from `first`)
   unsigned long long* hist;   // [nbins] global accumulators (+=)
   unsigned long long* stats;  // [8]: launched, exited, counted, absorbed, suspended, increments, wall_hits
-  // Work queue of the launch (zeroed by the host before it): the persistent waves take `sub` rays at a time off ctr[Q_RAYS]
-  // whenever their lanes run dry, so every wave keeps refilling until the LAUNCH has no rays left -- with one fixed slice per
-  // wave, a wave spent its last ~45 loop trips (18 % of them at 1200 rays per wave) waiting for its longest rays with a dozen
-  // live lanes.  ctr[Q_REGIONS]: exit-line regions handed out (SINK_REC), ctr[Q_BIN]: regions taken by the binning kernel.
+  // Work queue of the launch (zeroed by the host before it): the persistent waves take rays off ctr[Q_RAYS] (= offset of
+  // the next ray nobody has taken) whenever their lanes run dry, so every wave keeps refilling until the LAUNCH has no rays
+  // left -- with one fixed slice per wave, a wave spent its last ~45 loop trips (18 % of them at 1200 rays per wave) waiting
+  // for its longest rays with a dozen live lanes.  A wave asks for `sub` rays, and for fewer as the queue runs out (1/(2 W)
+  // of what was left at its last visit, W = waves of the launch, at least 64): the waves then finish close together.
+  // ctr[Q_REGIONS]: exit-line regions handed out (SINK_REC), ctr[Q_BIN]: quarter regions taken by the binning kernel.
   uint32_t* ctr;
   uint32_t sub, pad;
 };
-enum : int { Q_RAYS = 0, Q_REGIONS = 1, Q_BIN = 2, Q_WORDS = 4 };
+enum : int { Q_RAYS = 0 /* 64-bit: words 0-1 (it keeps counting after the last ray) */, Q_REGIONS = 2, Q_BIN = 3, Q_WORDS = 4 };
 // SINK_REC: a wave appends its exit lines to a private REGION of kRegion slots of the workspace and reserves the next one
 // (one atomic on ctr[Q_REGIONS]) when a trip's lines no longer fit; rec_counts[region] = lines in it.  A region is closed with
 // at least kRegion - 63 lines unless it is a wave's last, so a launch of n rays on W waves needs at most
@@ -1001,9 +1003,9 @@ __device__ __forceinline__ void persistent_body(const Geom& g_arg, const DetGrid
 
   const int lane = tid & 63;
   // the part of the launch's ray range this wave is refilling from: offsets [next, end) from wk.first (wave-uniform: SGPRs);
-  // `more`: the launch's queue may hold further sub-ranges
+  // next = kDry once the launch's queue has nothing left (a launch has fewer than 2^31 rays)
+  constexpr uint32_t kDry = 0xffffffffu;
   uint32_t next = 0, end = 0;
-  bool more = true;
   const uint64_t range_first = wk.first;
 
   Ray r;
@@ -1024,15 +1026,17 @@ __device__ __forceinline__ void persistent_body(const Geom& g_arg, const DetGrid
     // ---- refill dead lanes from this wave's range
     const unsigned long long dead = __ballot(!(run || parked));
     if (dead) {
-      if (!(next < end) && more) {   // this wave's sub-range is used up: the next one off the launch's queue
-        uint32_t s = 0;
-        if (lane == 0) s = atomicAdd(&wk.ctr[Q_RAYS], 1u);
-        s = (uint32_t)__builtin_amdgcn_readfirstlane((int)s);
-        const uint64_t b = (uint64_t)s * (uint64_t)wk.sub;
-        if (b < wk.n) {
-          const uint64_t e = b + (uint64_t)wk.sub;
-          next = (uint32_t)b; end = (uint32_t)(e < wk.n ? e : wk.n);
-        } else more = false;
+      if (next == end) {   // this wave's sub-range is used up: the next one off the launch's queue
+        const uint32_t n32 = (uint32_t)wk.n;
+        const uint32_t share = (n32 - end) / (2u * (uint32_t)wpb * gridDim.x);   // (end: where the queue stood at the last visit)
+        const uint32_t want = share >= wk.sub ? wk.sub : (share > 64u ? share : 64u);
+        unsigned long long b64 = 0;
+        if (lane == 0) b64 = atomicAdd(reinterpret_cast<unsigned long long*>(wk.ctr + Q_RAYS), (unsigned long long)want);
+        const uint32_t bhi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(b64 >> 32));
+        const uint32_t b = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)b64);
+        if (bhi == 0u && b < n32) {
+          next = b; end = n32 - b > want ? b + want : n32;
+        } else next = kDry;
       }
       if (next < end) {
         const uint32_t left = end - next;
@@ -1047,11 +1051,11 @@ __device__ __forceinline__ void persistent_body(const Geom& g_arg, const DetGrid
         ISX_TD_ADD(15, take);
         next += take; n_taken += take;
       }
-      if (__ballot(run || parked) == 0ull) break;   // (nothing left in the queue either: a wave with dead lanes and `more` set has just asked)
+      if (__ballot(run || parked) == 0ull) break;   // (nothing left in the queue either: a wave with dead lanes has just asked)
     }
     ISX_TD_MARK(0);
     ISX_TD_ADD(7, 1); ISX_TD_ADD(8, __popcll(__ballot(run))); ISX_TD_ADD(9, __popcll(__ballot(parked)));
-    if (!(next < end) && !more) { ISX_TD_ADD(10, 1); ISX_TD_ADD(11, __popcll(__ballot(run))); }
+    if (next == kDry) { ISX_TD_ADD(10, 1); ISX_TD_ADD(11, __popcll(__ballot(run))); }
     // ---- one boundary + interaction per live lane.  The hot boundary search (rule S1) runs every
     // iteration; the generic search (port transits, rim, box: ~0.75 % of lane-steps but ~40 % of
     // wave-iterations if run eagerly) is BATCHED: a lane that needs it parks until several lanes
@@ -1421,14 +1425,18 @@ isx_bin_lines_kernel(const DetGrid d_arg, const Work wk) {
 #pragma unroll 1
   for (;;) {
     // (wave-uniform: through readfirstlane so that the region pointer lives in scalar registers)
-    uint32_t region = 0;
-    if (lane == 0) region = atomicAdd(&wk.ctr[Q_BIN], 1u);
-    region = (uint32_t)__builtin_amdgcn_readfirstlane((int)region);
+    // (a quarter of a region at a time: the waves finish closer together than with whole regions)
+    uint32_t unit = 0;
+    if (lane == 0) unit = atomicAdd(&wk.ctr[Q_BIN], 1u);
+    unit = (uint32_t)__builtin_amdgcn_readfirstlane((int)unit);
+    const uint32_t region = unit >> 2;
     if (region >= n_regions) break;
-    const uint32_t n_lines = (uint32_t)__builtin_amdgcn_readfirstlane((int)d_arg.rec_counts[region]);
+    const uint32_t r_lines = (uint32_t)__builtin_amdgcn_readfirstlane((int)d_arg.rec_counts[region]);
+    const uint32_t q_first = (unit & 3u) * (kRegion / 4u);
+    const uint32_t n_lines = r_lines < q_first + kRegion / 4u ? r_lines : q_first + kRegion / 4u;
     const double* rec = d_arg.rec_lines + 6ull * ((uint64_t)region * kRegion);
 #pragma unroll 1
-    for (uint32_t b0 = 0; b0 < n_lines; b0 += 64u) {
+    for (uint32_t b0 = q_first; b0 < n_lines; b0 += 64u) {
       const bool have = b0 + (uint32_t)lane < n_lines;
       // (wave-uniform constants of the per-line preparation, derived again for every batch from the LDS copy of the grid: kept
       //  across the walks below they would sit in VGPRs -- gfx950 has no scalar float unit -- and push three values to scratch)
