@@ -774,6 +774,210 @@ __device__ __forceinline__ void walk_lines_packed(const D& d, uint32_t* __restri
   }
 }
 
+// ---- slot queues (isx_bin_slots_kernel).  A "slot" is one (exit line, detector row) pair with its column window; a column
+// pass of 64 slots lasts as long as its widest window, and with slots taken in arrival order a pass of the headline ran at 58 %
+// lane fill (windows of 1..24 columns side by side, mean 8.9).  Here every slot is first pushed into one of kClasses
+// wave-private LDS queues by window length (1-4, 5-6, 7-8, 9-10, 11-12, 13-16, 17-24 columns; a longer window goes in as
+// 16-column pieces), and a pass is made of 64 slots of ONE class, as soon as a class holds that many -- whatever lines and
+// producers (packed rows of fast-path lines, cap rows, box rows of grazing lines) they came from.  The queues of a wave
+// persist over the 256 lines of a work unit and are emptied at its end.  Same candidates, each once, same three-tier decision
+// (walk_columns), so the same histogram.  Slot record, 32 bits: line within the unit | row << 8 | first column << 16 |
+// columns << 24 -- the kernel serves grids of at most 256 rows and 255 columns (anything else: isx_bin_lines_kernel).
+constexpr int kClasses = 7, kQueueCap = 128;   // a class never holds more than 63 + 64 slots
+constexpr int kSlotWaveWords = kClasses * kQueueCap + 16 + 64;   // LDS words per wave: queues, counters, owner marks
+constexpr int kPiece = 16, kLongest = 24;
+struct SlotQueues {
+  uint32_t* q;        // [kClasses][kQueueCap]
+  int* tail;          // [8] slots pushed per class (running)
+  int* head;          // [8] slots popped per class (running)
+};
+__device__ __forceinline__ int slot_class(int cnt) {   // cnt in 1..kLongest
+  return cnt <= 4 ? 0 : (cnt <= 12 ? (cnt - 3) >> 1 : (cnt <= 16 ? 5 : 6));
+}
+
+// one pass: 64 slots (fewer when a unit's leftovers are flushed), lane = slot
+template <class D>
+__device__ __forceinline__ void consume_slots(const D& d, uint32_t* __restrict__ hist, const double* __restrict__ rowt,
+                                              const ColX* __restrict__ colx, const double* __restrict__ lines, uint32_t rec,
+                                              bool active, int lane) {
+  const int line = (int)(rec & 255u), i = (int)((rec >> 8) & 255u), jlo = (int)((rec >> 16) & 255u);
+  const int len = active ? (int)(rec >> 24) : 0;
+  const double* src6 = lines + 6 * line;   // (an idle lane reads line 0 of the unit, which exists)
+  V3 P, V;
+  {
+    const double2* src = reinterpret_cast<const double2*>(src6);
+    const double2 a = src[0], b = src[1], c = src[2];
+    P.x = a.x; P.y = a.y; P.z = b.x; V.x = b.y; V.y = c.x; V.z = c.y;
+  }
+  const double t0 = -fma(P.x, V.x, fma(P.y, V.y, (P.z - d.portz) * V.z));
+  ISX_DIAG_ADD(11, 1);
+  walk_columns(d, hist, colx, P, V, t0, lane, i, rowt, jlo, 0, len, 0, src6);
+}
+
+// passes for every class that holds at least `least` slots (64 while a unit is being produced, 1 at its end)
+template <class D>
+__device__ __forceinline__ void drain_slots(const D& d, uint32_t* __restrict__ hist, const double* __restrict__ rowt,
+                                            const ColX* __restrict__ colx, const double* __restrict__ lines,
+                                            const SlotQueues& sq, int least, int lane) {
+  volatile int* tl = sq.tail;
+  volatile int* hd = sq.head;
+  const int held = lane < kClasses ? tl[lane] - hd[lane] : 0;
+  unsigned long long m = __ballot(held >= least);
+  while (m) {
+    const int c = __builtin_ctzll(m);
+    m &= m - 1ull;
+    const int h = hd[c], n = tl[c] - h;          // (same address in every lane: wave-uniform)
+    const int take = n < 64 ? n : 64;
+    const uint32_t rec = lane < take ? reinterpret_cast<volatile uint32_t*>(sq.q)[c * kQueueCap + ((h + lane) & (kQueueCap - 1))] : 0u;
+    __builtin_amdgcn_wave_barrier();
+    if (lane == 0) hd[c] = h + take;
+    __builtin_amdgcn_wave_barrier();
+    consume_slots(d, hist, rowt, colx, lines, rec, lane < take, lane);
+  }
+}
+
+// every lane hands in (at most) one window: columns [jlo, jlo + cnt) of row i for line `line` of the unit (cnt = 0: nothing).
+// jlo may be negative by less than n_phi (cap_window).
+template <class D>
+__device__ __forceinline__ void push_slots(const D& d, uint32_t* __restrict__ hist, const double* __restrict__ rowt,
+                                           const ColX* __restrict__ colx, const double* __restrict__ lines,
+                                           const SlotQueues& sq, int line, int i, int jlo, int cnt, int lane) {
+  int j = jlo < 0 ? jlo + d.n_phi : jlo, rem = cnt;
+  for (;;) {
+    const int piece = rem > kLongest ? kPiece : rem;
+    if (piece > 0) {
+      const int c = slot_class(piece);
+      const int pos = __hip_atomic_fetch_add(sq.tail + c, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      reinterpret_cast<volatile uint32_t*>(sq.q)[c * kQueueCap + (pos & (kQueueCap - 1))] =
+          (uint32_t)line | ((uint32_t)i << 8) | ((uint32_t)j << 16) | ((uint32_t)piece << 24);
+      ISX_DIAG_ADD_LANES(7, piece);
+    }
+    rem -= piece;
+    j += piece;
+    if (j >= d.n_phi) j -= d.n_phi;
+    __builtin_amdgcn_wave_barrier();
+    drain_slots(d, hist, rowt, colx, lines, sq, 64, lane);   // every class is below 64 again before the next push
+    if (__ballot(rem > 0) == 0ull) break;
+  }
+}
+
+// producer: a line off the fast path (wave-uniform P, V; lane = row), cap windows around its two piercing points or box windows
+template <class DG, class D>
+__device__ inline void produce_general(const DG& dd, const D& dfast, uint32_t* __restrict__ hist, const double* __restrict__ rowt,
+                                       const ColX* __restrict__ colx, const double* __restrict__ lines, const SlotQueues& sq,
+                                       const V3 P, const V3 V, int line, int lane) {
+  struct { int n_theta, n_phi; double rho_d, R, portz; } d;
+  d.n_theta = dd.n_theta; d.n_phi = dd.n_phi; d.rho_d = dd.rho_d; d.R = dd.R; d.portz = dd.portz;
+  // (the construction of bin_culled<true>: same formulas, same margins)
+  const double wz = P.z - d.portz;
+  const double wv = fma(P.x, V.x, fma(P.y, V.y, wz * V.z));
+  const double hx = fma(-wv, V.x, P.x), hy = fma(-wv, V.y, P.y), hz = fma(-wv, V.z, wz);
+  const float dO2 = (float)fma(hx, hx, fma(hy, hy, hz * hz));
+  const float Rf = (float)d.R, rho = (float)d.rho_d;
+  const float R2 = Rf * Rf;
+  const float dO = sqrt_cull(dO2);
+  const float a1 = dO + rho;
+  CapWin w;
+  w.inv_dphi = (float)d.n_phi * 0.15915494309f;
+  w.Fz = 0.f; w.AF2 = 0.f; w.AF = 0.f; w.jf = 0.f; w.ch2 = 0.f;
+  const float inv_dth = (float)d.n_theta * 0.63661977237f;
+  bool caps = a1 < 0.999f * Rf;
+  float sF = 0.f, ch = 0.f, omega = 0.f;
+  if (caps) {
+    sF = sqrt_cull(R2 - dO2);
+    const float smin = sqrt_cull(R2 - a1 * a1);
+    const float a0 = fmaxf(0.f, dO - rho);
+    const float smax = sqrt_cull(R2 - a0 * a0);
+    const float ext = fmaxf(sF - smin, smax - sF);
+    w.ch2 = fmaf(ext, ext, rho * rho) * 1.0001f + 1e-3f;
+    caps = 4.0f * (R2 - dO2) > 4.04f * w.ch2;
+    ch = sqrt_cull(w.ch2);
+    omega = cap_angle(ch, rcp_cull(Rf));
+  }
+  // one loop nest for both constructions (one push site): caps -> two sides, one window per row; boxes -> one "side", up
+  // to two windows per row (the second ones in a second sweep over the same rows)
+  BoxLine bx;
+  int ilo = 0, ihi = -1;
+  if (!caps) {
+    if (!box_line(d, P, V, inv_dth, bx, ilo, ihi)) { ISX_DIAG_ADD(3, 1); return; }
+    ISX_DIAG_ADD(2, 1);
+  } else {
+    ISX_DIAG_ADD(1, 1);
+  }
+#pragma unroll 1
+  for (int side = 0; side < (caps ? 2 : 1); ++side) {
+    if (caps) {
+      const double s = side == 0 ? ((double)sF - wv) : (-(double)sF - wv);
+      const float Fx = (float)fma(s, V.x, P.x), Fy = (float)fma(s, V.y, P.y);
+      w.Fz = (float)fma(s, V.z, P.z);
+      if (w.Fz - ch > (float)d.portz) continue;  // cap entirely above every detector row
+      w.AF2 = fmaf(Fx, Fx, Fy * Fy);
+      w.AF = sqrt_cull(w.AF2);
+      float phiF = atan2_cull(Fy, Fx);
+      if (phiF < 0.f) phiF += 6.28318530718f;
+      w.jf = phiF * w.inv_dphi - 0.5f;
+      const float thF = atan2_cull(w.AF, (float)d.portz - w.Fz);
+      ilo = max((int)floorf((thF - omega) * inv_dth - 0.5f - 1e-3f), 0);
+      ihi = min((int)ceilf((thF + omega) * inv_dth - 0.5f + 1e-3f), d.n_theta - 1);
+    }
+#pragma unroll 1
+    for (int i0 = ilo; i0 <= ihi; i0 += 64) {
+      const int i = i0 + lane <= ihi ? i0 + lane : -1;
+      int nsweep = 1;
+#pragma unroll 1
+      for (int sweep = 0; sweep < nsweep; ++sweep) {
+        int jlo = 0, cnt = 0;
+        if (i >= 0) {
+          const float zi = (float)rowt[4 * i + 2], Ai = (float)rowt[4 * i + 3];
+          if (caps) {
+            cap_window(w, zi, Ai, d.n_phi, jlo, cnt);
+          } else {
+            int j0, c0, j1, c1;
+            box_window(bx, zi - (float)d.portz, Ai, d.n_phi, w.inv_dphi, j0, c0, j1, c1);
+            jlo = sweep == 0 ? j0 : j1;
+            cnt = sweep == 0 ? c0 : c1;
+            if (sweep == 0 && c1 > 0) nsweep = 2;
+          }
+        }
+        nsweep = __ballot(nsweep == 2) != 0ull ? 2 : 1;
+        push_slots(dfast, hist, rowt, colx, lines, sq, line, i >= 0 ? i : 0, jlo, cnt, lane);
+      }
+    }
+  }
+}
+
+// producer: the fast-path lines of a batch of 64, their rows packed over the lanes (the owner search of walk_lines_packed)
+template <class D>
+__device__ __forceinline__ void produce_packed(const D& d, uint32_t* __restrict__ hist, const double* __restrict__ rowt,
+                                               const ColX* __restrict__ colx, const double* __restrict__ lines, const SlotQueues& sq,
+                                               const RecPre& pre, int nrow, int excl, int incl, int total, float inv_dphi,
+                                               int first_line, int lane, int* mark) {
+#pragma unroll 1
+  for (int base = 0; base < total; base += 64) {
+    const int g = base + lane;
+    bool have = g < total;
+    volatile int* mk = mark;
+    mk[lane] = 0;
+    __builtin_amdgcn_wave_barrier();
+    if (nrow > 0 && excl < base + 64 && incl > base) mk[(excl > base ? excl : base) - base] = lane + 1;
+    __builtin_amdgcn_wave_barrier();
+    const int m = mk[lane];
+    const unsigned long long low = __ballot(m != 0) & (~0ull >> (63 - lane));   // marks at or below this lane
+    const int pos = 63 - __builtin_clzll(low | 1ull);                           // (slot `base` always carries one)
+    int owner = mk[pos] - 1;
+    if (!have || owner < 0) { owner = 0; have = false; }
+    const int o_excl = __shfl(excl, owner, 64), o_rows = __shfl(pre.rows, owner, 64);
+    const int i = have ? (o_rows & 0xffff) + (g - o_excl) : 0;
+    CapWin w;
+    w.inv_dphi = inv_dphi;
+    w.Fz = __shfl(pre.Fz, owner, 64); w.AF = __shfl(pre.AF, owner, 64); w.AF2 = w.AF * w.AF;
+    w.jf = __shfl(pre.jf, owner, 64); w.ch2 = __shfl(pre.ch2, owner, 64);
+    int jlo = 0, cnt = 0;
+    if (have) cap_window(w, (float)rowt[4 * i + 2], (float)rowt[4 * i + 3], d.n_phi, jlo, cnt);
+    push_slots(d, hist, rowt, colx, lines, sq, first_line + owner, i, jlo, cnt, lane);
+  }
+}
+
 // ISX_HITLINE_ORIGIN_COMPAT (fluxAtObserverFast.C:1181-1201,1285): start (0,0,0), direction last/|last|,
 // normalised twice (once by hand, once by the ARay constructor); plain ops as in the reference.
 __device__ __forceinline__ void hit_line_compat(V3& P, V3& V) {
@@ -1497,6 +1701,110 @@ isx_bin_lines_kernel(const DetGrid d_arg, const Work wk) {
   unsigned long long flushed = 0;
   unsigned long long* ghist = wk.hist;
   asm volatile("" : "+s"(ghist));   // (same: no VGPR copy of this pointer held from the prologue)
+  for (int b = tid; b < nbins; b += nthr) {
+    const uint32_t c = hist[b];
+    if (c) { atomicAdd(&ghist[b], (unsigned long long)c); flushed += c; }
+  }
+  if (flushed) atomicAdd(&wk.stats[5], flushed);
+}
+
+// ------------------------------------------------------------------ binning kernel with slot queues (default for grids
+// of at most 256 x 255 bins whose LDS need fits): as isx_bin_lines_kernel, but the windows of all rows go through the
+// wave's length-class queues (SlotQueues above) before they are walked.  Work unit = a quarter region = up to 256 lines.
+extern "C" __global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(ISX_BIN_WAVES_PER_EU, ISX_BIN_WAVES_PER_EU)))
+isx_bin_slots_kernel(const DetGrid d_arg, const Work wk) {
+  extern __shared__ __align__(16) unsigned char smem[];
+  uint32_t* hist = reinterpret_cast<uint32_t*>(smem);
+  const int nbins = d_arg.nbins;
+  const size_t off_row = ((size_t)nbins * 4 + 15) & ~(size_t)15;
+  double* rowt = reinterpret_cast<double*>(smem + off_row);
+  ColX* colx = reinterpret_cast<ColX*>(rowt + 4 * d_arg.n_theta);
+  DetGrid* d_lds = reinterpret_cast<DetGrid*>(colx + 2 * d_arg.n_phi);
+  uint32_t* wave_all = reinterpret_cast<uint32_t*>(d_lds + 1);
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int nthr = (int)blockDim.x;
+  for (int b = tid; b < nbins; b += nthr) hist[b] = 0u;
+  for (int b = tid; b < 4 * d_arg.n_theta; b += nthr) rowt[b] = d_arg.rowtab[b];
+  for (int b = tid; b < 2 * d_arg.n_phi; b += nthr) {
+    const int j = b < d_arg.n_phi ? b : b - d_arg.n_phi;
+    ColX e;
+    e.c = d_arg.coltab[2 * j]; e.s = d_arg.coltab[2 * j + 1]; e.off4 = (uint32_t)j * 4u; e.c32 = (float)e.c; e.s32 = (float)e.s; e.pad = 0u;
+    colx[b] = e;
+  }
+  if (tid == (nthr > 128 ? 128 : 0)) *d_lds = d_arg;
+  // per wave: the class queues, their 8 + 8 counters, 64 owner marks (kSlotWaveWords 32-bit words)
+  uint32_t* mine = wave_all + (size_t)(tid >> 6) * kSlotWaveWords;
+  SlotQueues sq;
+  sq.q = mine;
+  sq.tail = reinterpret_cast<int*>(mine + kClasses * kQueueCap);
+  sq.head = sq.tail + 8;
+  int* mrk = sq.head + 8;
+  if (lane < 16) sq.tail[lane] = 0;
+  __syncthreads();
+  typedef __attribute__((address_space(3))) DetGrid LdsDetGrid;
+  const volatile LdsDetGrid& d = *(const volatile LdsDetGrid*)d_lds;
+
+  const uint32_t n_regions = wk.ctr[Q_REGIONS];   // (the trace kernel of this launch has completed)
+#pragma unroll 1
+  for (;;) {
+    uint32_t unit = 0;
+    if (lane == 0) unit = atomicAdd(&wk.ctr[Q_BIN], 1u);
+    unit = (uint32_t)__builtin_amdgcn_readfirstlane((int)unit);
+    const uint32_t region = unit >> 2;
+    if (region >= n_regions) break;
+    const uint32_t r_lines = (uint32_t)__builtin_amdgcn_readfirstlane((int)d_arg.rec_counts[region]);
+    const uint32_t q_first = (unit & 3u) * (kRegion / 4u);
+    const uint32_t n_lines = r_lines < q_first + kRegion / 4u ? r_lines : q_first + kRegion / 4u;
+    const double* lines = d_arg.rec_lines + 6ull * ((uint64_t)region * kRegion + q_first);   // the unit's lines
+    struct { int n_phi; double half_w2, portz; const double* table; } dfast;
+    dfast.n_phi = d.n_phi; dfast.half_w2 = d.half_w2; dfast.portz = d_arg.portz; dfast.table = d.table;
+#pragma unroll 1
+    for (uint32_t b0 = q_first; b0 < n_lines; b0 += 64u) {
+      const bool have = b0 + (uint32_t)lane < n_lines;
+      const int first_line = (int)(b0 - q_first);
+      GridConst k;
+      k.Rf = (float)d.R; k.rho = (float)d.rho_d; k.portz = (float)d.portz; k.n_theta = d.n_theta;
+      k.inv_dphi = (float)d.n_phi * 0.15915494309f;
+      k.inv_dth = (float)k.n_theta * 0.63661977237f;
+      V3 lp, lv;
+      lp.x = lp.y = lp.z = 0.0; lv.x = lv.y = 0.0; lv.z = -1.0;
+      RecPre pre;
+      pre.Fz = pre.AF = pre.jf = pre.ch2 = 0.f; pre.rows = -2;
+      if (have) {
+        const double2* src = reinterpret_cast<const double2*>(lines + 6 * (first_line + lane));
+        const double2 a = src[0], b = src[1], c = src[2];
+        lp.x = a.x; lp.y = a.y; lp.z = b.x; lv.x = b.y; lv.y = c.x; lv.z = c.y;
+        pre = prep_record(k, lp, lv);
+      }
+      { const int n_far = (int)__popcll(__ballot(have && pre.rows == -2)); (void)n_far; ISX_DIAG_ADD(3, n_far); }
+      // lines off the fast path: one at a time, lane = row (cap or box windows)
+      unsigned long long em = __ballot(have && pre.rows == -1);
+      while (em) {
+        const int src = __builtin_ctzll(em);
+        em &= em - 1ull;
+        V3 P, V;
+        P.x = readlane_f64(lp.x, src); P.y = readlane_f64(lp.y, src); P.z = readlane_f64(lp.z, src);
+        V.x = readlane_f64(lv.x, src); V.y = readlane_f64(lv.y, src); V.z = readlane_f64(lv.z, src);
+        produce_general(d, dfast, hist, rowt, colx, lines, sq, P, V, first_line + src, lane);
+      }
+      // fast-path lines: their rows packed over the lanes
+      const int nrow = (have && pre.rows >= 0) ? ((pre.rows >> 16) - (pre.rows & 0xffff) + 1) : 0;
+      int incl = nrow;
+#pragma unroll
+      for (int dlt = 1; dlt < 64; dlt <<= 1) {
+        const int o = __shfl_up(incl, dlt, 64);
+        if (lane >= dlt) incl += o;
+      }
+      const int total = __builtin_amdgcn_readlane(incl, 63);
+      { const int n_fast = (int)__popcll(__ballot(nrow > 0)); (void)n_fast; ISX_DIAG_ADD(0, n_fast); }
+      produce_packed(dfast, hist, rowt, colx, lines, sq, pre, nrow, incl - nrow, incl, total, k.inv_dphi, first_line, lane, mrk);
+    }
+    drain_slots(dfast, hist, rowt, colx, lines, sq, 1, lane);   // the unit's leftovers, class by class
+  }
+  __syncthreads();
+  unsigned long long flushed = 0;
+  unsigned long long* ghist = wk.hist;
+  asm volatile("" : "+s"(ghist));
   for (int b = tid; b < nbins; b += nthr) {
     const uint32_t c = hist[b];
     if (c) { atomicAdd(&ghist[b], (unsigned long long)c); flushed += c; }
