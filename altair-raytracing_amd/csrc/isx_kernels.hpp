@@ -72,7 +72,16 @@ __device__ unsigned long long g_diag[32];
 #define ISX_TD_MARK(k) do { const unsigned long long c_ = clock64(); td_[k] += c_ - tdc_; tdc_ = c_; } while (0)
 #define ISX_TD_ADD(k, v) do { td_[k] += (unsigned long long)(v); } while (0)
 #define ISX_TD_FLUSH() do { if (lane == 0) for (int k_ = 0; k_ < 16; ++k_) atomicAdd(&g_diag[16 + k_], td_[k_]); } while (0)
+// binning kernel with slot queues: wave cycles since the previous mark go to region k (the timestamp lives in the two unused
+// counter words of the wave's SlotQueues): [16] batch preparation, [17] producers (owner search, windows), [18] push,
+// [19] pop + line fetch + coefficients, [20] column walk, [21] unit bookkeeping
+#define ISX_BD_MARK(sq, k) do { if (lane == 0) { const unsigned long long c_ = clock64(); \
+    const unsigned long long p_ = ((unsigned long long)(unsigned)(sq).head[7] << 32) | (unsigned)(sq).tail[7]; \
+    atomicAdd(&g_diag[16 + (k)], c_ - p_); (sq).tail[7] = (int)(unsigned)c_; (sq).head[7] = (int)(unsigned)(c_ >> 32); } } while (0)
+#define ISX_BD_INIT(sq) do { if (lane == 0) { const unsigned long long c_ = clock64(); (sq).tail[7] = (int)(unsigned)c_; (sq).head[7] = (int)(unsigned)(c_ >> 32); } } while (0)
 #else
+#define ISX_BD_INIT(sq) do { } while (0)
+#define ISX_BD_MARK(sq, k) do { } while (0)
 #define ISX_DIAG_ADD(k, v) do { } while (0)
 #define ISX_DIAG_ADD_LANES(k, v) do { } while (0)
 #define ISX_TD_DECL do { } while (0)
@@ -799,7 +808,7 @@ __device__ __forceinline__ int slot_class(int cnt) {   // cnt in 1..kLongest
 template <class D>
 __device__ __forceinline__ void consume_slots(const D& d, uint32_t* __restrict__ hist, const double* __restrict__ rowt,
                                               const ColX* __restrict__ colx, const double* __restrict__ lines, uint32_t rec,
-                                              bool active, int lane) {
+                                              bool active, int lane, const SlotQueues& sq) {
   const int line = (int)(rec & 255u), i = (int)((rec >> 8) & 255u), jlo = (int)((rec >> 16) & 255u);
   const int len = active ? (int)(rec >> 24) : 0;
   const double* src6 = lines + 6 * line;   // (an idle lane reads line 0 of the unit, which exists)
@@ -811,7 +820,9 @@ __device__ __forceinline__ void consume_slots(const D& d, uint32_t* __restrict__
   }
   const double t0 = -fma(P.x, V.x, fma(P.y, V.y, (P.z - d.portz) * V.z));
   ISX_DIAG_ADD(11, 1);
+  ISX_BD_MARK(sq, 3);
   walk_columns(d, hist, colx, P, V, t0, lane, i, rowt, jlo, 0, len, 0, src6);
+  ISX_BD_MARK(sq, 4);
 }
 
 // passes for every class that holds at least `least` slots (64 while a unit is being produced, 1 at its end)
@@ -832,7 +843,7 @@ __device__ __forceinline__ void drain_slots(const D& d, uint32_t* __restrict__ h
     __builtin_amdgcn_wave_barrier();
     if (lane == 0) hd[c] = h + take;
     __builtin_amdgcn_wave_barrier();
-    consume_slots(d, hist, rowt, colx, lines, rec, lane < take, lane);
+    consume_slots(d, hist, rowt, colx, lines, rec, lane < take, lane, sq);
   }
 }
 
@@ -842,6 +853,7 @@ template <class D>
 __device__ __forceinline__ void push_slots(const D& d, uint32_t* __restrict__ hist, const double* __restrict__ rowt,
                                            const ColX* __restrict__ colx, const double* __restrict__ lines,
                                            const SlotQueues& sq, int line, int i, int jlo, int cnt, int lane) {
+  ISX_BD_MARK(sq, 1);
   int j = jlo < 0 ? jlo + d.n_phi : jlo, rem = cnt;
   for (;;) {
     const int piece = rem > kLongest ? kPiece : rem;
@@ -856,6 +868,7 @@ __device__ __forceinline__ void push_slots(const D& d, uint32_t* __restrict__ hi
     j += piece;
     if (j >= d.n_phi) j -= d.n_phi;
     __builtin_amdgcn_wave_barrier();
+    ISX_BD_MARK(sq, 2);
     drain_slots(d, hist, rowt, colx, lines, sq, 64, lane);   // every class is below 64 again before the next push
     if (__ballot(rem > 0) == 0ull) break;
   }
@@ -1741,6 +1754,7 @@ isx_bin_slots_kernel(const DetGrid d_arg, const Work wk) {
   int* mrk = sq.head + 8;
   if (lane < 16) sq.tail[lane] = 0;
   __syncthreads();
+  ISX_BD_INIT(sq);
   typedef __attribute__((address_space(3))) DetGrid LdsDetGrid;
   const volatile LdsDetGrid& d = *(const volatile LdsDetGrid*)d_lds;
 
@@ -1756,6 +1770,7 @@ isx_bin_slots_kernel(const DetGrid d_arg, const Work wk) {
     const uint32_t q_first = (unit & 3u) * (kRegion / 4u);
     const uint32_t n_lines = r_lines < q_first + kRegion / 4u ? r_lines : q_first + kRegion / 4u;
     const double* lines = d_arg.rec_lines + 6ull * ((uint64_t)region * kRegion + q_first);   // the unit's lines
+    ISX_BD_MARK(sq, 5);
     struct { int n_phi; double half_w2, portz; const double* table; } dfast;
     dfast.n_phi = d.n_phi; dfast.half_w2 = d.half_w2; dfast.portz = d_arg.portz; dfast.table = d.table;
 #pragma unroll 1
@@ -1777,6 +1792,7 @@ isx_bin_slots_kernel(const DetGrid d_arg, const Work wk) {
         pre = prep_record(k, lp, lv);
       }
       { const int n_far = (int)__popcll(__ballot(have && pre.rows == -2)); (void)n_far; ISX_DIAG_ADD(3, n_far); }
+      ISX_BD_MARK(sq, 0);
       // lines off the fast path: one at a time, lane = row (cap or box windows)
       unsigned long long em = __ballot(have && pre.rows == -1);
       while (em) {

@@ -659,6 +659,40 @@ int isxo_check_intersection(const double det[6], double width, const double last
 /* ------------------------------------------------------------------------- */
 /* drivers                                                                    */
 /* ------------------------------------------------------------------------- */
+/* ---- hooks for the reference-side bounce dump (tools/ref_dump/dumpBounces.C -> tests/test_robast_dump.py): the pieces of
+ * the trace loop one bounce at a time, so that ROBAST's own points and random draws can be replayed through them. */
+int isxo_next_boundary(const isxo_config* c, const double p[3], const double v[3], int on, double q_out[3]) {
+  geom g;
+  if (prepare(c, &g)) return -1;
+  v3 q, P = { p[0], p[1], p[2] }, V = { v[0], v[1], v[2] };
+  const int kind = next_hit(&g, P, V, on, &q);
+  q_out[0] = q.x; q_out[1] = q.y; q_out[2] = q.z;
+  return kind;
+}
+/* unit surface normal (towards the free side) of boundary `kind` at q */
+int isxo_surface_normal(const isxo_config* c, int kind, const double q[3], double n_out[3]) {
+  geom g;
+  if (prepare(c, &g)) return -1;
+  v3 Q = { q[0], q[1], q[2] };
+  const v3 n = surface_normal(&g, kind, Q);
+  n_out[0] = n.x; n_out[1] = n.y; n_out[2] = n.z;
+  return 0;
+}
+/* the cosine-law emission of interact(), Newton step included, for given uniforms (u1: polar, u2: azimuth) about the unit normal n */
+void isxo_cosine_emission(const double n[3], double u1, double u2, double w_out[3]) {
+  const double r = sqrt(u1), z = sqrt(1.0 - u1);
+  double sf, cf;
+  isxo_circle_point(u2, &cf, &sf);
+  const double x = r * cf, y = r * sf;
+  const double sp = -copysign(1.0, n[2]);
+  const double t = fma(n[0], x, n[1] * y);
+  const double ia = -1.0 / (1.0 + fabs(n[2]));
+  const double cc = fma(t, ia, z);
+  v3 w = { fma(cc, n[0], x), fma(cc, n[1], y), fma(n[2], z, sp * t) };
+  const double k = fma(-0.5, dot3(w, w), 1.5);   /* the Newton step of interact() */
+  w_out[0] = w.x * k; w_out[1] = w.y * k; w_out[2] = w.z * k;
+}
+
 void isxo_default_config(isxo_config* c) {
   memset(c, 0, sizeof(*c));
   c->struct_size = (uint32_t)sizeof(*c);

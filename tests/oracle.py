@@ -89,6 +89,10 @@ def lib():
         L.isxo_trace_rays_detector.argtypes = [P(Config), P(dbl), dbl, u64, u64, u64, P(u64), P(Stats)]
         L.isxo_exit_directions.argtypes = [P(Config), u64, u64, u64, u64, P(u64), P(dbl), P(u64)]
         L.isxo_max_threads.restype = C.c_int
+        L.isxo_next_boundary.argtypes = [P(Config), P(dbl), P(dbl), C.c_int, P(dbl)]
+        L.isxo_surface_normal.argtypes = [P(Config), C.c_int, P(dbl), P(dbl)]
+        L.isxo_cosine_emission.argtypes = [P(dbl), dbl, dbl, P(dbl)]
+        L.isxo_cosine_emission.restype = None
         _lib = L
     return _lib
 
@@ -127,6 +131,30 @@ def sincos(x):
     s, c = C.c_double(), C.c_double()
     lib().isxo_sincos(x, C.byref(s), C.byref(c))
     return s.value, c.value
+
+
+def next_boundary(cfg, p, v, on):
+    """(kind, point) of the next boundary from p along v for a ray sitting on boundary `on` (isxo_next_boundary)."""
+    P3, V3, Q3 = (C.c_double * 3)(*p), (C.c_double * 3)(*v), (C.c_double * 3)()
+    kind = lib().isxo_next_boundary(C.byref(cfg), P3, V3, int(on), Q3)
+    return kind, np.array(Q3[:])
+
+
+def surface_normal(cfg, kind, q):
+    Q3, N3 = (C.c_double * 3)(*q), (C.c_double * 3)()
+    assert lib().isxo_surface_normal(C.byref(cfg), int(kind), Q3, N3) == 0
+    return np.array(N3[:])
+
+
+def cosine_emission(n, u1, u2):
+    N3, W3 = (C.c_double * 3)(*n), (C.c_double * 3)()
+    lib().isxo_cosine_emission(N3, float(u1), float(u2), W3)
+    return np.array(W3[:])
+
+
+def check_intersection(det, width, last_point, direction):
+    D6, L3, V3 = (C.c_double * 6)(*det), (C.c_double * 3)(*last_point), (C.c_double * 3)(*direction)
+    return int(lib().isxo_check_intersection(D6, float(width), L3, V3))
 
 
 def detector_table(cfg):

@@ -338,13 +338,9 @@ def test_full_size_properties(isx, golden):
     assert abs(st.counted_below_z / n - ref) < 0.004
     # reference per-position map (results_overnight_03_31, dir 5,0,0)
     m = [m for m in golden["per_position_maps"] if m["port_deg"] == 170.0 and m["source_direction"] == [5.0, 0.0, 0.0]][0]
-    frac = h / n
-    assert abs(frac.sum() / m["sum_fraction"] - 1) < 0.015
-    prof, gold = frac.mean(axis=1), np.array(m["theta_profile"])
-    # the golden rows are phi-means of 90 independent 50 000-ray binomial estimates
-    sigma = np.sqrt(np.maximum(gold, 1e-7) / (m["rays_per_position"] * m["n_phi"]))
-    z = np.abs(prof - gold) / (sigma + 0.01 * gold)
-    assert z.max() < 5.0, (z.max(), int(z.argmax()))
+    # total only, symmetric about the reference's value (measured: -0.3 %); the bin-by-bin comparison against all seven
+    # 8.1e8-ray maps, with pure binomial sigmas, is tests/test_gpu_round2.py::test_every_bin_of_the_reference_maps
+    assert abs(h.sum() / n / m["sum_fraction"] - 1) < 0.013
 
 
 def test_disc_sweep_bit_exact(isx, orc):
@@ -689,4 +685,4 @@ def test_billion_rays_partition_invariance(isx, golden):
     assert st.counted_below_z == counted and st.launched == n == st.exited + st.absorbed + st.suspended
     assert st.bin_increments == int(full.sum())
     m = [m for m in golden["per_position_maps"] if m["port_deg"] == 170.0 and m["source_direction"] == [5.0, 0.0, 0.0]][0]
-    assert abs((full.sum() / n) / m["sum_fraction"] - 1) < 0.01
+    assert abs((full.sum() / n) / m["sum_fraction"] - 1) < 0.013     # (symmetric; see test_every_bin_of_the_reference_maps)

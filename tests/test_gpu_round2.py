@@ -294,10 +294,11 @@ def _chi2(ref_hits, n_ref, our_hits, n_our):
 # model of this build every one of the seven maps has chi2/dof <= 1.04 over ~16 000 bins, i.e. bin by bin the maps are
 # indistinguishable at the resolution of one 50 000-ray bin (3.6 %); summed over a map the total is 0.3-1.0 % low, a
 # smooth theta-only pattern (+1 % on axis, -1.5 % at 25-35 deg) that none of the inferred ROBAST behaviours removes and
-# that the reference's own single-threaded exit log does not show.  The windows below are that measured state: they fail
-# if the model moves away from the reference OR if somebody "improves" it without updating the record.
+# that the reference's own single-threaded exit log does not show.  The bounds below are SYMMETRIC about the reference's value
+# (round-2 advice): they hold the measured state (totals 0.3-1.0 % low) and would also hold a model that closed the gap; the
+# one marker of the gap itself is test_totals_of_the_reference_maps_within_0p15_percent (xfail, strict).
 CHI2_MAX = 1.08
-TOTAL_WINDOW = (0.9870, 0.9990)
+TOTAL_WINDOW = (0.9870, 1.0130)
 
 
 @pytest.mark.parametrize("k", range(7))
@@ -351,7 +352,7 @@ def test_reference_maps_differ_from_this_build_by_a_smooth_function_of_theta_onl
         chi2_0 = float((((r - n * p) ** 2 / np.where(var > 0, var, 1))[use]).sum() / use.sum())
         chi2_f = float((((r - n * p * f[:, None]) ** 2 / np.where(var > 0, var * f[:, None], 1))[use]).sum() / (use.sum() - 7))
         print(f"{info['name']}: chi2/dof {chi2_0:.4f} -> {chi2_f:.4f} after f(theta), f in [{f[w > 0.05 * w.max()].min():.4f}, {f[w > 0.05 * w.max()].max():.4f}]")
-        assert 1.01 < chi2_0 < 1.12, (info["name"], chi2_0)            # the residual is there ...
+        assert chi2_0 < 1.12, (info["name"], chi2_0)                   # the residual (1.03-1.08 today) is bounded ...
         assert 0.955 < chi2_f < 1.045, (info["name"], chi2_f)          # ... and it is a smooth factor of theta, nothing else (4 sigma)
         big = w > 0.05 * w.max()                                       # (rows that carry hits: the last degrees before 90 carry almost none)
         assert 0.96 < f[big].min() and f[big].max() < 1.04, (info["name"], f[big].min(), f[big].max())

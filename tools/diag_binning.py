@@ -10,7 +10,7 @@ L.isx_diag_read.argtypes = [C.POINTER(C.c_uint64)]
 def diag():
     a = (C.c_uint64 * 32)()
     assert L.isx_diag_read(a) == 0
-    return np.array(a[:16], dtype=np.uint64)
+    return np.array(a[:32], dtype=np.uint64)
 def run(name, c, n):
     diag()
     h, st = isx.fluxmap(c, n, 5)
@@ -24,6 +24,10 @@ def run(name, c, n):
            "tier2_per_candidate": d[12] / max(d[7] + d[8] + d[9], 1), "tier3_per_candidate": d[13] / max(d[7] + d[8] + d[9], 1),
            "WRONG_DECISIONS": int(d[14]), "candidates_total": int(d[7] + d[8] + d[9]),
            "lane_fill": {"fast": d[7] / max(d[4] * 64, 1), "caps": d[8] / max(d[5] * 64, 1), "fallback": d[9] / max(d[6] * 64, 1)}}
+    if d[16:22].sum() > 0:   # binning kernel with slot queues: share of the waves' cycles per region (ISX_BD_MARK)
+        names = ["batch_prep", "producers", "push", "pop_fetch_t0", "coefficients_and_walk", "unit_bookkeeping"]
+        out["slot_kernel_wave_cycle_share"] = {n: round(float(v / d[16:22].sum()), 4) for n, v in zip(names, d[16:22])}
+        out["slot_kernel_wave_cycles_per_pass"] = float(d[16:22].sum() / max(d[11], 1))
     print(name, json.dumps(out, indent=1))
 c = isx.default_config()
 run("headline", c, 20_000_000)
