@@ -57,6 +57,8 @@ struct State {
   static constexpr size_t kCtrRing = 256;
   int ray_sub = 0;                        // rays a wave takes off the queue at a time (0: by launch size)
   int bin_block = 512, bin_blocks_per_cu = 0;   // binning kernel: workgroup size, workgroups per CU in the grid (0: what is resident)
+  int assist_block = ISX_ASSIST_BLOCK;          // its workgroup size: (assist_block / 64 - 1) tracer waves + 1 assist wave
+  int assist = 1;                               // 1: trace kernels with an assist wave per workgroup (assist_body)
   int bin_slots = 1;                            // 1: isx_bin_slots_kernel (slot queues by window length) where the grid allows it
   // options
   int bin_mode = 1;
@@ -73,7 +75,6 @@ struct State {
   // is resident (the waves share one ray queue, so late workgroups have nothing to even out); trace_blocks_per_cu > 0 overrides
   int trace_block = 512, trace_blocks_per_cu = 0;
   // hipFuncSetAttribute(MaxDynamicSharedMemorySize) is made once per kernel and size, not once per launch
-  bool attr_set[1] = {false};
   std::map<const void*, size_t> attr_lds;
 } S;
 
@@ -390,8 +391,12 @@ int enqueue(int sink, const isx_config* c, uint64_t n, uint64_t seed, uint64_t f
   hipEvent_t e0;
   // ---- two-kernel pipeline (lean flux maps: headline, chord mode, BRDF source): trace kernel -> exit lines in HBM -> binning kernel, chunk by chunk
   if (sink == SINK_FLUX && (lean || brdf) && S.pipeline && S.bin_mode != 0) {
-    const KernelFn rec_fn = chord ? isx_trace_rec_chord_kernel : brdf ? isx_trace_rec_brdf_kernel : isx_trace_rec_kernel;
-    const size_t lds_trace = 16 + 64 + sizeof(Geom) + sizeof(DetGrid);
+    // trace kernel: with an assist wave per workgroup (ISX_ASSIST_BLOCK threads; isx_kernels.hpp: assist_body) or without
+    const bool assist = S.assist != 0;
+    const KernelFn rec_fn = assist ? (chord ? isx_trace_assist_chord_kernel : brdf ? isx_trace_assist_brdf_kernel : isx_trace_assist_kernel)
+                                   : (chord ? isx_trace_rec_chord_kernel : brdf ? isx_trace_rec_brdf_kernel : isx_trace_rec_kernel);
+    const size_t lds_trace = 16 + 64 + sizeof(Geom) + sizeof(DetGrid) +
+                             (assist ? 16 + sizeof(AssistQueues) + (size_t)(kResumeCap + kPendCap) * 64 : 0);
     const size_t lds_tables = (((size_t)d.nbins * 4 + 15) & ~(size_t)15) + (size_t)(4 * d.n_theta) * 8 + (size_t)(2 * d.n_phi) * sizeof(ColX) +
                               sizeof(DetGrid) + 16;
     // the binning kernel with slot queues (1024-thread workgroups: 61 KB of queues next to the histogram) if the grid fits its
@@ -400,15 +405,13 @@ int enqueue(int sink, const isx_config* c, uint64_t n, uint64_t seed, uint64_t f
                        lds_tables + (size_t)(kBlock / 64) * kSlotWaveWords * 4 <= S.lds_limit;
     typedef void (*BinFn)(const DetGrid, const Work);
     const BinFn bin_fn = slots ? isx_bin_slots_kernel : isx_bin_lines_kernel;
-    const int pblock = S.trace_block, bblock = slots ? kBlock : S.bin_block;
+    const int pblock = assist ? S.assist_block : S.trace_block, bblock = slots ? kBlock : S.bin_block;
     const size_t lds_bin = lds_tables + (slots ? (size_t)(bblock / 64) * kSlotWaveWords * 4 : (size_t)(bblock / 64) * 128 * 4);
     if (lds_bin <= S.lds_limit) {
       const uint64_t chunk = n < S.pipe_chunk ? n : S.pipe_chunk;
-      if (!S.attr_set[0]) {   // (once per library lifetime: the sizes do not depend on the call)
-        HIPCHK(hipFuncSetAttribute((const void*)isx_trace_rec_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_trace));
-        HIPCHK(hipFuncSetAttribute((const void*)isx_trace_rec_chord_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_trace));
-        HIPCHK(hipFuncSetAttribute((const void*)isx_trace_rec_brdf_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_trace));
-        S.attr_set[0] = true;
+      if (S.attr_lds[(const void*)rec_fn] != lds_trace) {   // (once per kernel and size, not once per launch)
+        HIPCHK(hipFuncSetAttribute((const void*)rec_fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_trace));
+        S.attr_lds[(const void*)rec_fn] = lds_trace;
       }
       if (S.attr_lds[(const void*)bin_fn] != lds_bin) {
         HIPCHK(hipFuncSetAttribute((const void*)bin_fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bin));
@@ -562,6 +565,8 @@ int collect_stats(isx_stats* out) {
   unsigned long long h[8];
   HIPCHK(hipMemcpy(h, S.d_stats, sizeof(h), hipMemcpyDeviceToHost));
   HIPCHK(hipMemset(S.d_stats, 0, sizeof(h)));
+  // stats[7]: a wave of an assist-wave trace kernel gave up a bounded wait (its results are incomplete): never seen, never silent
+  if (h[7] != 0) { S.last_hip = (int)hipErrorLaunchFailure; return ISX_ERR_HIP; }
   if (out) {
     out->launched = h[0]; out->exited = h[1]; out->counted_below_z = h[2]; out->absorbed = h[3];
     out->suspended = h[4]; out->bin_increments = h[5]; out->wall_hits = h[6];
@@ -665,7 +670,7 @@ void isx_shutdown(void) {
   }
   if (S.d_ctr) (void)hipFree(S.d_ctr);
   S.d_ctr = nullptr; S.ctr_next = 0;
-  S.attr_set[0] = false; S.attr_lds.clear();
+  S.attr_lds.clear();
   S.d_table = S.d_rowtab = S.d_coltab = nullptr;
   S.d_hist = S.d_stats = nullptr;
   S.cap_bins = S.cap_rows = S.cap_cols = S.cap_hist = 0;
@@ -695,6 +700,8 @@ int isx_set_option(const char* key, int64_t value) {
   if (!std::strcmp(key, "bin_block")) { if (value != 256 && value != 512 && value != 1024) return ISX_ERR_BAD_ARG; S.bin_block = (int)value; return ISX_OK; }
   if (!std::strcmp(key, "overlap_trace_streams")) { if (value < 1 || value > 2) return ISX_ERR_BAD_ARG; S.overlap_trace_streams = (int)value; return ISX_OK; }
   if (!std::strcmp(key, "overlap")) { if (value < 0 || value > 64) return ISX_ERR_BAD_ARG; S.overlap = (int)value; return ISX_OK; }
+  if (!std::strcmp(key, "assist_block")) { if (value < 128 || value > ISX_ASSIST_BLOCK || value % 64) return ISX_ERR_BAD_ARG; S.assist_block = (int)value; return ISX_OK; }
+  if (!std::strcmp(key, "assist")) { if (value < 0 || value > 1) return ISX_ERR_BAD_ARG; S.assist = (int)value; return ISX_OK; }
   if (!std::strcmp(key, "bin_slots")) { if (value < 0 || value > 1) return ISX_ERR_BAD_ARG; S.bin_slots = (int)value; return ISX_OK; }
   if (!std::strcmp(key, "ray_sub")) { if (value < 0 || value > (1 << 20)) return ISX_ERR_BAD_ARG; S.ray_sub = (int)value; return ISX_OK; }
   if (!std::strcmp(key, "pipeline")) { if (value < 0 || value > 1) return ISX_ERR_BAD_ARG; S.pipeline = (int)value; return ISX_OK; }

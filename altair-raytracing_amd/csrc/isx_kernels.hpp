@@ -1601,6 +1601,426 @@ isx_trace_log_kernel(const Geom g, const DetGrid d, const Work wk) { persistent_
 extern "C" __global__ void ISX_KERNEL_ATTR
 isx_trace_log_lean_kernel(const Geom g, const DetGrid d, const Work wk) { persistent_body<SINK_LOG, true, 0>(g, d, wk); }
 
+// ------------------------------------------------------------------ trace kernel of the pipeline with an ASSIST wave
+// (default for the lean flux maps since round 3).  In persistent_body a lane whose ray leaves rule S1' -- it heads for the port
+// opening: 0.75 % of the lane-steps -- parks until a dozen lanes of its wave wait, and the generic boundary search (port,
+// rim, outer sphere, world box: ~400 instructions with three IEEE square roots) then runs for ~9 of 64 lanes: 10 % of the
+// trace kernel's time, and 5 of 64 lanes parked at any moment (tools/diag_trace.py).  Here the LAST wave of every workgroup
+// traces nothing: it serves the others.  A tracer lane that leaves rule S1' hands its ray (64 bytes: point, direction, index,
+// interaction count) to a workgroup-wide LDS queue at the end of the loop trip and is free for the next ray at once; the
+// assist wave takes up to 64 queued rays at a time -- lane = ray -- and does for them everything that is not a bounce off the
+// inner sphere: the generic search, the interaction with the rim or the outer sphere, the end of the ray at the world box
+// with the port census and the exit line for the binning kernel (SINK_REC's regions), the BRDF re-scatter of a primary that
+// left.  A ray that is back on the inner sphere returns through a second LDS queue, from which the tracers refill before
+// they take fresh rays.  Scheduling only: a ray's history is a function of (seed, index), so histogram and census are those
+// of persistent_body<SINK_REC> bit for bit.
+//
+// Queue discipline (all in LDS, workgroup scope):
+//   pending  kPendCap slots, many producers (the tracers: slots reserved by compare-and-swap, so the ring never overflows; a
+//            wave that finds no room keeps its rays and tries again a trip later), one consumer (the assist wave, which only
+//            takes what is published: res == pub);
+//   resume   kResumeCap slots, one producer (the assist wave, which waits for room -- the tracers never wait for it, so there
+//            is no cycle), many consumers (compare-and-swap on the head);
+//   busy     rays that are in neither a tracer lane nor ended; a tracer wave with no ray left leaves when the launch's ray
+//            queue is dry and busy == 0, the assist wave when every tracer has left.
+// Every wait is bounded (kSpinLimit): a wave that gives up raises stats[7] and the host reports ISX_ERR_HIP-like failure
+// instead of hanging the device.
+constexpr uint32_t kPendCap = 512, kResumeCap = 128;
+constexpr uint32_t kSpinLimit = 1u << 22;
+struct AssistQueues {   // LDS, one per workgroup
+  uint32_t pend_res, pend_pub, pend_head, resume_pub, resume_head, busy, tracers_done, failed;
+};
+enum : uint32_t { IDO_SCATTERED = 0x80000000u, IDO_TARGET = 0x40000000u };   // Ray::ido flags in a queue record (offsets < 2^30)
+
+template <int CH, bool RESC>
+__device__ __forceinline__ void assist_body(const Geom& g_arg, const DetGrid& d_arg, const Work& wk) {
+  constexpr bool LEAN = true;
+  extern __shared__ __align__(16) unsigned char smem[];
+  unsigned long long* sstat = reinterpret_cast<unsigned long long*>(smem);
+  Geom* g_lds = reinterpret_cast<Geom*>(sstat + 8);
+  DetGrid* d_lds = reinterpret_cast<DetGrid*>(g_lds + 1);
+  AssistQueues* Q = reinterpret_cast<AssistQueues*>(smem + ((reinterpret_cast<unsigned char*>(d_lds + 1) - smem + 15) & ~(size_t)15));
+  uint4* resume_q = reinterpret_cast<uint4*>(Q + 1);               // [kResumeCap][4]
+  uint4* pend_q = resume_q + 4 * kResumeCap;                       // [kPendCap][4]
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int nthr = (int)blockDim.x, wpb = nthr >> 6;
+  const int n_tracers = wpb - 1;
+  if (tid < 8) sstat[tid] = 0ull;
+  if (tid == 64) {
+    *g_lds = g_arg;
+    const Hot h0 = make_hot(g_arg);
+    V3 s0, d0, q0;
+    s0.x = g_arg.src[0]; s0.y = g_arg.src[1]; s0.z = g_arg.src[2];
+    d0.x = g_arg.dir0[0]; d0.y = g_arg.dir0[1]; d0.z = g_arg.dir0[2];
+    q0 = s0;
+    const bool ok = next_hit_s1<true>(h0, g_arg, s0, d0, K_NONE, q0);
+    g_lds->q0[0] = q0.x; g_lds->q0[1] = q0.y; g_lds->q0[2] = q0.z;
+    g_lds->q0_ok = ok ? 1 : 0;
+  }
+  if (tid == 0) { *d_lds = d_arg; AssistQueues z = {0, 0, 0, 0, 0, 0, 0, 0}; *Q = z; }
+  __syncthreads();
+  typedef __attribute__((address_space(3))) Geom LdsGeom;
+  const volatile LdsGeom& g = *(const volatile LdsGeom*)g_lds;
+  const Hot h = make_hot(g_arg);
+  const double portz = d_arg.portz;
+  const uint64_t seed = wk.seed, first = wk.first;
+  auto ld = [](uint32_t* p) { return __hip_atomic_load(p, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP); };
+  auto add = [](uint32_t* p, uint32_t v) { return __hip_atomic_fetch_add(p, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP); };
+  uint32_t n_wall = 0;                                   // per lane
+  uint32_t n_exited = 0, n_counted = 0, n_susp = 0, n_ended = 0, n_taken = 0;   // per wave
+
+  if ((tid >> 6) < n_tracers) {
+    // =============================================================== tracer waves
+    constexpr uint32_t kDry = 0xffffffffu;
+    uint32_t next = 0, end = 0, spins = 0;
+    Ray r;
+    ray_start(g, r, 0);
+    bool run = false, hand = false;    // hand: the lane's ray waits to be handed to the assist wave
+    // (-DISX_DIAG, tools/diag_trace.py: cycles [16] refill, [17] bounce steps, [18] census, [19] hand-over; [23] trips, [24] lanes
+    //  running / [25] still waiting to be handed over at the top of a trip, [26] hand-overs refused for lack of room, [27] rays
+    //  taken back from the assist wave, [28] rays ended here, [29] waits for the workgroup's last rays)
+    ISX_TD_DECL;
+    for (;;) {
+      // ---- refill: rays that come back from the assist wave first, then fresh ones off the launch's queue
+      unsigned long long dead = __ballot(!(run || hand));
+      if (dead) {
+        // optimistic pop: read the candidates, then move the head by compare-and-swap -- it succeeds only if nobody else took
+        // them, and the assist wave overwrites a slot only after the head has passed it, so what was read is what was won
+        const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(dead >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)dead, 0u));
+        for (;;) {
+          const uint32_t hd = ld(&Q->resume_head), avail = ld(&Q->resume_pub) - hd;
+          if (avail == 0u) break;
+          const uint32_t want = (uint32_t)__popcll(dead);
+          const uint32_t take = want < avail ? want : avail;
+          const bool mine = !(run || hand) && rank < take;
+          uint4 a = make_uint4(0u, 0u, 0u, 0u), b = a, c = a, e = a;
+          if (mine) {
+            const uint4* src = resume_q + 4 * ((hd + rank) & (kResumeCap - 1));
+            a = src[0]; b = src[1]; c = src[2]; e = src[3];
+          }
+          __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+          uint32_t won = 0;
+          if (lane == 0) {
+            uint32_t expect = hd;
+            won = __hip_atomic_compare_exchange_strong(&Q->resume_head, &expect, hd + take, __ATOMIC_ACQ_REL, __ATOMIC_RELAXED,
+                                                       __HIP_MEMORY_SCOPE_WORKGROUP) ? 1u : 0u;
+          }
+          won = (uint32_t)__builtin_amdgcn_readfirstlane((int)won);
+          if (!won) continue;
+          if (mine) {
+            r.p.x = __longlong_as_double(((long long)a.y << 32) | a.x); r.p.y = __longlong_as_double(((long long)a.w << 32) | a.z);
+            r.p.z = __longlong_as_double(((long long)b.y << 32) | b.x); r.v.x = __longlong_as_double(((long long)b.w << 32) | b.z);
+            r.v.y = __longlong_as_double(((long long)c.y << 32) | c.x); r.v.z = __longlong_as_double(((long long)c.w << 32) | c.z);
+            r.ido = e.x & ~IDO_TARGET; r.tgt = (e.x & IDO_TARGET) != 0u; r.j = e.y; r.on = K_INNER;
+            r.cw[0] = 0u; r.cw[1] = 0u; r.cw[2] = e.z; r.cw[3] = e.w;
+            run = true;
+          }
+          if (lane == 0) __hip_atomic_fetch_sub(&Q->busy, take, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+          ISX_TD_ADD(11, take);
+          dead = __ballot(!(run || hand));
+          break;
+        }
+      }
+      if (dead) {
+        if (next == end) {   // this wave's sub-range is used up: the next one off the launch's queue (persistent_body)
+          const uint32_t n32 = (uint32_t)wk.n;
+          const uint32_t share = (n32 - end) / (2u * (uint32_t)n_tracers * gridDim.x);
+          const uint32_t want = share >= wk.sub ? wk.sub : (share > 64u ? share : 64u);
+          unsigned long long b64 = 0;
+          if (lane == 0) b64 = atomicAdd(reinterpret_cast<unsigned long long*>(wk.ctr + Q_RAYS), (unsigned long long)want);
+          const uint32_t bhi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(b64 >> 32));
+          const uint32_t b = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)b64);
+          if (bhi == 0u && b < n32) { next = b; end = n32 - b > want ? b + want : n32; }
+          else next = kDry;
+        }
+        if (next < end) {
+          const uint32_t left = end - next;
+          const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(dead >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)dead, 0u));
+          if (!(run || hand) && rank < left) { ray_start(g, r, next + rank); run = true; }
+          const uint32_t want = (uint32_t)__popcll(dead);
+          const uint32_t take = want < left ? want : left;
+          next += take; n_taken += take;
+        }
+        if (__ballot(run || hand) == 0ull) {
+          // no ray in this wave and none to be had from the launch; rays of this workgroup may still come back
+          if (ld(&Q->busy) == 0u) break;
+          if (++spins > kSpinLimit) { if (lane == 0) add(&Q->failed, 1u); break; }
+          ISX_TD_ADD(13, 1);
+          __builtin_amdgcn_s_sleep(8);
+          continue;
+        }
+      }
+      ISX_TD_MARK(0);
+      ISX_TD_ADD(7, 1); ISX_TD_ADD(8, __popcll(__ballot(run))); ISX_TD_ADD(9, __popcll(__ballot(hand)));
+      // ---- kStepsPerTrip bounces off the inner sphere per live lane (rule S1'); anything else is the assist wave's
+      int pend = 0;
+      auto arrive = [&](const V3& q, auto ph) {
+        const int st = ray_arrive<false, LEAN, CH, decltype(ph)::value>(h, g, r, seed, first, K_INNER, q);
+        if (st != 0) { run = false; pend = st; }
+      };
+      auto hot_search = [&](V3& q) -> bool {
+        if (CH != 0 && r.tgt) return chord_arrive<true>(h, r, q);
+        return next_hit_s1<false>(h, g, r.p, r.v, r.on, q);
+      };
+      {
+        V3 q;
+        bool arrived = false;
+        if (run) {
+          const bool fresh = r.on == K_NONE && r.j == 0u && !r.scattered();
+          if (fresh) {
+            if (g.q0_ok) { q.x = g.q0[0]; q.y = g.q0[1]; q.z = g.q0[2]; arrived = true; }
+            else { hand = true; run = false; }
+          } else if (hot_search(q)) arrived = true;
+          else { hand = true; run = false; }
+        }
+        if (arrived) arrive(q, std::integral_constant<int, PH_EVEN>());
+      }
+      static_steps<1, kStepsPerTrip>([&](auto rep) {
+        V3 q;
+        bool arrived = false;
+        if (run) {
+          if (hot_search(q)) arrived = true;
+          else { hand = true; run = false; }
+        }
+        if (arrived) arrive(q, std::integral_constant<int, (decltype(rep)::value & 1) ? PH_ODD : PH_EVEN>());
+      });
+      ISX_TD_MARK(1);
+      // ---- rays that ended on the inner sphere (absorbed, suspended): census, or the BRDF re-scatter of a primary
+      if (RESC && pend != 0 && h.source_model == 1 && !r.scattered()) {
+        n_wall += r.j;
+        ray_rescatter(g, r, seed, first);
+        if (r.on == K_INNER) run = true; else hand = true;   // (a primary ends on the inner sphere here, so: run)
+        pend = 0;
+      }
+      {
+        const bool ended = pend != 0;
+        if (ended) {
+          n_wall += r.j;
+          if (n_wall > 0x7fffffffu) { atomicAdd(&sstat[6], (unsigned long long)n_wall); n_wall = 0; }
+        }
+        const unsigned long long me = __ballot(ended);
+        if (me) {
+          n_ended += (uint32_t)__popcll(me);
+          n_susp += (uint32_t)__popcll(__ballot(pend == ST_SUSPENDED));
+          ISX_TD_ADD(12, __popcll(me));
+        }
+      }
+      ISX_TD_MARK(2);
+      // ---- hand the rays that left rule S1' to the assist wave
+      const unsigned long long hm = __ballot(hand);
+      if (hm) {
+        const uint32_t cnt = (uint32_t)__popcll(hm);
+        uint32_t base = 0, ok = 0;
+        if (lane == 0) {
+          for (;;) {
+            const uint32_t res = ld(&Q->pend_res), hd = ld(&Q->pend_head);
+            if (res + cnt - hd > kPendCap) break;                      // no room: keep them for a trip
+            uint32_t expect = res;
+            if (__hip_atomic_compare_exchange_strong(&Q->pend_res, &expect, res + cnt, __ATOMIC_ACQ_REL, __ATOMIC_RELAXED,
+                                                     __HIP_MEMORY_SCOPE_WORKGROUP)) { base = res; ok = 1u; break; }
+          }
+        }
+        ok = (uint32_t)__builtin_amdgcn_readfirstlane((int)ok);
+        base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+        if (ok) {
+          if (hand) {
+            const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(hm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)hm, 0u));
+            uint4* dst = pend_q + 4 * ((base + rank) & (kPendCap - 1));
+            const unsigned long long px = (unsigned long long)__double_as_longlong(r.p.x), py = (unsigned long long)__double_as_longlong(r.p.y),
+                                     pz = (unsigned long long)__double_as_longlong(r.p.z), vx = (unsigned long long)__double_as_longlong(r.v.x),
+                                     vy = (unsigned long long)__double_as_longlong(r.v.y), vz = (unsigned long long)__double_as_longlong(r.v.z);
+            dst[0] = make_uint4((uint32_t)px, (uint32_t)(px >> 32), (uint32_t)py, (uint32_t)(py >> 32));
+            dst[1] = make_uint4((uint32_t)pz, (uint32_t)(pz >> 32), (uint32_t)vx, (uint32_t)(vx >> 32));
+            dst[2] = make_uint4((uint32_t)vy, (uint32_t)(vy >> 32), (uint32_t)vz, (uint32_t)(vz >> 32));
+            dst[3] = make_uint4(r.ido | (r.tgt ? IDO_TARGET : 0u), r.j, (uint32_t)r.on, 0u);
+            hand = false;
+          }
+          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+          if (lane == 0) { add(&Q->busy, cnt); add(&Q->pend_pub, cnt); }
+        } else {
+          ISX_TD_ADD(10, 1);
+        }
+      }
+      ISX_TD_MARK(3);
+    }
+    ISX_TD_FLUSH();
+    if (lane == 0) add(&Q->tracers_done, 1u);
+  } else {
+    // =============================================================== the assist wave
+    uint32_t reg_slot = 0, reg_left = 0, reg_id = 0xffffffffu;       // cursor in the open region of exit lines (SINK_REC)
+    uint32_t spins = 0;
+    // one wave serves eleven: it goes first whenever it has something to do (its SIMD's five tracers take every other slot)
+    __builtin_amdgcn_s_setprio(3);
+    for (;;) {
+      const uint32_t res = ld(&Q->pend_res), pub = ld(&Q->pend_pub), hd = ld(&Q->pend_head);
+      const uint32_t n = pub == res ? res - hd : 0u;                 // everything below res is written once pub has caught up
+      if (n == 0u) {
+        if (res == hd && ld(&Q->tracers_done) == (uint32_t)n_tracers) break;
+        if (++spins > kSpinLimit) { if (lane == 0) add(&Q->failed, 1u); break; }
+        __builtin_amdgcn_s_sleep(4);
+        continue;
+      }
+      spins = 0;
+      const uint32_t take = n < 64u ? n : 64u;
+      const bool have = (uint32_t)lane < take;
+      Ray r;
+      ray_start(g, r, 0);
+      if (have) {
+        const uint4* src = pend_q + 4 * ((hd + (uint32_t)lane) & (kPendCap - 1));
+        const uint4 a = src[0], b = src[1], c = src[2], e = src[3];
+        r.p.x = __longlong_as_double(((long long)a.y << 32) | a.x); r.p.y = __longlong_as_double(((long long)a.w << 32) | a.z);
+        r.p.z = __longlong_as_double(((long long)b.y << 32) | b.x); r.v.x = __longlong_as_double(((long long)b.w << 32) | b.z);
+        r.v.y = __longlong_as_double(((long long)c.y << 32) | c.x); r.v.z = __longlong_as_double(((long long)c.w << 32) | c.z);
+        r.ido = e.x & ~IDO_TARGET; r.tgt = (e.x & IDO_TARGET) != 0u; r.j = e.y; r.on = (int)e.z;
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");          // (the slots are free once they have been read)
+      if (lane == 0) add(&Q->pend_head, take);
+      // ---- one step of everything that is not a bounce off the inner sphere.  A ray that is then neither ended nor back on
+      // the inner sphere (it sits on the rim, on the outer sphere, or starts its re-scattered life on the world box) goes to
+      // the back of the pending queue: its next step is taken with a full wave again, not with the two or three lanes that
+      // need one.  (No room there: it takes its steps here.)
+      int st = 0;
+      bool go = have;
+      for (;;) {
+        if (go) {
+          if (CH != 0 && r.tgt) chord_leave(r);
+          V3 q;
+          const int kind = next_hit_generic(g, r.p, r.v, r.on, q);
+          st = ray_arrive<false, LEAN, CH, PH_DIRECT>(h, g, r, seed, first, kind, q);
+          if (RESC && st != 0 && h.source_model == 1 && !r.scattered()) {   // nonLambertianFlux.C:253-268
+            n_wall += r.j;
+            ray_rescatter(g, r, seed, first);
+            st = 0;
+          }
+          if (st != 0 || r.on == K_INNER) go = false;
+        }
+        const unsigned long long gm = __ballot(go);
+        if (gm == 0ull) break;
+        const uint32_t cnt = (uint32_t)__popcll(gm);
+        uint32_t base = 0, ok = 0;
+        if (lane == 0) {
+          for (;;) {
+            const uint32_t rs = ld(&Q->pend_res), h2 = ld(&Q->pend_head);
+            if (rs + cnt - h2 > kPendCap) break;
+            uint32_t expect = rs;
+            if (__hip_atomic_compare_exchange_strong(&Q->pend_res, &expect, rs + cnt, __ATOMIC_ACQ_REL, __ATOMIC_RELAXED,
+                                                     __HIP_MEMORY_SCOPE_WORKGROUP)) { base = rs; ok = 1u; break; }
+          }
+        }
+        ok = (uint32_t)__builtin_amdgcn_readfirstlane((int)ok);
+        base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+        if (!ok) continue;
+        if (go) {
+          const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(gm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)gm, 0u));
+          uint4* dst = pend_q + 4 * ((base + rank) & (kPendCap - 1));
+          const unsigned long long px = (unsigned long long)__double_as_longlong(r.p.x), py = (unsigned long long)__double_as_longlong(r.p.y),
+                                   pz = (unsigned long long)__double_as_longlong(r.p.z), vx = (unsigned long long)__double_as_longlong(r.v.x),
+                                   vy = (unsigned long long)__double_as_longlong(r.v.y), vz = (unsigned long long)__double_as_longlong(r.v.z);
+          dst[0] = make_uint4((uint32_t)px, (uint32_t)(px >> 32), (uint32_t)py, (uint32_t)(py >> 32));
+          dst[1] = make_uint4((uint32_t)pz, (uint32_t)(pz >> 32), (uint32_t)vx, (uint32_t)(vx >> 32));
+          dst[2] = make_uint4((uint32_t)vy, (uint32_t)(vy >> 32), (uint32_t)vz, (uint32_t)(vz >> 32));
+          dst[3] = make_uint4(r.ido | (r.tgt ? IDO_TARGET : 0u), r.j, (uint32_t)r.on, 0u);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        if (lane == 0) add(&Q->pend_pub, cnt);
+        break;
+      }
+      const bool requeued = go;   // (still counted in `busy`)
+      // ---- census + exit lines of the rays that ended
+      const bool ended = have && st != 0, exited = have && st == ST_EXITED;
+      const bool below = exited && (r.p.z < portz);                   // isRayPassingThroughExitPort, fluxAtObserver.C:162-166
+      if (ended) n_wall += r.j;
+      if (n_wall > 0x7fffffffu) { atomicAdd(&sstat[6], (unsigned long long)n_wall); n_wall = 0; }
+      const uint32_t c_ended = (uint32_t)__popcll(__ballot(ended));
+      n_ended += c_ended;
+      n_exited += (uint32_t)__popcll(__ballot(exited));
+      n_susp += (uint32_t)__popcll(__ballot(have && st == ST_SUSPENDED));
+      const unsigned long long m = __ballot(below);
+      if (m) {
+        const uint32_t cnt = (uint32_t)__popcll(m);
+        n_counted += cnt;
+        if (cnt > reg_left) {   // close the open region, reserve the next one (kRegion)
+          if (lane == 0 && reg_id != 0xffffffffu) d_arg.rec_counts[reg_id] = kRegion - reg_left;
+          uint32_t id = 0;
+          if (lane == 0) id = atomicAdd(&wk.ctr[Q_REGIONS], 1u);
+          reg_id = (uint32_t)__builtin_amdgcn_readfirstlane((int)id);
+          reg_slot = 0; reg_left = kRegion;
+        }
+        if (below) {
+          const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+          double2* dst = reinterpret_cast<double2*>(d_arg.rec_lines + 6ull * ((uint64_t)reg_id * kRegion + (uint64_t)(reg_slot + rank)));
+          dst[0] = make_double2(r.p.x, r.p.y); dst[1] = make_double2(r.p.z, r.v.x); dst[2] = make_double2(r.v.y, r.v.z);
+        }
+        reg_slot += cnt; reg_left -= cnt;
+      }
+      // ---- the rays that go on: back to the tracers
+      const bool back = have && st == 0 && !requeued;
+      const unsigned long long bm = __ballot(back);
+      if (bm) {
+        const uint32_t cnt = (uint32_t)__popcll(bm);
+        const uint32_t pubr = ld(&Q->resume_pub);
+        uint32_t w = 0;
+        while (pubr + cnt - ld(&Q->resume_head) > kResumeCap) {       // room?  (the tracers never wait for this wave)
+          if (++w > kSpinLimit) { if (lane == 0) add(&Q->failed, 1u); break; }
+          __builtin_amdgcn_s_sleep(2);
+        }
+        if (back) {
+          const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(bm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bm, 0u));
+          uint32_t cw2 = 0u, cw3 = 0u;
+          if (r.j & 1u) {   // the tracer's next step finds words (2,3) of block j/2 in the lane (bounce_words, PH_EVEN)
+            uint32_t wv[4];
+            draw_block(seed, first + (uint64_t)r.offset(), r.j >> 1, r.stream(), wv);
+            cw2 = wv[2]; cw3 = wv[3];
+          }
+          uint4* dst = resume_q + 4 * ((pubr + rank) & (kResumeCap - 1));
+          const unsigned long long px = (unsigned long long)__double_as_longlong(r.p.x), py = (unsigned long long)__double_as_longlong(r.p.y),
+                                   pz = (unsigned long long)__double_as_longlong(r.p.z), vx = (unsigned long long)__double_as_longlong(r.v.x),
+                                   vy = (unsigned long long)__double_as_longlong(r.v.y), vz = (unsigned long long)__double_as_longlong(r.v.z);
+          dst[0] = make_uint4((uint32_t)px, (uint32_t)(px >> 32), (uint32_t)py, (uint32_t)(py >> 32));
+          dst[1] = make_uint4((uint32_t)pz, (uint32_t)(pz >> 32), (uint32_t)vx, (uint32_t)(vx >> 32));
+          dst[2] = make_uint4((uint32_t)vy, (uint32_t)(vy >> 32), (uint32_t)vz, (uint32_t)(vz >> 32));
+          dst[3] = make_uint4(r.ido | (r.tgt ? IDO_TARGET : 0u), r.j, cw2, cw3);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        if (lane == 0) add(&Q->resume_pub, cnt);
+      }
+      if (c_ended && lane == 0) __hip_atomic_fetch_sub(&Q->busy, c_ended, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
+    if (lane == 0 && reg_id != 0xffffffffu) d_arg.rec_counts[reg_id] = kRegion - reg_left;
+  }
+
+  // ---- census (persistent_body's epilogue)
+  atomicAdd(&sstat[6], (unsigned long long)n_wall);
+  if (lane == 0) {
+    atomicAdd(&sstat[1], (unsigned long long)n_exited);
+    atomicAdd(&sstat[2], (unsigned long long)n_counted);
+    atomicAdd(&sstat[3], (unsigned long long)(n_ended - n_exited - n_susp));  // absorbed
+    atomicAdd(&sstat[4], (unsigned long long)n_susp);
+    atomicAdd(&sstat[0], (unsigned long long)n_taken);
+  }
+  __syncthreads();
+  if (tid == 0 && Q->failed) atomicAdd(&wk.stats[7], (unsigned long long)Q->failed);
+  {
+    uint32_t t2 = threadIdx.x;
+    asm volatile("" : "+v"(t2));
+    if (t2 < 7u) {
+      const unsigned long long c = sstat[t2];
+      if (c) atomicAdd(&wk.stats[t2], c);
+    }
+  }
+}
+
+#ifndef ISX_ASSIST_BLOCK
+#define ISX_ASSIST_BLOCK 768
+#endif
+#define ISX_ASSIST_ATTR __launch_bounds__(ISX_ASSIST_BLOCK) __attribute__((amdgpu_waves_per_eu(6, 6)))
+extern "C" __global__ void ISX_ASSIST_ATTR
+isx_trace_assist_kernel(const Geom g, const DetGrid d, const Work wk) { assist_body<0, false>(g, d, wk); }
+extern "C" __global__ void ISX_ASSIST_ATTR
+isx_trace_assist_chord_kernel(const Geom g, const DetGrid d, const Work wk) { assist_body<1, false>(g, d, wk); }
+extern "C" __global__ void ISX_ASSIST_ATTR
+isx_trace_assist_brdf_kernel(const Geom g, const DetGrid d, const Work wk) { assist_body<0, true>(g, d, wk); }
+
 // ------------------------------------------------------------------ binning kernel of the two-kernel pipeline
 // Persistent waves take the regions of exit lines the trace kernel filled (kRegion slots each, rec_counts[region] lines in
 // them) off the launch's queue, ctr[Q_BIN], and bin them 64 lines at a time: lane = line for the per-line preparation
