@@ -50,10 +50,16 @@ int env_int(std::initializer_list<const char*> names, int dflt) {
 // One directory per job, private to the user: <ISX_RENDEZVOUS | $XDG_RUNTIME_DIR | $TMPDIR | /tmp>/isx_rdzv_<uid>_<job>.
 // <job> is the per-launch nonce: ISX_JOB_ID, else torchrun's TORCHELASTIC_RUN_ID + MASTER_PORT.  A multi-rank launch
 // without any of them is refused (two jobs would share one directory).  Files: `id` = magic | job tag | ncclUniqueId,
-// created with O_EXCL, mode 0600, published by rename; `ready.<rank>` / `fail.<rank>` = the pre-flight of rccl_init().
+// created with O_EXCL, mode 0600, published by rename; `launch` = rank 0's nonce of this launch; `ready.<rank>` /
+// `fail.<rank>` = the pre-flight of rccl_init(), each carrying that nonce (a file of an earlier launch is ignored).
 constexpr char kMagic[8] = {'I', 'S', 'X', 'R', 'D', 'Z', 'V', '2'};
 constexpr size_t kTagLen = 96;
-constexpr int kWaitSeconds = 120;
+constexpr int kWaitSecondsDefault = 120;
+// how long a rank waits for the others in the rendezvous directory (ISX_RENDEZVOUS_WAIT, seconds: tests shorten it)
+int wait_seconds() {
+  if (const char* s = std::getenv("ISX_RENDEZVOUS_WAIT")) { const int v = std::atoi(s); if (v >= 1 && v <= 3600) return v; }
+  return kWaitSecondsDefault;
+}
 
 bool job_tag(std::string& tag) {
   if (const char* s = std::getenv("ISX_JOB_ID")) { tag = s; return !tag.empty(); }
@@ -110,10 +116,33 @@ bool publish(const std::string& dir, const std::string& name, const void* bytes,
   return true;
 }
 
-// a file of THIS launch: owned by us and not older than the launch skew we tolerate
-bool fresh(const std::string& path, std::time_t started, struct stat* sb) {
-  return stat(path.c_str(), sb) == 0 && sb->st_uid == getuid() && sb->st_mtime + kWaitSeconds >= started;
+// Files of the pre-flight carry the nonce of THIS launch (rank 0 draws it and publishes it as `launch`); a file of an
+// earlier launch with the same job tag -- a `fail.<r>` that was never removed, a `ready.<r>` of a rank that died before
+// ncclCommInitRank -- has another nonce and is ignored, whatever its age.
+bool read_nonce(const std::string& path, unsigned long long* nonce) {
+  struct stat sb;
+  if (stat(path.c_str(), &sb) != 0 || sb.st_uid != getuid() || sb.st_size != (off_t)(sizeof(kMagic) + sizeof(*nonce))) return false;
+  unsigned char blob[sizeof(kMagic) + sizeof(*nonce)];
+  FILE* f = std::fopen(path.c_str(), "rb");
+  if (!f) return false;
+  const bool ok = std::fread(blob, 1, sizeof(blob), f) == sizeof(blob) && std::memcmp(blob, kMagic, sizeof(kMagic)) == 0;
+  std::fclose(f);
+  if (ok) std::memcpy(nonce, blob + sizeof(kMagic), sizeof(*nonce));
+  return ok;
 }
+bool publish_nonce(const std::string& dir, const std::string& name, unsigned long long nonce) {
+  unsigned char blob[sizeof(kMagic) + sizeof(nonce)];
+  std::memcpy(blob, kMagic, sizeof(kMagic));
+  std::memcpy(blob + sizeof(kMagic), &nonce, sizeof(nonce));
+  (void)unlink((dir + "/" + name).c_str());
+  return publish(dir, name, blob, sizeof(blob));
+}
+bool has_nonce(const std::string& path, unsigned long long nonce) {
+  unsigned long long got = 0;
+  return read_nonce(path, &got) && got == nonce;
+}
+
+std::string g_fail_file;   // this rank's fail.<rank>, removed when the process leaves (Comm::finalize)
 
 struct Rccl {
   bool ready = false, failed = false;
@@ -129,22 +158,50 @@ bool rccl_init(const Comm& c) {
   R.failed = true;  // until proven otherwise
   std::string dir, tag;
   if (!rendezvous_dir(c, dir, tag)) return false;
-  const std::time_t started = std::time(nullptr);
   // ---- pre-flight: a rank whose GPU cannot be bound says so in the directory, so that nobody enters
   // ncclCommInitRank (which has no time-out) for a job that cannot start
-  const bool dev_ok = ensure_device();   // libisx has bound this process to its GPU (same HIP runtime)
+  // (ISX_COMM_ASSUME_DEVICE=1, tests only: rehearse the pre-flight's file protocol on a box without a GPU)
+  const bool dev_ok = ensure_device() || (std::getenv("ISX_COMM_ASSUME_DEVICE") && std::atoi(std::getenv("ISX_COMM_ASSUME_DEVICE")) == 1);
   const std::string me = std::to_string(c.rank);
-  if (!publish(dir, (dev_ok ? "ready." : "fail.") + me, nullptr, 0)) {
+  (void)unlink((dir + "/ready." + me).c_str());   // nothing of this rank survives from an earlier launch with the same tag
+  (void)unlink((dir + "/fail." + me).c_str());
+  unsigned long long nonce = 0;
+  if (c.rank == 0) {
+    nonce = ((unsigned long long)std::chrono::steady_clock::now().time_since_epoch().count() << 20) ^ (unsigned long long)getpid() ^
+            ((unsigned long long)std::time(nullptr) << 40);
+    if (nonce == 0) nonce = 1;
+    if (!publish_nonce(dir, "launch", nonce)) {
+      std::cerr << "Error: isx_comm: cannot write into " << dir << std::endl;
+      return false;
+    }
+  }
+  auto announce = [&](unsigned long long n) {
+    const std::string name = (dev_ok ? "ready." : "fail.") + me;
+    if (!dev_ok) g_fail_file = dir + "/" + name;
+    return publish_nonce(dir, name, n);
+  };
+  if (c.rank == 0 && !announce(nonce)) {
     std::cerr << "Error: isx_comm: cannot write into " << dir << std::endl;
     return false;
   }
-  bool all_ready = false, someone_failed = !dev_ok;
-  for (int tries = 0; tries < kWaitSeconds * 20 && !all_ready && !someone_failed; ++tries) {
+  bool all_ready = false, someone_failed = !dev_ok && c.rank == 0;
+  for (int tries = 0; tries < wait_seconds() * 20 && !all_ready && !someone_failed; ++tries) {
+    if (c.rank != 0) {   // follow rank 0's nonce (the `launch` file of an earlier launch may still be there for a moment)
+      unsigned long long seen = 0;
+      if (read_nonce(dir + "/launch", &seen) && seen != nonce) {
+        nonce = seen;
+        if (!announce(nonce)) {
+          std::cerr << "Error: isx_comm: cannot write into " << dir << std::endl;
+          return false;
+        }
+      }
+      if (nonce == 0) { std::this_thread::sleep_for(std::chrono::milliseconds(50)); continue; }
+      if (!dev_ok) { someone_failed = true; break; }
+    }
     int n_ready = 0;
     for (int r = 0; r < c.world; ++r) {
-      struct stat sb;
-      if (fresh(dir + "/fail." + std::to_string(r), started, &sb)) someone_failed = true;
-      else if (fresh(dir + "/ready." + std::to_string(r), started, &sb)) n_ready++;
+      if (has_nonce(dir + "/fail." + std::to_string(r), nonce)) someone_failed = true;
+      else if (has_nonce(dir + "/ready." + std::to_string(r), nonce)) n_ready++;
     }
     all_ready = n_ready == c.world;
     if (!all_ready && !someone_failed) std::this_thread::sleep_for(std::chrono::milliseconds(50));
@@ -156,13 +213,14 @@ bool rccl_init(const Comm& c) {
   }
   // ---- the ncclUniqueId
   ncclUniqueId id;
-  unsigned char blob[sizeof(kMagic) + kTagLen + sizeof(id)];
+  unsigned char blob[sizeof(kMagic) + kTagLen + sizeof(nonce) + sizeof(id)];
   if (c.rank == 0) {
     ISX_NCCL_OK(ncclGetUniqueId(&id));
     std::memset(blob, 0, sizeof(blob));
     std::memcpy(blob, kMagic, sizeof(kMagic));
     std::strncpy((char*)blob + sizeof(kMagic), tag.c_str(), kTagLen - 1);
-    std::memcpy(blob + sizeof(kMagic) + kTagLen, &id, sizeof(id));
+    std::memcpy(blob + sizeof(kMagic) + kTagLen, &nonce, sizeof(nonce));
+    std::memcpy(blob + sizeof(kMagic) + kTagLen + sizeof(nonce), &id, sizeof(id));
     (void)unlink((dir + "/id").c_str());   // nothing of an earlier launch survives
     if (!publish(dir, "id", blob, sizeof(blob))) {
       std::cerr << "Error: isx_comm: cannot publish " << dir << "/id" << std::endl;
@@ -170,28 +228,29 @@ bool rccl_init(const Comm& c) {
     }
   } else {
     bool got = false;
-    for (int tries = 0; tries < kWaitSeconds * 20 && !got; ++tries) {
+    for (int tries = 0; tries < wait_seconds() * 20 && !got; ++tries) {
       struct stat sb;
-      if (fresh(dir + "/id", started, &sb) && sb.st_size == (off_t)sizeof(blob)) {
+      if (stat((dir + "/id").c_str(), &sb) == 0 && sb.st_uid == getuid() && sb.st_size == (off_t)sizeof(blob)) {
         FILE* f = std::fopen((dir + "/id").c_str(), "rb");
         if (f) {
           got = std::fread(blob, 1, sizeof(blob), f) == sizeof(blob) && std::memcmp(blob, kMagic, sizeof(kMagic)) == 0 &&
-                std::strncmp((const char*)blob + sizeof(kMagic), tag.c_str(), kTagLen - 1) == 0;
+                std::strncmp((const char*)blob + sizeof(kMagic), tag.c_str(), kTagLen - 1) == 0 &&
+                std::memcmp(blob + sizeof(kMagic) + kTagLen, &nonce, sizeof(nonce)) == 0;   // the id of THIS launch
           std::fclose(f);
         }
       }
       if (!got) std::this_thread::sleep_for(std::chrono::milliseconds(50));
     }
     if (!got) {
-      std::cerr << "Error: isx_comm: rank " << c.rank << " found no id of job '" << tag << "' in " << dir << " within " << kWaitSeconds
+      std::cerr << "Error: isx_comm: rank " << c.rank << " found no id of job '" << tag << "' in " << dir << " within " << wait_seconds()
                 << " s" << std::endl;
       return false;
     }
-    std::memcpy(&id, blob + sizeof(kMagic) + kTagLen, sizeof(id));
+    std::memcpy(&id, blob + sizeof(kMagic) + kTagLen + sizeof(nonce), sizeof(id));
   }
   ISX_NCCL_OK(ncclCommInitRank(&R.comm, c.world, id, c.rank));   // returns once every rank has joined
   (void)unlink((dir + "/ready." + me).c_str());
-  if (c.rank == 0) { (void)unlink((dir + "/id").c_str()); (void)rmdir(dir.c_str()); }   // rmdir succeeds once the last rank has cleaned up
+  if (c.rank == 0) { (void)unlink((dir + "/id").c_str()); (void)unlink((dir + "/launch").c_str()); (void)rmdir(dir.c_str()); }   // rmdir succeeds once the last rank has cleaned up
   else (void)rmdir(dir.c_str());
   ISX_HIP_OK(hipStreamCreateWithFlags(&R.stream, hipStreamNonBlocking));
   R.failed = false;
@@ -295,6 +354,7 @@ bool Comm::agree(bool local_ok) {
 }
 
 void Comm::finalize() {
+  if (!g_fail_file.empty()) { (void)unlink(g_fail_file.c_str()); g_fail_file.clear(); }   // (a relaunch with the same tag starts clean)
   if (R.ready) {
     (void)hipStreamSynchronize(R.stream);
     (void)ncclCommDestroy(R.comm);
@@ -308,6 +368,19 @@ std::string outputPath(const std::string& base) { return comm().writer() ? getUn
 
 // ---------------------------------------------------------------------------------------------
 // Sharded equivalents of the ABI calls: this rank's share, then ONE collective that also carries the status.
+//
+// The collective's element count comes from arguments every rank shares, so it is the same on all of them -- but it must
+// be a count the library accepts: a configuration the ABI refuses (n_theta * n_phi outside 1..36000, more than 36000 discs
+// or histogram bins) leaves only the status word to exchange, instead of a buffer sized by unvalidated numbers.
+namespace {
+constexpr long long kMaxBins = 36000;   // isx.h: the LDS histogram limit of every sink
+size_t grid_bins(const isx_config* cfg) {
+  if (!cfg || cfg->n_theta < 1 || cfg->n_phi < 1) return 0;
+  const long long nb = (long long)cfg->n_theta * (long long)cfg->n_phi;
+  return nb <= kMaxBins ? (size_t)nb : 0;
+}
+size_t list_bins(long long n) { return n >= 1 && n <= kMaxBins ? (size_t)n : 0; }
+}  // namespace
 int fluxmap_all(const isx_config* cfg, uint64_t n_rays, uint64_t seed, uint64_t first_ray, uint64_t* hits, isx_stats* st) {
   Comm& c = comm();
   if (!c.active()) return isx_fluxmap(cfg, n_rays, seed, first_ray, hits, st);
@@ -315,7 +388,7 @@ int fluxmap_all(const isx_config* cfg, uint64_t n_rays, uint64_t seed, uint64_t 
   c.shard(n_rays, f, cnt);
   isx_stats local{};
   int rc = isx_fluxmap(cfg, cnt, seed, first_ray + f, hits, &local);
-  rc = c.reduce(rc, hits, (size_t)cfg->n_theta * cfg->n_phi, &local);
+  rc = c.reduce(rc, hits, grid_bins(cfg), &local);
   if (rc == ISX_OK && st) *st = local;
   return rc;
 }
@@ -328,7 +401,7 @@ int fluxmap_per_position_range_all(const isx_config* cfg, uint64_t rays_per_posi
   c.shard(n_groups, g0, ng);   // whole detector groups per rank: group g keeps its rays [first_ray + g*rays_per_position, ...)
   isx_stats local{};
   int rc = isx_fluxmap_per_position(cfg, rays_per_position, fold, first_group + g0, ng, seed, first_ray, hits, &local);
-  rc = c.reduce(rc, hits, (size_t)cfg->n_theta * cfg->n_phi, &local);
+  rc = c.reduce(rc, hits, grid_bins(cfg), &local);
   if (rc == ISX_OK && st) *st = local;
   return rc;
 }
@@ -363,7 +436,7 @@ int disc_sweep_all(const isx_config* cfg, const double* centers_axes, int32_t n_
   c.shard(n_rays, f, cnt);
   isx_stats local{};
   int rc = isx_disc_sweep(cfg, centers_axes, n_disc, radius, half_thick, cnt, seed, first_ray + f, hits, &local);
-  rc = c.reduce(rc, hits, n_disc > 0 ? (size_t)n_disc : 0, &local);
+  rc = c.reduce(rc, hits, list_bins(n_disc), &local);
   if (rc == ISX_OK && st) *st = local;
   return rc;
 }
@@ -379,11 +452,11 @@ int disc_sweep_per_position_all(const isx_config* cfg, const double* centers_axe
   c.shard(n_disc > 0 ? (uint64_t)n_disc : 0, k0, nk);
   isx_stats local{};
   int rc = ISX_OK;
-  if (n_disc > 0) std::memset(hits, 0, (size_t)n_disc * sizeof(uint64_t));
+  if (list_bins(n_disc)) std::memset(hits, 0, list_bins(n_disc) * sizeof(uint64_t));
   if (nk > 0)
     rc = isx_disc_sweep_per_position(cfg, centers_axes + 6 * k0, (int32_t)nk, radius, half_thick, rays_per_position, seed,
                                      first_ray + k0 * rays_per_position, hits + k0, &local);
-  rc = c.reduce(rc, hits, n_disc > 0 ? (size_t)n_disc : 0, &local);
+  rc = c.reduce(rc, hits, list_bins(n_disc), &local);
   if (rc == ISX_OK && st) *st = local;
   return rc;
 }
@@ -396,7 +469,7 @@ int exit_dz_hist_all(const isx_config* cfg, uint64_t n_rays, uint64_t seed, uint
   c.shard(n_rays, f, cnt);
   isx_stats local{};
   int rc = isx_exit_dz_hist(cfg, cnt, seed, first_ray + f, nbins, hist, &local);
-  rc = c.reduce(rc, hist, nbins > 0 ? (size_t)nbins : 0, &local);
+  rc = c.reduce(rc, hist, list_bins(nbins), &local);
   if (rc == ISX_OK && st) *st = local;
   return rc;
 }

@@ -10,7 +10,9 @@ A "step" = one pass of the hot path over one batch: every rank traces `--rays` r
 contiguous slice of the global ray-index stream of that step, so results do not depend on N),
 bins them into the 180x90 detector histogram on its GPU, and the histograms are summed with
 ONE all-reduce over RCCL (torch.distributed backend "nccl").  Weak scaling: per-GPU work is
-fixed.  Prints one JSON line on rank 0.
+fixed -- 5e7 rays per GPU per step for EVERY N, so the N = 1 point of a scaling curve is the
+single-GPU bench.  At N = 8 a second timed loop runs BASELINE configs[4] (1e9 rays per step over
+the node) and is reported under "configs4".  Prints one JSON line on rank 0.
 """
 import argparse
 import json
@@ -46,8 +48,7 @@ def parse():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--rays", type=int, default=0,
-                    help="rays per GPU per step; default 5e7 (BASELINE configs[1]), and 1.25e8 at --gpus 8 "
-                         "(BASELINE configs[4]: 1e9 rays per step over the node)")
+                    help="rays per GPU per step; default 5e7 (BASELINE configs[1]) for every --gpus")
     ap.add_argument("--seed", type=lambda s: int(s, 0), default=0x5EED0001)
     ap.add_argument("--cpu-rays", type=int, default=-1, help="oracle sample size for cpu_baseline (0: skip, -1: auto)")
     ap.add_argument("--trace-mode", choices=["explicit", "chord"], default="explicit",
@@ -56,6 +57,19 @@ def parse():
     ap.add_argument("--reduce", choices=["auto", "device", "host"], default="auto",
                     help="where the histogram lives for the all-reduce")
     return ap.parse_args()
+
+
+def default_rays_per_gpu(world):
+    """5e7 rays per GPU per step (BASELINE configs[1]) whatever the number of GPUs: the points of a scaling curve must be
+    the same per-GPU workload (tests/test_host_driver.py asserts it)."""
+    del world
+    return 50_000_000
+
+
+# the reference's own number for this metric's workload (BASELINE.md section 1: per-position 180x90 map, 8.1e8 rays in
+# 12 523.9 s on <= 4 ROBAST threads of an unknown CPU) -- quoted in the bench line so that it is self-contained
+REFERENCE_PUBLISHED = {"value": 0.0647, "unit": "Mrays/s", "what": "fluxAtObserverOptimize.C sweepDetector, 8.1e8 rays in 12523.9 s, <= 4 ROBAST "
+                       "threads, CPU unknown (flux_at_observer/results_overnight_03_31-60_0_-75_5/fluxmap_50000rays_180x90_src-60_0_-75.csv:16217)"}
 
 
 def cpu_baseline(seed, n_req):
@@ -78,7 +92,7 @@ def cpu_baseline(seed, n_req):
     t0 = time.time()
     _, st = oracle.fluxmap(cfg, n_req, seed, 0, threads)
     dt = time.time() - t0
-    return {"value": n_req / dt / 1e6, "unit": "Mrays/s", "cores": threads, "kind": "port",
+    return {"value": n_req / dt / 1e6, "unit": "Mrays/s", "cores": threads, "kind": "port", "reference_published": REFERENCE_PUBLISHED,
             "sample": f"{n_req} rays of the same workload (180x90 map, src(-60,0,-75), port 170deg), "
                       f"oracle/libisx_oracle.so, OpenMP {threads} threads, {dt:.1f} s"}
 
@@ -93,8 +107,9 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != a.gpus and world > 1:
-        raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}")
+    if world != a.gpus:   # (before any GPU call: a bare `bench.py --gpus 4` would silently measure one GPU)
+        raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}: launch through python -m torch.distributed.run "
+                         f"--nnodes=1 --nproc-per-node {a.gpus} --master-addr 127.0.0.1 bench.py --gpus {a.gpus} ...")
 
     import numpy as np
     import torch
@@ -126,8 +141,8 @@ def main():
     cfg = isx.default_config()
     cfg.trace_mode = 1 if a.trace_mode == "chord" else 0
     nb = cfg.n_theta * cfg.n_phi
-    n = a.rays if a.rays > 0 else (125_000_000 if world == 8 else 50_000_000)
-    which = "BASELINE configs[4]: 1e9 rays per step over 8 GPUs" if (world == 8 and n == 125_000_000) else "BASELINE configs[1]"
+    n = a.rays if a.rays > 0 else default_rays_per_gpu(world)
+    which = "BASELINE configs[1]"
 
     hist_dev = torch.zeros(nb, dtype=torch.int64, device=dev)
 
@@ -166,51 +181,79 @@ def main():
         dist.all_reduce(flag, op=dist.ReduceOp.MIN)
         mode = "device" if int(flag.item()) == 1 else "host"
 
-    kernel_ms, census, kind_ms = [], [], []
+    def timed_loop(n_rays, first_step, warmup, steps):
+        """`warmup` untimed + `steps` timed steps of n_rays rays per GPU -> (seconds = max over ranks, per-step records)"""
+        rec = {"kernel_ms": [], "kind_ms": [], "census": [], "allreduce_ms": []}
 
-    def step(s):
-        """trace + bin this rank's slice of step s, then all-reduce the 180x90 histogram."""
-        first, _ = isx.step_slice(s, rank, world, n)
-        if mode == "device":
-            hist_dev.zero_()
-            torch.cuda.synchronize()
-            isx.fluxmap_device(cfg, n, a.seed, first, hist_dev.data_ptr())
-            isx.sync()
-            st = isx.take_stats()
-            kind_ms.append(isx.last_kernel_ms())
-        else:
-            h, st = isx.fluxmap(cfg, n, a.seed, first)
-            kind_ms.append(isx.last_kernel_ms())
-            hist_dev.copy_(torch.from_numpy(h.reshape(-1).astype(np.int64)))
+        def step(s):
+            """trace + bin this rank's slice of step s, then all-reduce the 180x90 histogram."""
+            first, _ = isx.step_slice(s, rank, world, n_rays)
+            if mode == "device":
+                hist_dev.zero_()
+                torch.cuda.synchronize()
+                isx.fluxmap_device(cfg, n_rays, a.seed, first, hist_dev.data_ptr())
+                isx.sync()
+                st = isx.take_stats()
+                rec["kind_ms"].append(isx.last_kernel_ms())
+            else:
+                h, st = isx.fluxmap(cfg, n_rays, a.seed, first)
+                rec["kind_ms"].append(isx.last_kernel_ms())
+                hist_dev.copy_(torch.from_numpy(h.reshape(-1).astype(np.int64)))
+            if use_dist:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                dist.all_reduce(hist_dev, op=dist.ReduceOp.SUM)
+                e1.record()
+                torch.cuda.synchronize()
+                rec["allreduce_ms"].append(e0.elapsed_time(e1))
+            rec["kernel_ms"].append(st.t_kernel_ms)
+            rec["census"].append(st)
+
+        for s in range(first_step, first_step + warmup):
+            step(s)
+        for v in rec.values():
+            v.clear()
+        barrier()
+        t0 = time.perf_counter()
+        for s in range(first_step + warmup, first_step + warmup + steps):
+            step(s)
+        barrier()
+        dt = time.perf_counter() - t0
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
         if use_dist:
-            dist.all_reduce(hist_dev, op=dist.ReduceOp.SUM)
-        kernel_ms.append(st.t_kernel_ms)
-        census.append(st)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item()), rec
 
-    for s in range(a.warmup):
-        step(s)
-    kernel_ms.clear()
-    census.clear()
-    kind_ms.clear()
+    def over_ranks(values):
+        """[min, max] over the ranks of this rank's mean of `values` (what a bad scaling point would be diagnosed from)"""
+        v = torch.tensor([float(np.mean(values)) if len(values) else 0.0], dtype=torch.float64, device=dev)
+        if not use_dist:
+            return [float(v.item())] * 2
+        lo, hi = v.clone(), v.clone()
+        dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+        dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+        return [float(lo.item()), float(hi.item())]
 
-    barrier()
-    t0 = time.perf_counter()
-    for s in range(a.warmup, a.warmup + a.steps):
-        step(s)
-    barrier()
-    dt = time.perf_counter() - t0
-    t = torch.tensor([dt], dtype=torch.float64, device=dev)
-    if use_dist:
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    dt = float(t.item())
-
+    dt, rec = timed_loop(n, 0, a.warmup, a.steps)
+    kernel_ms, census, kind_ms = rec["kernel_ms"], rec["census"], rec["kind_ms"]
+    per_rank = {"kernel_ms": over_ranks(kernel_ms), "trace_ms": over_ranks([k[1] for k in kind_ms]),
+                "bin_ms": over_ranks([k[2] for k in kind_ms]), "allreduce_ms": over_ranks(rec["allreduce_ms"])}
     total_hits = int(hist_dev.sum().item())
+    # BASELINE configs[4] (1e9 rays per step over the 8 GPUs of a node) as a second timed loop at N = 8; extra keys only
+    configs4 = None
+    if world == 8 and a.rays <= 0:
+        n4 = 125_000_000
+        dt4, rec4 = timed_loop(n4, a.warmup + a.steps, 1, a.steps)
+        configs4 = {"workload": "BASELINE configs[4]: 1e9 rays per step over 8 GPUs (1.25e8 per GPU), same map", "rays_per_gpu_per_step": n4,
+                    "value": n4 * world * a.steps / dt4 / 1e6, "unit": "Mrays/s", "ms_per_step": dt4 / a.steps * 1e3,
+                    "kernel_ms_min_max_over_ranks": over_ranks(rec4["kernel_ms"]),
+                    "allreduce_ms_min_max_over_ranks": over_ranks(rec4["allreduce_ms"])}
     if rank == 0:
         rays_total = n * world * a.steps
         value = rays_total / dt / 1e6
         k_ms = float(np.mean(kernel_ms)) if kernel_ms else float("nan")
-        # --- rooflines, per launch.  The headline map runs as TWO kernels (isx_trace_rec_kernel -> exit lines in HBM ->
-        # isx_bin_lines_kernel); libisx times them separately with HIP events on its stream (isx_last_kernel_ms).
+        # --- rooflines, per launch.  The headline map runs as TWO kernels (trace kernel -> exit lines in HBM -> binning
+        # kernel); libisx times them separately with HIP events on its stream (isx_last_kernel_ms).
         t_single = float(np.mean([k[0] for k in kind_ms])) if kind_ms else 0.0
         t_trace = float(np.mean([k[1] for k in kind_ms])) if kind_ms else 0.0
         t_bin = float(np.mean([k[2] for k in kind_ms])) if kind_ms else 0.0
@@ -242,20 +285,30 @@ def main():
         peak_issue = cus * 4 * VALU_CLOCK_GHZ / 4.0
 
         def issue_block(kernel, live_ms, pk):
-            """VALU-issue roofline of one kernel: executed SQ_INSTS_VALU per ray (its PMC pass) x rays / its LIVE time."""
+            """VALU-issue roofline of one kernel: executed SQ_INSTS_VALU per ray (its PMC pass) x rays / its LIVE time.
+            `frac` charges every wave64 VALU instruction 4 cycles (the convention of rounds 1-2; it exceeds what a mixed stream
+            can reach, so a saturated kernel reads ~1); `frac_mix` prices the executed mix by class (f64 4 cycles, 32-bit 2,
+            v_mad_u64_u32 7, f64 rcp/rsq 16: tools/summarize_profile.py) against 1024 SIMDs x 2.4 GHz; `valu_busy` is the
+            counter that says whether the VALU had idle cycles at all."""
             blk = {"bound": "valu_issue", "kernel": kernel, "kernel_ms": live_ms, "peak": peak_issue, "unit": "G wave-instr/s",
                    "achieved": None, "frac": None, "traffic": (pk or {}).get("hbm_bytes_per_launch")}
             if pk and pk.get("valu_wave_insts_per_ray") and live_ms > 0:
                 ach = pk["valu_wave_insts_per_ray"] * n / (live_ms * 1e-3) / 1e9
                 blk.update(achieved=ach, frac=ach / peak_issue, valu_wave_insts_per_ray=pk["valu_wave_insts_per_ray"],
                            valu_busy=pk.get("valu_busy"), valu_lane_utilization=pk.get("valu_lane_utilization"),
-                           profiled_kernel_ms=pk.get("kernel_ms"))
+                           profiled_kernel_ms=pk.get("kernel_ms"), profiled_clock_ghz=pk.get("clock_ghz"))
+                mix = pk.get("issue_mix")
+                if mix:
+                    blk.update(peak_mix_cycles_per_ray=mix["cycles_per_ray"],
+                               frac_mix=mix["cycles_per_ray"] * n / (cus * 4 * VALU_CLOCK_GHZ * 1e9 * live_ms * 1e-3))
             return blk
 
         kern = pj.get("kernels", {})
+        k_trace = next((k for k in kern if "trace" in k), "isx_trace_assist_kernel")
+        k_bin = next((k for k in kern if "bin" in k), "isx_bin_slots_kernel")
         if pipeline:
-            b_trace = issue_block("isx_trace_rec_kernel", t_trace, kern.get("isx_trace_rec_kernel"))
-            b_bin = issue_block("isx_bin_lines_kernel", t_bin, kern.get("isx_bin_lines_kernel"))
+            b_trace = issue_block(k_trace, t_trace, kern.get(k_trace))
+            b_bin = issue_block(k_bin, t_bin, kern.get(k_bin))
             b_trace["algorithmic_hbm_bytes"], b_bin["algorithmic_hbm_bytes"] = alg_bytes_trace, alg_bytes_bin
             dominant, other = (b_bin, b_trace) if t_bin >= t_trace else (b_trace, b_bin)
         else:
@@ -282,8 +335,11 @@ def main():
             # convention.  `roofline` is the dominant (longer) kernel of the launch, `roofline_other_kernel` the second one.
             "roofline": dominant,
             "roofline_other_kernel": other,
-            "pipeline": ({"kernels": ["isx_trace_rec_kernel", "isx_bin_lines_kernel"], "trace_ms": t_trace, "bin_ms": t_bin,
+            "pipeline": ({"kernels": [k_trace, k_bin], "trace_ms": t_trace, "bin_ms": t_bin,
                           "exit_lines_per_launch": lines} if pipeline else None),
+            # per-rank means of the timed steps, [min, max] over the ranks: kernel time, its two halves, the one all-reduce
+            "per_rank_ms_min_max": per_rank,
+            "configs4": configs4,
             # the HBM figure the north star asks for: algorithmic bytes (exit lines written once and read once, 48 B each, plus
             # one 129.6 KB histogram) / kernel time against 8 TB/s
             "roofline_hbm": {"bound": "hbm", "achieved": hbm_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",

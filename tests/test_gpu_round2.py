@@ -437,6 +437,12 @@ def test_bench_two_ranks_share_the_gpu_over_gloo(isx):
     assert out["census_last_step"]["counted_below_z"] == counted0       # (rank 0's own census)
     # whole-job throughput: both ranks' rays over the slowest rank's time
     assert abs(out["value"] - 2 * rays / (out["ms_per_step"] * 1e3)) < 1e-6 * out["value"]
+    # what a bad scaling point would be diagnosed from: per-rank kernel time, its halves and the one all-reduce, [min, max] over ranks
+    pr = out["per_rank_ms_min_max"]
+    for key in ("kernel_ms", "trace_ms", "bin_ms", "allreduce_ms"):
+        lo, hi = pr[key]
+        assert 0 < lo <= hi, (key, pr)
+    assert pr["kernel_ms"][1] < out["ms_per_step"] and out["configs4"] is None
 
 
 def test_random_configurations_equal_the_oracle(isx, orc):

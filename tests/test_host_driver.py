@@ -220,6 +220,33 @@ def test_multirank_launch_stops_instead_of_hanging(cli, tmp_path):
     env = dict(base, ISX_QUIET="1", ISX_RAYS="1000", ISX_RANK="0", ISX_WORLD="2", ISX_RENDEZVOUS=str(tmp_path))
     r = subprocess.run([cli, *args], cwd=tmp_path, env=env, capture_output=True, text=True, timeout=60)
     assert r.returncode != 0 and "per-job nonce" in r.stderr, r.stderr
+    # files of an EARLIER launch with the same job tag (a fail.<r> that was never removed, a ready.<r> of a rank
+    # that died) carry that launch's nonce and must be ignored, whatever their age.  Relaunch at once with the same tag ...
+    for attempt in range(2):
+        procs = []
+        for rank in (0, 1):
+            env = dict(base, ISX_QUIET="1", ISX_RAYS="1000", ISX_RANK=str(rank), ISX_WORLD="2", ISX_JOB_ID="t-%d" % os.getpid(),
+                       ISX_RENDEZVOUS=str(tmp_path))
+            procs.append(subprocess.Popen([cli, *args], cwd=tmp_path, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+        for p in procs:
+            _, err = p.communicate(timeout=60)
+            assert p.returncode != 0 and ("could not bind its GPU" in err or "no CPU fallback" in err), err
+    # ... and a lone rank 0 that finds a well-formed ready.1 of another launch does not take it for a live rank (it would then
+    # publish the id and block in ncclCommInitRank for ever): it reports the missing rank after the rendezvous wait.
+    import struct
+    jobdir = [d for d in os.listdir(tmp_path) if d.startswith("isx_rdzv_")]
+    job = "stale-%d" % os.getpid()
+    rd = os.path.join(str(tmp_path), "isx_rdzv_%d_%s" % (os.getuid(), job))
+    os.makedirs(rd, mode=0o700, exist_ok=True)
+    for name in ("ready.1", "fail.1", "launch"):
+        with open(os.path.join(rd, name), "wb") as f:
+            f.write(b"ISXRDZV2" + struct.pack("<Q", 0x1234567))
+    env = dict(base, ISX_QUIET="1", ISX_RAYS="1000", ISX_RANK="0", ISX_WORLD="2", ISX_JOB_ID=job, ISX_RENDEZVOUS=str(tmp_path),
+               ISX_RENDEZVOUS_WAIT="2", ISX_COMM_ASSUME_DEVICE="1")
+    t0 = time.time()
+    r = subprocess.run([cli, *args], cwd=tmp_path, env=env, capture_output=True, text=True, timeout=60)
+    assert r.returncode != 0 and "not every rank showed up" in r.stderr and time.time() - t0 < 30, r.stderr
+    del jobdir
 
 
 # --------------------------------------------------------------------------------------------- GPU
@@ -365,3 +392,20 @@ def test_series_entry_point(cli, isx, tmp_path):
         assert meta["Exit port angle"] == "164 degrees"
         assert meta["Total rays exiting port"] == f"{st.counted_below_z} out of 20000"
         assert np.array_equal(rows[:, 2], np.array([float(f"{h / 20000.0:.6f}") for h in hits.reshape(-1)]))
+
+
+def test_bench_workload_does_not_depend_on_the_number_of_gpus():
+    """the points of a scaling curve are the same per-GPU workload (BASELINE configs[1]: 5e7 rays per GPU per
+    step), so the N = 1 point equals the single-GPU bench; configs[4] is an extra loop at N = 8, not a different default.  And
+    `bench.py --gpus N` without a launcher stops before it touches a GPU instead of measuring one GPU under another label."""
+    import importlib.util
+    import subprocess
+    import sys
+    spec = importlib.util.spec_from_file_location("bench_module", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    assert {bench.default_rays_per_gpu(w) for w in (1, 2, 4, 8)} == {50_000_000}
+    assert bench.REFERENCE_PUBLISHED["value"] == pytest.approx(810_000_000 / 12523.937080 / 1e6, rel=1e-3)
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4"], env=env, capture_output=True, text=True, timeout=120)
+    assert r.returncode != 0 and "torch.distributed.run" in (r.stderr + r.stdout) and r.stdout.strip() == ""

@@ -126,11 +126,11 @@ if pmc:
         # read (16 B per lane) -- the binning kernel reads its 48-byte exit lines as three 16-byte loads per lane, so its fetch
         # figure is doubled; the other kernels read a few KB of scalar/L2 traffic (no correction).  WRITE_SIZE is exact for
         # 16-B-per-lane streaming stores (the trace kernel's exit lines) and for the 8-byte atomics of the histogram flush.
-        fx = 2.0 if KERNEL == "isx_bin_lines_kernel" else 1.0
+        fx = 2.0 if KERNEL in ("isx_bin_lines_kernel", "isx_bin_slots_kernel") else 1.0
         fetch_b, write_b = pmc["FETCH_SIZE"] * 1024 * fx, pmc["WRITE_SIZE"] * 1024
         summ.update(fetch_bytes=fetch_b, write_bytes=write_b, hbm_bytes_per_launch=fetch_b + write_b, fetch_correction=fx,
                     note="FETCH_SIZE/WRITE_SIZE are KiB; gfx950 correction of MI355X_MICROARCH.md (HBM section): FETCH_SIZE x2 for "
-                         "wide coalesced streaming reads (applied to isx_bin_lines_kernel only), WRITE_SIZE exact.")
+                         "wide coalesced streaming reads (applied to the binning kernels only), WRITE_SIZE exact.")
         lines += [f"HBM bytes per launch: fetch {fetch_b/1e6:.3f} MB" + (" (FETCH_SIZE x 2, gfx950 streaming-read correction)" if fx != 1.0 else "") +
                   f" + write {write_b/1e6:.3f} MB = {(fetch_b+write_b)/1e6:.3f} MB.", ""]
     if big and "GRBM_GUI_ACTIVE" in pmc:
@@ -170,6 +170,26 @@ if pmc:
         lines.append(f"* f32: add {f32[0]/RAYS:.1f}, mul {f32[1]/RAYS:.1f}, fma {f32[2]/RAYS:.1f}, trans {f32[3]/RAYS:.2f}")
         lines.append(f"* int32 {pmc.get('SQ_INSTS_VALU_INT32',0)/RAYS:.1f}, int64 {pmc.get('SQ_INSTS_VALU_INT64',0)/RAYS:.1f}, "
                      f"cvt {pmc.get('SQ_INSTS_VALU_CVT',0)/RAYS:.1f}, LDS atomics {pmc.get('SQ_INSTS_LDS_ATOMIC',0)/RAYS:.2f}")
+        # Mix-aware issue bound: the 614.4 G/s "peak" charges every wave64 VALU instruction 4 cycles; on gfx950
+        # a 32-bit VALU instruction issues in 2 (MI355X_MICROARCH.md, cycle constants: v_fma_f32 2 cyc with several waves per
+        # SIMD), an f64 one in 4, and tools/ubench/inst_rate.hip measured v_mad_u64_u32 at ~7 and v_rcp_f64 / v_rsq_f64 at ~16.
+        # issue cycles per ray = sum over classes; whatever the class counters do not cover (moves, compares, selects, bit
+        # operations, lane permutes) is priced as 32-bit.
+        f32n = f32[0] + f32[1] + f32[2]
+        i64, cvt, i32 = pmc.get("SQ_INSTS_VALU_INT64", 0.0), pmc.get("SQ_INSTS_VALU_CVT", 0.0), pmc.get("SQ_INSTS_VALU_INT32", 0.0)
+        other = max(0.0, pmc["SQ_INSTS_VALU"] - (wave_insts + f32n + f32[3] + i64 + cvt + i32))
+        mix_cycles = 4.0 * (add + mul + fma) + 16.0 * trans + 2.0 * f32n + 4.0 * f32[3] + 7.0 * i64 + 4.0 * cvt + 2.0 * (i32 + other)
+        summ["issue_mix"] = {"cycles_per_ray": mix_cycles / RAYS, "uniform_4_cycles_per_ray": 4.0 * pmc["SQ_INSTS_VALU"] / RAYS,
+                             "unclassified_valu_per_ray": other / RAYS,
+                             "cycles": {"f64": 4, "f64_trans": 16, "f32_int32_other": 2, "f32_trans": 4, "int64_mad": 7, "cvt": 4}}
+        lines.append(f"* mix-aware issue cycles per ray = {mix_cycles/RAYS:.1f} (f64 4, f64 rcp/rsq 16, v_mad_u64_u32 7, cvt 4, f32 trans 4, every "
+                     f"other VALU instruction 2; {other/RAYS:.1f} unclassified per ray) against {4.0*pmc['SQ_INSTS_VALU']/RAYS:.1f} with 4 cycles for all")
+        if big:
+            t = sum(big) / len(big) * 1e-3
+            for label, clk in (("2.4 GHz", 2.4e9), ("the measured clock", summ.get("clock_ghz", 2.4) * 1e9)):
+                lines.append(f"  * fraction of the mix-aware issue peak at {label}: {mix_cycles / (1024 * clk * t):.3f}")
+            summ["issue_mix"]["frac_at_2p4GHz"] = mix_cycles / (1024 * 2.4e9 * t)
+            summ["issue_mix"]["frac_at_measured_clock"] = mix_cycles / (1024 * summ.get("clock_ghz", 2.4) * 1e9 * t)
         if big:
             tf = lane_flop / (sum(big) / len(big) * 1e-3) / 1e12
             summ["fp64_executed"]["tflops"] = tf
