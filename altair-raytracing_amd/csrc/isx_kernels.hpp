@@ -1632,7 +1632,10 @@ struct AssistQueues {   // LDS, one per workgroup
 };
 enum : uint32_t { IDO_SCATTERED = 0x80000000u, IDO_TARGET = 0x40000000u };   // Ray::ido flags in a queue record (offsets < 2^30)
 
-template <int CH, bool RESC>
+// DISC (the shared-ray physical-disc sweep, integratingSphereDetectorSweep.C:134-172 / SINK_DISC): the assist wave writes, for
+// EVERY ray that leaves for the world box, its forward exit segment -- start point, direction, length (8 doubles per slot) --
+// and isx_bin_discs_kernel tests the segments against the discs.
+template <int CH, bool RESC, bool DISC = false>
 __device__ __forceinline__ void assist_body(const Geom& g_arg, const DetGrid& d_arg, const Work& wk) {
   constexpr bool LEAN = true;
   extern __shared__ __align__(16) unsigned char smem[];
@@ -1886,7 +1889,7 @@ __device__ __forceinline__ void assist_body(const Geom& g_arg, const DetGrid& d_
           if (CH != 0 && r.tgt) chord_leave(r);
           V3 q;
           const int kind = next_hit_generic(g, r.p, r.v, r.on, q);
-          st = ray_arrive<false, LEAN, CH, PH_DIRECT>(h, g, r, seed, first, kind, q);
+          st = ray_arrive<DISC, LEAN, CH, PH_DIRECT>(h, g, r, seed, first, kind, q);   // (DISC: r.prev = start of this segment)
           if (RESC && st != 0 && h.source_model == 1 && !r.scattered()) {   // nonLambertianFlux.C:253-268
             n_wall += r.j;
             ray_rescatter(g, r, seed, first);
@@ -1935,10 +1938,11 @@ __device__ __forceinline__ void assist_body(const Geom& g_arg, const DetGrid& d_
       n_ended += c_ended;
       n_exited += (uint32_t)__popcll(__ballot(exited));
       n_susp += (uint32_t)__popcll(__ballot(have && st == ST_SUSPENDED));
-      const unsigned long long m = __ballot(below);
+      n_counted += (uint32_t)__popcll(__ballot(below));
+      const bool keep = DISC ? exited : below;                        // what goes to the binning kernel
+      const unsigned long long m = __ballot(keep);
       if (m) {
         const uint32_t cnt = (uint32_t)__popcll(m);
-        n_counted += cnt;
         if (cnt > reg_left) {   // close the open region, reserve the next one (kRegion)
           if (lane == 0 && reg_id != 0xffffffffu) d_arg.rec_counts[reg_id] = kRegion - reg_left;
           uint32_t id = 0;
@@ -1946,10 +1950,18 @@ __device__ __forceinline__ void assist_body(const Geom& g_arg, const DetGrid& d_
           reg_id = (uint32_t)__builtin_amdgcn_readfirstlane((int)id);
           reg_slot = 0; reg_left = kRegion;
         }
-        if (below) {
+        if (keep) {
           const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
-          double2* dst = reinterpret_cast<double2*>(d_arg.rec_lines + 6ull * ((uint64_t)reg_id * kRegion + (uint64_t)(reg_slot + rank)));
-          dst[0] = make_double2(r.p.x, r.p.y); dst[1] = make_double2(r.p.z, r.v.x); dst[2] = make_double2(r.v.y, r.v.z);
+          const uint64_t slot = (uint64_t)reg_id * kRegion + (uint64_t)(reg_slot + rank);
+          if (DISC) {   // forward exit segment: start, direction, length (bin_discs' own expression)
+            V3 dl; dl.x = r.p.x - r.prev.x; dl.y = r.p.y - r.prev.y; dl.z = r.p.z - r.prev.z;
+            double2* dst = reinterpret_cast<double2*>(d_arg.rec_lines + 8ull * slot);
+            dst[0] = make_double2(r.prev.x, r.prev.y); dst[1] = make_double2(r.prev.z, r.v.x); dst[2] = make_double2(r.v.y, r.v.z);
+            dst[3] = make_double2(dot3(dl, r.v), 0.0);
+          } else {
+            double2* dst = reinterpret_cast<double2*>(d_arg.rec_lines + 6ull * slot);
+            dst[0] = make_double2(r.p.x, r.p.y); dst[1] = make_double2(r.p.z, r.v.x); dst[2] = make_double2(r.v.y, r.v.z);
+          }
         }
         reg_slot += cnt; reg_left -= cnt;
       }
@@ -2020,6 +2032,65 @@ extern "C" __global__ void ISX_ASSIST_ATTR
 isx_trace_assist_chord_kernel(const Geom g, const DetGrid d, const Work wk) { assist_body<1, false>(g, d, wk); }
 extern "C" __global__ void ISX_ASSIST_ATTR
 isx_trace_assist_brdf_kernel(const Geom g, const DetGrid d, const Work wk) { assist_body<0, true>(g, d, wk); }
+extern "C" __global__ void ISX_ASSIST_ATTR
+isx_trace_assist_disc_kernel(const Geom g, const DetGrid d, const Work wk) { assist_body<0, false, true>(g, d, wk); }
+
+// ------------------------------------------------------------------ disc-binning kernel of the shared-ray disc sweep
+// Persistent waves take quarter regions of exit segments (isx_trace_assist_disc_kernel) off the launch's queue; lane = segment,
+// the discs one after the other (wave-uniform disc data: scalar loads), every segment against every disc with the test of
+// SINK_DISC (segment_hits_tube: bounding-ball cull, then the exact tube test).  SINK_DISC's "one exit at a time, lane = disc"
+// idled the wave while most discs were culled (VALU issue 0.70); here all 64 lanes run the 12-instruction cull, and the rare
+// lanes that pass it the exact test.  Same decisions, so the same counts.
+extern "C" __global__ void __launch_bounds__(512)
+isx_bin_discs_kernel(const DetGrid d_arg, const Work wk) {
+  extern __shared__ __align__(16) unsigned char smem[];
+  uint32_t* hist = reinterpret_cast<uint32_t*>(smem);
+  const int nbins = d_arg.nbins;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int nthr = (int)blockDim.x;
+  for (int b = tid; b < nbins; b += nthr) hist[b] = 0u;
+  __syncthreads();
+  const double* __restrict__ discs = d_arg.discs;
+  const double disc_r = d_arg.disc_r, disc_h = d_arg.disc_h;
+  const uint32_t n_regions = wk.ctr[Q_REGIONS];
+#pragma unroll 1
+  for (;;) {
+    uint32_t unit = 0;
+    if (lane == 0) unit = atomicAdd(&wk.ctr[Q_BIN], 1u);
+    unit = (uint32_t)__builtin_amdgcn_readfirstlane((int)unit);
+    const uint32_t region = unit >> 2;
+    if (region >= n_regions) break;
+    const uint32_t r_lines = (uint32_t)__builtin_amdgcn_readfirstlane((int)d_arg.rec_counts[region]);
+    const uint32_t q_first = (unit & 3u) * (kRegion / 4u);
+    const uint32_t n_lines = r_lines < q_first + kRegion / 4u ? r_lines : q_first + kRegion / 4u;
+    const double* rec = d_arg.rec_lines + 8ull * ((uint64_t)region * kRegion);
+#pragma unroll 1
+    for (uint32_t b0 = q_first; b0 < n_lines; b0 += 64u) {
+      const bool have = b0 + (uint32_t)lane < n_lines;
+      V3 P0, V;
+      P0.x = P0.y = P0.z = 0.0; V.x = V.y = 0.0; V.z = -1.0;
+      double tmax = 0.0;
+      if (have) {
+        const double2* src = reinterpret_cast<const double2*>(rec + 8ull * (b0 + (uint32_t)lane));
+        const double2 a = src[0], b = src[1], c = src[2], e = src[3];
+        P0.x = a.x; P0.y = a.y; P0.z = b.x; V.x = b.y; V.y = c.x; V.z = c.y; tmax = e.x;
+      }
+#pragma unroll 1
+      for (int k = 0; k < nbins; ++k) {
+        const bool hit = have && segment_hits_tube(P0, V, tmax, discs + 6 * (size_t)k, disc_r, disc_h);
+        const unsigned long long hm = __ballot(hit);
+        if (hm && lane == 0) atomicAdd(&hist[k], (uint32_t)__popcll(hm));   // (same bin for the whole wave: one LDS add)
+      }
+    }
+  }
+  __syncthreads();
+  unsigned long long flushed = 0;
+  for (int b = tid; b < nbins; b += nthr) {
+    const uint32_t c = hist[b];
+    if (c) { atomicAdd(&wk.hist[b], (unsigned long long)c); flushed += c; }
+  }
+  if (flushed) atomicAdd(&wk.stats[5], flushed);
+}
 
 // ------------------------------------------------------------------ binning kernel of the two-kernel pipeline
 // Persistent waves take the regions of exit lines the trace kernel filled (kRegion slots each, rec_counts[region] lines in

@@ -104,3 +104,37 @@ def test_overlapped_pipeline_option_is_bit_identical(isx):
             _same(st, rst)
     finally:
         _reset(isx)
+
+
+def test_disc_sweep_through_the_pipeline_is_bit_identical(isx, orc):
+    """isx_set_option("disc_pipeline", 1): the shared-ray disc sweep as assist-wave trace kernel -> exit segments in HBM ->
+    isx_bin_discs_kernel (lane = segment).  Same counts and census as the fused SINK_DISC kernel and as the oracle."""
+    def cfg(mod):
+        c = mod.default_config()
+        c.r_out = 105.0; c.reflectance = 1.0; c.roughness_rad = 0.0; c.max_points = 10000; c.box_half = 200.0; c.src[2] = -80
+        return c
+    ca = []
+    for theta in np.arange(-45, 45.01, 1.5):
+        for phi in (0.0, 180.0, 77.0):
+            t, p = np.deg2rad(theta), np.deg2rad(phi)
+            x, y, z = 200 * np.sin(t) * np.cos(p), 200 * np.sin(t) * np.sin(p), -200 * np.cos(t)
+            a = np.array([0 - x, 0 - y, -100 - z]); a /= np.linalg.norm(a)
+            ca.append([x, y, z, *a])
+    ca = np.array(ca)
+    try:
+        ref, rst = isx.disc_sweep(cfg(isx), ca, 5.0, 0.1, 400_000, 99)
+        isx.set_option("disc_pipeline", 1)
+        for grid, block in ((0, 768), (1, 256), (5, 512)):
+            isx.set_option("grid_blocks", grid); isx.set_option("assist_block", block)
+            h, st = isx.disc_sweep(cfg(isx), ca, 5.0, 0.1, 400_000, 99)
+            assert np.array_equal(h, ref), (grid, block)
+            _same(st, rst)
+        _reset(isx)
+        isx.set_option("disc_pipeline", 1)
+        gh, gst = isx.disc_sweep(cfg(isx), ca, 5.0, 0.1, 30000, 7)
+        oh, ost = orc.disc_sweep(cfg(orc), ca, 5.0, 0.1, 30000, 7)
+        assert np.array_equal(gh, oh)
+        _same(gst, ost)
+    finally:
+        isx.set_option("disc_pipeline", 0)
+        _reset(isx)
