@@ -50,11 +50,11 @@ typedef enum isx_status {
   ISX_ERR_BAD_ARG = -3,     /* null pointer, zero size ... */
   ISX_ERR_HIP = -4,         /* a HIP call failed; isx_last_hip_error() has the code */
   ISX_ERR_NOT_INIT = -5,
-  ISX_ERR_TOO_LARGE = -6    /* n_rays per call above ISX_MAX_RAYS_PER_CALL, or above 2^32-1 per workgroup */
+  ISX_ERR_TOO_LARGE = -6    /* n_rays per call above ISX_MAX_RAYS_PER_CALL (or records above ISX_MAX_LOG_RECORDS) */
 } isx_status;
 
-/* One launch may trace at most this many rays, and at most 2^32-1 per workgroup (32-bit LDS bins, 32-bit ray offsets):
- * with the default grid of one workgroup per CU that is ~1.1e12 rays on an MI355X.  Split larger jobs over calls.
+/* One call may trace at most this many rays (the library cuts a call into launches of at most 2^30 rays: a lane keeps a
+ * 31-bit offset from its launch's first ray, a workgroup counts in 32-bit LDS bins).  Split larger jobs over calls.
  * Ray indices are 64-bit; first_ray + n_rays must not exceed 2^64 - 1 (ISX_ERR_BAD_ARG). */
 #define ISX_MAX_RAYS_PER_CALL (1ull << 40)
 /* isx_exit_directions keeps at most this many 32-byte records per call (8 GiB of device memory) */
@@ -169,14 +169,24 @@ void* isx_stream(void);
  * launches, the trace kernel of the two-kernel flux-map pipeline, its binning kernel.  Any pointer may be NULL. */
 int isx_last_kernel_ms(double* single_ms, double* trace_ms, double* bin_ms);
 
-/* Tuning/diagnostic switches.  "bin_mode": 1 (default) culled + classified binning,
- * 0 brute-force reference-order test of every detector position; "blocks_per_cu";
- * "grid_blocks" (0 = auto); "pipeline" 1 (default): the lean flux maps (headline, chord mode, BRDF source) run as two kernels -- a trace kernel writes
- * the exit lines (48 B per counted ray) to an HBM workspace, a binning kernel reads them ("pipeline_chunk" = rays per pair,
- * default 2^26 = at most 3.2 GB of workspace) -- 0: one fused trace+bin kernel; "sched_mask", "sched_min": batching of the
- * generic boundary search (every (mask+1)-th loop trip or when `min` lanes wait); "trace_block" (256/512/1024, default 512) and
- * "trace_blocks_per_cu" (1..32, default 8): workgroup size and workgroups per CU in the grid of the kernels that keep no LDS
- * histogram.  None of them changes any result. */
+/* Tuning/diagnostic switches.  None of them changes any result (a ray's history is a function of seed and index).
+ *   "bin_mode"     1 (default) culled + classified binning, 0 brute-force reference-order test of every detector position
+ *   "pipeline"     1 (default): the lean flux maps (headline, chord mode, BRDF source) run as two kernels -- a trace kernel
+ *                  writes the exit lines (48 B per counted ray) to an HBM workspace, a binning kernel reads them; 0: one fused kernel
+ *   "pipeline_chunk"  rays per trace / binning pair, default and maximum 2^26.  WORKSPACE: exit lines live in regions of 1024
+ *                  slots; a chunk of n rays traced by W waves is given n/961 + W + 1 regions of 48 KB (3.4 GB for 2^26 rays),
+ *                  allocated once and kept until isx_shutdown(); "overlap" keeps three of them
+ *   "assist"       1 (default): trace kernels with an assist wave per workgroup; 0: round 2's kernels;
+ *                  "assist_block" = their workgroup size (128..768, default 768 = 11 tracer waves + 1 assist wave)
+ *   "bin_slots"    1 (default): binning kernel with slot queues by window length (grids up to 256 x 255); 0: round 2's
+ *   "bin_block", "bin_blocks_per_cu"  shape of round 2's binning kernel (0 workgroups per CU = what is resident)
+ *   "ray_sub"      rays a wave takes off a launch's ray queue at a time (0 = default: 512, 256 for small launches)
+ *   "overlap", "overlap_trace_streams"  cut a flux-map call into k chunks, binning of chunk i on a second stream while chunk
+ *                  i+1 is traced (measured slower on MI355X, default 0)
+ *   "disc_pipeline"  1: the shared-ray disc sweep as trace kernel + disc-binning kernel (default 0: fused kernel)
+ *   "blocks_per_cu", "grid_blocks" (0 = auto), "trace_block" (64..1024, default 512), "trace_blocks_per_cu" (0 = resident)
+ *                  launch shapes; "sched_mask", "sched_min": batching of the generic boundary search in the kernels without
+ *                  an assist wave (every (mask+1)-th loop trip or when `min` lanes wait). */
 int isx_set_option(const char* key, int64_t value);
 
 /* Device-side probe of the numeric contract (tests): out[i] = op(a[i],b[i],c[i]) with
