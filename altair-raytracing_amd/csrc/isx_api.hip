@@ -58,7 +58,7 @@ struct State {
   int ray_sub = 0;                        // rays a wave takes off the queue at a time (0: by launch size)
   int bin_block = 512, bin_blocks_per_cu = 0;   // binning kernel: workgroup size, workgroups per CU in the grid (0: what is resident)
   int assist_block = ISX_ASSIST_BLOCK;          // its workgroup size: (assist_block / 64 - 1) tracer waves + 1 assist wave
-  int disc_pipeline = 0;                        // 1: the shared-ray disc sweep as assist-wave trace kernel + isx_bin_discs_kernel (measured: 13.3 vs 12.3 ms fused)
+  int disc_pipeline = 1;                        // 1 (default): the shared-ray disc sweep as assist-wave trace kernel + isx_bin_discs_kernel; 0: fused SINK_DISC kernel
   int assist = 1;                               // 1: trace kernels with an assist wave per workgroup (assist_body)
   int bin_slots = 1;                            // 1: isx_bin_slots_kernel (slot queues by window length) where the grid allows it
   // options
@@ -282,6 +282,8 @@ int next_ctr(uint32_t** ctr) {
 constexpr uint64_t kLaunchMax = 1ull << 30;
 
 int ensure_pipeline(size_t rays, size_t waves, int buf = 0, size_t slot_doubles = 6);
+// the disc list of the current isx_disc_sweep call as isx_bin_discs_kernel wants it (upload_discs_clustered below)
+struct DiscClusters { size_t n = 0, off_ordered = 0, off_clusters = 0, off_perm = 0; int n_clusters = 0; } g_disc_clusters;
 
 // enqueue one persistent kernel accumulating into d_hist (device) and S.d_stats
 struct PerPos { uint64_t map_first = 0, rays_per_group = 0; int fold = 1; const double* d_table = nullptr; double width = 0; };
@@ -495,10 +497,12 @@ int enqueue(int sink, const isx_config* c, uint64_t n, uint64_t seed, uint64_t f
   }
   // ---- the shared-ray disc sweep as a pipeline as well: assist-wave trace kernel -> exit segments in HBM (8 doubles each) ->
   // disc-binning kernel (lane = segment, the discs one after the other)
-  if (sink == SINK_DISC && lean_explicit && S.pipeline && S.assist && S.disc_pipeline) {
+  if (sink == SINK_DISC && lean_explicit && S.pipeline && S.assist && S.disc_pipeline && g_disc_clusters.n == (size_t)d.nbins &&
+      d_discs == S.d_aux) {
     const int pblock = S.assist_block, bblock = 512;
     const size_t lds_trace = 16 + 64 + sizeof(Geom) + sizeof(DetGrid) + 16 + sizeof(AssistQueues) + (size_t)(kResumeCap + kPendCap) * 64;
-    const size_t lds_bin = ((size_t)d.nbins * 4 + 15) & ~(size_t)15;
+    const size_t lds_bin = (((size_t)d.nbins * 4 + 15) & ~(size_t)15) + (size_t)(bblock / 64) * (64 * 7 + kPairCap / 2) * sizeof(double);
+    if (lds_bin > S.lds_limit) return ISX_ERR_BAD_CONFIG;
     const KernelFn rec_fn = isx_trace_assist_disc_kernel;
     if (S.attr_lds[(const void*)rec_fn] != lds_trace) {
       HIPCHK(hipFuncSetAttribute((const void*)rec_fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_trace));
@@ -520,6 +524,10 @@ int enqueue(int sink, const isx_config* c, uint64_t n, uint64_t seed, uint64_t f
       rc = next_ctr(&w2.ctr); if (rc) return rc;
       DetGrid dt = d;
       dt.rec_lines = S.d_rec[0]; dt.rec_counts = S.d_rec_counts[0];
+      dt.discs = S.d_aux + g_disc_clusters.off_ordered;              // (the binning kernel walks the discs in cluster order)
+      dt.clusters = reinterpret_cast<const float*>(S.d_aux + g_disc_clusters.off_clusters);
+      dt.disc_perm = reinterpret_cast<const int*>(S.d_aux + g_disc_clusters.off_perm);
+      dt.n_clusters = g_disc_clusters.n_clusters;
       hipLaunchKernelGGL(rec_fn, dim3(pick_grid(cnt, pblock, tres)), dim3(pblock), lds_trace, S.stream, g, dt, w2);
       HIPCHK(hipGetLastError());
       rc = span(1, nullptr); if (rc) return rc;
@@ -560,6 +568,63 @@ int upload_aux(const double* host, size_t n_doubles) {
   }
   HIPCHK(hipMemcpyAsync(S.d_aux, host, n_doubles * sizeof(double), hipMemcpyHostToDevice, S.stream));
   HIPCHK(hipStreamSynchronize(S.stream));   // `host` may be a temporary of the caller
+  return ISX_OK;
+}
+
+// The disc list of isx_disc_sweep for isx_bin_discs_kernel: the discs in spatial (Morton) order, eight to a cluster, with the ball
+// that holds the bounding balls of a cluster's discs.  Device layout behind the caller's own list (6 n doubles) in the pooled
+// aux buffer: ordered discs (6 n doubles) | clusters (4 floats each) | permutation (n ints).
+
+int upload_discs_clustered(const double* ca, size_t n, double radius, double half_thick) {
+  g_disc_clusters = DiscClusters();
+  double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300};
+  for (size_t k = 0; k < n; ++k)
+    for (int a = 0; a < 3; ++a) { lo[a] = std::min(lo[a], ca[6 * k + a]); hi[a] = std::max(hi[a], ca[6 * k + a]); }
+  std::vector<std::pair<uint32_t, int>> order(n);
+  for (size_t k = 0; k < n; ++k) {
+    uint32_t code = 0;
+    for (int a = 0; a < 3; ++a) {
+      const double span = hi[a] - lo[a];
+      uint32_t q = span > 0 ? (uint32_t)std::min(1023.0, std::floor((ca[6 * k + a] - lo[a]) / span * 1024.0)) : 0u;
+      for (int bit = 0; bit < 10; ++bit) code |= ((q >> bit) & 1u) << (3 * bit + a);   // Morton interleave
+    }
+    order[k] = {code, (int)k};
+  }
+  std::stable_sort(order.begin(), order.end());
+  const size_t ncl = (n + 7) / 8;
+  std::vector<double> ordered(6 * n);
+  std::vector<float> clusters(4 * ncl);
+  std::vector<int> perm(n);
+  const double ball = std::sqrt(radius * radius + half_thick * half_thick);
+  for (size_t j = 0; j < n; ++j) {
+    perm[j] = order[j].second;
+    std::memcpy(&ordered[6 * j], ca + 6 * (size_t)perm[j], 6 * sizeof(double));
+  }
+  for (size_t c = 0; c < ncl; ++c) {
+    const size_t j0 = 8 * c, j1 = std::min(n, j0 + 8);
+    double ctr[3] = {0, 0, 0};
+    for (size_t j = j0; j < j1; ++j)
+      for (int a = 0; a < 3; ++a) ctr[a] += ordered[6 * j + a] / (double)(j1 - j0);
+    float cf[3] = {(float)ctr[0], (float)ctr[1], (float)ctr[2]};
+    double r = 0;
+    for (size_t j = j0; j < j1; ++j) {   // against the ROUNDED centre the kernel will use
+      const double dx = ordered[6 * j] - (double)cf[0], dy = ordered[6 * j + 1] - (double)cf[1], dz = ordered[6 * j + 2] - (double)cf[2];
+      r = std::max(r, std::sqrt(dx * dx + dy * dy + dz * dz));
+    }
+    clusters[4 * c + 0] = cf[0]; clusters[4 * c + 1] = cf[1]; clusters[4 * c + 2] = cf[2];
+    clusters[4 * c + 3] = std::nextafter((float)((r + ball) * (1.0 + 1e-6)), INFINITY);
+  }
+  const size_t off_ordered = 6 * n, off_clusters = 12 * n, off_perm = off_clusters + 2 * ncl;
+  const size_t total = off_perm + (n + 1) / 2 + 1;
+  std::vector<double> blob(total, 0.0);
+  std::memcpy(blob.data(), ca, 6 * n * sizeof(double));
+  std::memcpy(blob.data() + off_ordered, ordered.data(), 6 * n * sizeof(double));
+  std::memcpy(blob.data() + off_clusters, clusters.data(), clusters.size() * sizeof(float));
+  std::memcpy(blob.data() + off_perm, perm.data(), n * sizeof(int));
+  const int rc = upload_aux(blob.data(), total);
+  if (rc) return rc;
+  g_disc_clusters.n = n; g_disc_clusters.off_ordered = off_ordered; g_disc_clusters.off_clusters = off_clusters;
+  g_disc_clusters.off_perm = off_perm; g_disc_clusters.n_clusters = (int)ncl;
   return ISX_OK;
 }
 
@@ -862,7 +927,8 @@ int isx_disc_sweep(const isx_config* cfg, const double* centers_axes, int32_t n_
   if (rc) return rc;
   rc = collect_stats(nullptr);
   if (rc) return rc;
-  rc = upload_aux(centers_axes, (size_t)n_disc * 6);
+  g_disc_clusters = DiscClusters();
+  rc = S.disc_pipeline ? upload_discs_clustered(centers_axes, (size_t)n_disc, radius, half_thick) : upload_aux(centers_axes, (size_t)n_disc * 6);
   if (rc) return rc;
   HIPCHK(hipMemsetAsync(S.d_hist, 0, (size_t)n_disc * sizeof(unsigned long long), S.stream));
   rc = enqueue(SINK_DISC, cfg, n_rays, seed, first_ray, S.d_hist, n_disc, S.d_aux, radius, half_thick);

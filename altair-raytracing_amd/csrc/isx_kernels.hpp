@@ -34,6 +34,12 @@ struct DetGrid {
   // SINK_DISC: physical discs (integratingSphereDetectorSweep.C:145-172); nbins == n_disc
   const double* discs;                  // [n_disc][6] centre, unit axis
   double disc_r, disc_h;
+  // isx_bin_discs_kernel: the discs in spatial order, eight to a cluster -- clusters[k] = centre and radius of a ball that
+  // holds the bounding balls of discs 8k..8k+7 of that order (binary32, radius rounded up), disc_perm[j] = the caller's index of
+  // the j-th disc of that order (host: cluster_discs, isx_api.hip)
+  const float* clusters;                // [n_clusters][4]
+  const int* disc_perm;                 // [n_disc]
+  int n_clusters, pad1;
   // SINK_DISCPOS: the reference's physical-disc loop as it is written (integratingSphereDetectorSweep.C:54-77): disc g
   // sees only its own rays [map_first + g*rays_per_group, +rays_per_group) -- one launch for all positions.
   // SINK_PERPOS: the reference's per-position maps (fluxAtObserverOptimize.C:542-579): rays
@@ -2036,11 +2042,15 @@ extern "C" __global__ void ISX_ASSIST_ATTR
 isx_trace_assist_disc_kernel(const Geom g, const DetGrid d, const Work wk) { assist_body<0, false, true>(g, d, wk); }
 
 // ------------------------------------------------------------------ disc-binning kernel of the shared-ray disc sweep
-// Persistent waves take quarter regions of exit segments (isx_trace_assist_disc_kernel) off the launch's queue; lane = segment,
-// the discs one after the other (wave-uniform disc data: scalar loads), every segment against every disc with the test of
-// SINK_DISC (segment_hits_tube: bounding-ball cull, then the exact tube test).  SINK_DISC's "one exit at a time, lane = disc"
-// idled the wave while most discs were culled (VALU issue 0.70); here all 64 lanes run the 12-instruction cull, and the rare
-// lanes that pass it the exact test.  Same decisions, so the same counts.
+// Persistent waves take quarter regions of exit segments (isx_trace_assist_disc_kernel) off the launch's queue, 64 segments at a
+// time.  SINK_DISC tested every exit against every disc ("one exit at a time, lane = disc": VALU issue 0.70, most lanes culled);
+// here, per batch:
+//   1. lane = segment: the line of the segment against the ball of every CLUSTER of eight neighbouring discs (binary32, with a
+//      margin that covers its rounding: never drops a hit); a (segment, cluster) pair that passes goes to a wave-private list;
+//   2. lane = (pair, disc of the cluster): the exact test of SINK_DISC (segment_hits_tube: bounding-ball cull in binary64, then
+//      the tube) on the segment read back from wave-private LDS; a hit increments the disc's bin.
+// ~100 pairs per batch instead of 64 x 362 tests.  Same decisions, so the same counts.
+constexpr int kPairCap = 1024;
 extern "C" __global__ void __launch_bounds__(512)
 isx_bin_discs_kernel(const DetGrid d_arg, const Work wk) {
   extern __shared__ __align__(16) unsigned char smem[];
@@ -2048,11 +2058,34 @@ isx_bin_discs_kernel(const DetGrid d_arg, const Work wk) {
   const int nbins = d_arg.nbins;
   const int tid = threadIdx.x, lane = tid & 63;
   const int nthr = (int)blockDim.x;
+  // per wave: the batch's 64 segments (7 doubles each) and the pair list
+  double* seg = reinterpret_cast<double*>(smem + (((size_t)nbins * 4 + 15) & ~(size_t)15)) + (size_t)(tid >> 6) * (64 * 7 + kPairCap / 2);
+  uint32_t* pairs = reinterpret_cast<uint32_t*>(seg + 64 * 7);
   for (int b = tid; b < nbins; b += nthr) hist[b] = 0u;
   __syncthreads();
   const double* __restrict__ discs = d_arg.discs;
+  const float4* __restrict__ clusters = reinterpret_cast<const float4*>(d_arg.clusters);
+  const int* __restrict__ perm = d_arg.disc_perm;
+  const int n_clusters = d_arg.n_clusters;
   const double disc_r = d_arg.disc_r, disc_h = d_arg.disc_h;
   const uint32_t n_regions = wk.ctr[Q_REGIONS];
+  // phase 2: the exact test for every (pair, disc of its cluster), 64 at a time
+  auto flush = [&](int n_pairs) {
+#pragma unroll 1
+    for (int base = 0; base < n_pairs * 8; base += 64) {
+      const int item = base + lane;
+      const uint32_t pr = item < n_pairs * 8 ? reinterpret_cast<volatile uint32_t*>(pairs)[item >> 3] : 0u;
+      const int j = (int)(pr >> 8) * 8 + (item & 7);                 // disc in spatial order
+      bool hit = false;
+      if (item < n_pairs * 8 && j < nbins) {
+        const volatile double* sp = seg + 7 * (int)(pr & 63u);
+        V3 P0, V;
+        P0.x = sp[0]; P0.y = sp[1]; P0.z = sp[2]; V.x = sp[3]; V.y = sp[4]; V.z = sp[5];
+        hit = segment_hits_tube(P0, V, sp[6], discs + 6 * (size_t)j, disc_r, disc_h);
+      }
+      if (hit) atomicAdd(&hist[perm[j]], 1u);
+    }
+  };
 #pragma unroll 1
   for (;;) {
     uint32_t unit = 0;
@@ -2067,20 +2100,39 @@ isx_bin_discs_kernel(const DetGrid d_arg, const Work wk) {
 #pragma unroll 1
     for (uint32_t b0 = q_first; b0 < n_lines; b0 += 64u) {
       const bool have = b0 + (uint32_t)lane < n_lines;
-      V3 P0, V;
-      P0.x = P0.y = P0.z = 0.0; V.x = V.y = 0.0; V.z = -1.0;
-      double tmax = 0.0;
+      float px = 0.f, py = 0.f, pz = 0.f, vx = 0.f, vy = 0.f, vz = -1.f;
       if (have) {
         const double2* src = reinterpret_cast<const double2*>(rec + 8ull * (b0 + (uint32_t)lane));
         const double2 a = src[0], b = src[1], c = src[2], e = src[3];
-        P0.x = a.x; P0.y = a.y; P0.z = b.x; V.x = b.y; V.y = c.x; V.z = c.y; tmax = e.x;
+        volatile double* sp = seg + 7 * lane;
+        sp[0] = a.x; sp[1] = a.y; sp[2] = b.x; sp[3] = b.y; sp[4] = c.x; sp[5] = c.y; sp[6] = e.x;
+        px = (float)a.x; py = (float)a.y; pz = (float)b.x; vx = (float)b.y; vy = (float)c.x; vz = (float)c.y;
       }
+      __builtin_amdgcn_wave_barrier();
+      const float vv = fmaf(vx, vx, fmaf(vy, vy, vz * vz));
+      int n_pairs = 0;                                               // wave-uniform
 #pragma unroll 1
-      for (int k = 0; k < nbins; ++k) {
-        const bool hit = have && segment_hits_tube(P0, V, tmax, discs + 6 * (size_t)k, disc_r, disc_h);
-        const unsigned long long hm = __ballot(hit);
-        if (hm && lane == 0) atomicAdd(&hist[k], (uint32_t)__popcll(hm));   // (same bin for the whole wave: one LDS add)
+      for (int k = 0; k < n_clusters; ++k) {
+        const float4 c = clusters[k];                                // (same address in every lane: a scalar load)
+        const float wx = px - c.x, wy = py - c.y, wz = pz - c.z;
+        const float wv = fmaf(wx, vx, fmaf(wy, vy, wz * vz)), ww = fmaf(wx, wx, fmaf(wy, wy, wz * wz));
+        // line-to-centre distance^2 * vv = ww vv - wv^2 against R^2 vv, with 0.2 % on the radius^2 and 4e-6 of the two
+        // cancelling terms for the binary32 rounding of inputs and products (2e-6 of them by the count of roundings)
+        const float lhs = fmaf(ww, vv, -(wv * wv)), rhs = fmaf(c.w * c.w * 1.002f, vv, 4e-6f * fmaf(ww, vv, wv * wv));
+        const bool near = have && !(lhs > rhs);
+        const unsigned long long nm = __ballot(near);
+        if (nm) {
+          if (near) {
+            const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(nm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)nm, 0u));
+            reinterpret_cast<volatile uint32_t*>(pairs)[n_pairs + (int)rank] = (uint32_t)lane | ((uint32_t)k << 8);
+          }
+          n_pairs += (int)__popcll(nm);
+          if (n_pairs > kPairCap - 64) { __builtin_amdgcn_wave_barrier(); flush(n_pairs); n_pairs = 0; }
+        }
       }
+      __builtin_amdgcn_wave_barrier();
+      flush(n_pairs);
+      __builtin_amdgcn_wave_barrier();
     }
   }
   __syncthreads();

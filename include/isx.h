@@ -183,7 +183,8 @@ int isx_last_kernel_ms(double* single_ms, double* trace_ms, double* bin_ms);
  *   "ray_sub"      rays a wave takes off a launch's ray queue at a time (0 = default: 512, 256 for small launches)
  *   "overlap", "overlap_trace_streams"  cut a flux-map call into k chunks, binning of chunk i on a second stream while chunk
  *                  i+1 is traced (measured slower on MI355X, default 0)
- *   "disc_pipeline"  1: the shared-ray disc sweep as trace kernel + disc-binning kernel (default 0: fused kernel)
+ *   "disc_pipeline"  1 (default): the shared-ray disc sweep as trace kernel + disc-binning kernel (discs clustered by eight on the
+ *                  host, exit segments in HBM); 0: one fused kernel
  *   "blocks_per_cu", "grid_blocks" (0 = auto), "trace_block" (64..1024, default 512), "trace_blocks_per_cu" (0 = resident)
  *                  launch shapes; "sched_mask", "sched_min": batching of the generic boundary search in the kernels without
  *                  an assist wave (every (mask+1)-th loop trip or when `min` lanes wait). */

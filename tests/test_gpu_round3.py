@@ -107,8 +107,9 @@ def test_overlapped_pipeline_option_is_bit_identical(isx):
 
 
 def test_disc_sweep_through_the_pipeline_is_bit_identical(isx, orc):
-    """isx_set_option("disc_pipeline", 1): the shared-ray disc sweep as assist-wave trace kernel -> exit segments in HBM ->
-    isx_bin_discs_kernel (lane = segment).  Same counts and census as the fused SINK_DISC kernel and as the oracle."""
+    """The shared-ray disc sweep as assist-wave trace kernel -> exit segments in HBM -> isx_bin_discs_kernel (clusters of eight
+    discs, binary32 ball cull per (segment, cluster), exact test per (pair, disc)); "disc_pipeline" = 0 is the fused SINK_DISC
+    kernel.  Same counts and census from both and from the oracle."""
     def cfg(mod):
         c = mod.default_config()
         c.r_out = 105.0; c.reflectance = 1.0; c.roughness_rad = 0.0; c.max_points = 10000; c.box_half = 200.0; c.src[2] = -80
@@ -122,6 +123,7 @@ def test_disc_sweep_through_the_pipeline_is_bit_identical(isx, orc):
             ca.append([x, y, z, *a])
     ca = np.array(ca)
     try:
+        isx.set_option("disc_pipeline", 0)
         ref, rst = isx.disc_sweep(cfg(isx), ca, 5.0, 0.1, 400_000, 99)
         isx.set_option("disc_pipeline", 1)
         for grid, block in ((0, 768), (1, 256), (5, 512)):
@@ -136,5 +138,5 @@ def test_disc_sweep_through_the_pipeline_is_bit_identical(isx, orc):
         assert np.array_equal(gh, oh)
         _same(gst, ost)
     finally:
-        isx.set_option("disc_pipeline", 0)
+        isx.set_option("disc_pipeline", 1)
         _reset(isx)

@@ -9,6 +9,7 @@ import altair_raytracing_amd as isx
 import oracle as orc
 isx.load(); isx.init(0)
 NS = int(sys.argv[1]) if len(sys.argv) > 1 else 100
+if os.environ.get("ISX_DISC_PIPELINE"): isx.set_option("disc_pipeline", int(os.environ["ISX_DISC_PIPELINE"]))   # the pipeline form of the shared-ray sweep
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 99)
 bad = 0
 for k in range(NS):
