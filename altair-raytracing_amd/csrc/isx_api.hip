@@ -501,7 +501,9 @@ int enqueue(int sink, const isx_config* c, uint64_t n, uint64_t seed, uint64_t f
       d_discs == S.d_aux) {
     const int pblock = S.assist_block, bblock = 512;
     const size_t lds_trace = 16 + 64 + sizeof(Geom) + sizeof(DetGrid) + 16 + sizeof(AssistQueues) + (size_t)(kResumeCap + kPendCap) * 64;
-    const size_t lds_bin = (((size_t)d.nbins * 4 + 15) & ~(size_t)15) + (size_t)(bblock / 64) * (64 * 7 + kPairCap / 2) * sizeof(double);
+    const size_t lds_bin = (((size_t)d.nbins * 4 + 15) & ~(size_t)15) + (size_t)g_disc_clusters.n_clusters * 16 +
+                           (d.nbins <= kDiscsInLds ? (size_t)d.nbins * 48 + (size_t)((d.nbins + 1) & ~1) * 4 : 0) +
+                           (size_t)(bblock / 64) * (64 * 7 + kPairCap / 2) * sizeof(double);
     if (lds_bin > S.lds_limit) return ISX_ERR_BAD_CONFIG;
     const KernelFn rec_fn = isx_trace_assist_disc_kernel;
     if (S.attr_lds[(const void*)rec_fn] != lds_trace) {

@@ -173,6 +173,11 @@ struct __align__(16) ColX {
   uint32_t pad;
 };
 
+// (LDS-typed pointers: a volatile access through a GENERIC pointer compiles to flat_load / flat_store with system scope, which
+//  a wave waits on for hundreds of cycles; through these it is a ds_read / ds_write)
+typedef __attribute__((address_space(3))) uint32_t LdsWord;
+typedef __attribute__((address_space(3))) int LdsInt;
+
 // acos in f32 for |x| <= 1, |error| < 1e-4 rad (Abramowitz & Stegun 4.4.45 on |x|, reflected for x < 0;
 // restated in numpy and checked in tests/test_cull_math.py)
 __device__ __forceinline__ float acos_cull(float x) {
@@ -508,7 +513,7 @@ constexpr int MODE_CAP = 1, MODE_BOX = 2;
 template <int MODE, class D>
 __device__ __forceinline__ void walk_rows(const D& d, uint32_t* __restrict__ hist, const double* __restrict__ rowt,
                                           const ColX* __restrict__ colx, const V3& P, const V3& V, int lane, int ilo,
-                                          int ihi, const CapWin& w, const BoxLine& bx, int* split, int path) {
+                                          int ihi, const CapWin& w, const BoxLine& bx, LdsInt* split, int path) {
   // parameter of the point of the line nearest to O = (0,0,portz), the centre of the detector sphere (walk_columns)
   const double t0 = -fma(P.x, V.x, fma(P.y, V.y, (P.z - d.portz) * V.z));
 #pragma unroll 1
@@ -525,7 +530,7 @@ __device__ __forceinline__ void walk_rows(const D& d, uint32_t* __restrict__ his
           const int slot = lane >> logq;
           part = lane & ((1 << logq) - 1);
           have = slot < nlong;
-          i = have ? reinterpret_cast<volatile int*>(split)[slot] : 0;
+          i = have ? ((volatile LdsInt*)split)[slot] : 0;
         }
         int jlo = 0, cnt = 0;
         bool second = false;
@@ -555,7 +560,7 @@ __device__ __forceinline__ void walk_rows(const D& d, uint32_t* __restrict__ his
               npass = 2;
               if (cnt > kSplitAt) {
                 const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(lm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)lm, 0u));
-                reinterpret_cast<volatile int*>(split)[rank] = i;
+                ((volatile LdsInt*)split)[rank] = i;
                 len = kSplitAt;
               }
               __builtin_amdgcn_wave_barrier();
@@ -629,7 +634,7 @@ __device__ __forceinline__ RecPre prep_record(const GridConst& k, const V3& P, c
 template <bool CAPS_TOO, class DG>
 __device__ inline void bin_culled(const DG& dd, uint32_t* __restrict__ hist,
                                       const double* __restrict__ rowt, const ColX* __restrict__ colx,
-                                      const V3 P, const V3 V, int lane, int* split) {
+                                      const V3 P, const V3 V, int lane, LdsInt* split) {
   // one read of each constant (dd is a volatile LDS copy: nothing of it lives in SGPRs across the trace loop)
   struct { int n_theta, n_phi; double half_w2, rho_d, R, portz; const double* table; } d;
   d.n_theta = dd.n_theta; d.n_phi = dd.n_phi; d.half_w2 = dd.half_w2; d.rho_d = dd.rho_d; d.R = dd.R;
@@ -713,7 +718,7 @@ template <class D>
 __device__ __forceinline__ void walk_lines_packed(const D& d, uint32_t* __restrict__ hist, const double* __restrict__ rowt,
                                                   const ColX* __restrict__ colx, const double* __restrict__ lines,
                                                   const RecPre& pre, int nrow, int excl, int incl, int total, float inv_dphi,
-                                                  int lane, int* mark, int* split) {
+                                                  int lane, LdsInt* mark, LdsInt* split) {
 #pragma unroll 1
   for (int base = 0; base < total; base += 64) {
     int npass = 1, logq = 0, nlong = 0;
@@ -724,7 +729,7 @@ __device__ __forceinline__ void walk_lines_packed(const D& d, uint32_t* __restri
       if (pass == 0) {
         const int g = base + lane;
         have = g < total;
-        volatile int* mk = mark;
+        volatile LdsInt* mk = mark;
         mk[lane] = 0;
         __builtin_amdgcn_wave_barrier();
         if (nrow > 0 && excl < base + 64 && incl > base) mk[(excl > base ? excl : base) - base] = lane + 1;
@@ -740,7 +745,7 @@ __device__ __forceinline__ void walk_lines_packed(const D& d, uint32_t* __restri
         const int slot = lane >> logq;
         part = lane & ((1 << logq) - 1);
         have = slot < nlong;
-        const int e = have ? reinterpret_cast<volatile int*>(split)[slot] : 0;
+        const int e = have ? ((volatile LdsInt*)split)[slot] : 0;
         owner = e & 63;
         i = e >> 8;
       }
@@ -768,7 +773,7 @@ __device__ __forceinline__ void walk_lines_packed(const D& d, uint32_t* __restri
             npass = 2;
             if (cnt > kSplitAt) {
               const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(lm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)lm, 0u));
-              reinterpret_cast<volatile int*>(split)[rank] = owner | (i << 8);
+              ((volatile LdsInt*)split)[rank] = owner | (i << 8);
               len = kSplitAt;
             }
             __builtin_amdgcn_wave_barrier();
@@ -802,9 +807,9 @@ constexpr int kClasses = 7, kQueueCap = 128;   // a class never holds more than 
 constexpr int kSlotWaveWords = kClasses * kQueueCap + 16 + 64;   // LDS words per wave: queues, counters, owner marks
 constexpr int kPiece = 16, kLongest = 24;
 struct SlotQueues {
-  uint32_t* q;        // [kClasses][kQueueCap]
-  int* tail;          // [8] slots pushed per class (running)
-  int* head;          // [8] slots popped per class (running)
+  LdsWord* q;         // [kClasses][kQueueCap]
+  LdsInt* tail;       // [8] slots pushed per class (running)
+  LdsInt* head;       // [8] slots popped per class (running)
 };
 __device__ __forceinline__ int slot_class(int cnt) {   // cnt in 1..kLongest
   return cnt <= 4 ? 0 : (cnt <= 12 ? (cnt - 3) >> 1 : (cnt <= 16 ? 5 : 6));
@@ -836,8 +841,8 @@ template <class D>
 __device__ __forceinline__ void drain_slots(const D& d, uint32_t* __restrict__ hist, const double* __restrict__ rowt,
                                             const ColX* __restrict__ colx, const double* __restrict__ lines,
                                             const SlotQueues& sq, int least, int lane) {
-  volatile int* tl = sq.tail;
-  volatile int* hd = sq.head;
+  volatile LdsInt* tl = sq.tail;
+  volatile LdsInt* hd = sq.head;
   const int held = lane < kClasses ? tl[lane] - hd[lane] : 0;
   unsigned long long m = __ballot(held >= least);
   while (m) {
@@ -845,7 +850,7 @@ __device__ __forceinline__ void drain_slots(const D& d, uint32_t* __restrict__ h
     m &= m - 1ull;
     const int h = hd[c], n = tl[c] - h;          // (same address in every lane: wave-uniform)
     const int take = n < 64 ? n : 64;
-    const uint32_t rec = lane < take ? reinterpret_cast<volatile uint32_t*>(sq.q)[c * kQueueCap + ((h + lane) & (kQueueCap - 1))] : 0u;
+    const uint32_t rec = lane < take ? ((volatile LdsWord*)sq.q)[c * kQueueCap + ((h + lane) & (kQueueCap - 1))] : 0u;
     __builtin_amdgcn_wave_barrier();
     if (lane == 0) hd[c] = h + take;
     __builtin_amdgcn_wave_barrier();
@@ -866,7 +871,7 @@ __device__ __forceinline__ void push_slots(const D& d, uint32_t* __restrict__ hi
     if (piece > 0) {
       const int c = slot_class(piece);
       const int pos = __hip_atomic_fetch_add(sq.tail + c, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-      reinterpret_cast<volatile uint32_t*>(sq.q)[c * kQueueCap + (pos & (kQueueCap - 1))] =
+      ((volatile LdsWord*)sq.q)[c * kQueueCap + (pos & (kQueueCap - 1))] =
           (uint32_t)line | ((uint32_t)i << 8) | ((uint32_t)j << 16) | ((uint32_t)piece << 24);
       ISX_DIAG_ADD_LANES(7, piece);
     }
@@ -970,12 +975,12 @@ template <class D>
 __device__ __forceinline__ void produce_packed(const D& d, uint32_t* __restrict__ hist, const double* __restrict__ rowt,
                                                const ColX* __restrict__ colx, const double* __restrict__ lines, const SlotQueues& sq,
                                                const RecPre& pre, int nrow, int excl, int incl, int total, float inv_dphi,
-                                               int first_line, int lane, int* mark) {
+                                               int first_line, int lane, LdsInt* mark) {
 #pragma unroll 1
   for (int base = 0; base < total; base += 64) {
     const int g = base + lane;
     bool have = g < total;
-    volatile int* mk = mark;
+    volatile LdsInt* mk = mark;
     mk[lane] = 0;
     __builtin_amdgcn_wave_barrier();
     if (nrow > 0 && excl < base + 64 && incl > base) mk[(excl > base ? excl : base) - base] = lane + 1;
@@ -1474,7 +1479,7 @@ __device__ __forceinline__ void persistent_body(const Geom& g_arg, const DetGrid
       // per-wave staging of the exit-line records in LDS (16 B + 4 B per lane, after the parameter blocks)
       float4* rec4 = nullptr;
       int* reci = nullptr;
-      int* spl = nullptr;
+      LdsInt* spl = nullptr;
       if (fast && em) {
         // (offsets from `smem`, not pointer-to-integer casts: the accesses must stay ds_read/ds_write with 32-bit addresses)
         const uint32_t off_rec = ((uint32_t)(reinterpret_cast<unsigned char*>(d_lds + 1) - smem) + 15u) & ~15u;
@@ -1485,7 +1490,7 @@ __device__ __forceinline__ void persistent_body(const Geom& g_arg, const DetGrid
         asm volatile("" : "+v"(wslot));
         rec4 = base + wslot * 64u;
         reci = reinterpret_cast<int*>(base + wpb * 64) + wslot * 64u;
-        spl = reinterpret_cast<int*>(base + wpb * 64) + ((uint32_t)wpb + wslot) * 64u;   // long-row list of walk_rows
+        spl = (LdsInt*)(reinterpret_cast<int*>(base + wpb * 64) + ((uint32_t)wpb + wslot) * 64u);   // long-row list of walk_rows
         if (bin_me) {   // the exiting lanes prepare their own lines, all at once, and park the result in LDS
           GridConst k;
           k.Rf = (float)d.R; k.rho = (float)d.rho_d; k.portz = (float)d.portz; k.n_theta = d.n_theta;
@@ -2050,7 +2055,7 @@ isx_trace_assist_disc_kernel(const Geom g, const DetGrid d, const Work wk) { ass
 //   2. lane = (pair, disc of the cluster): the exact test of SINK_DISC (segment_hits_tube: bounding-ball cull in binary64, then
 //      the tube) on the segment read back from wave-private LDS; a hit increments the disc's bin.
 // ~100 pairs per batch instead of 64 x 362 tests.  Same decisions, so the same counts.
-constexpr int kPairCap = 1024;
+constexpr int kPairCap = 1024, kDiscsInLds = 1024;
 extern "C" __global__ void __launch_bounds__(512)
 isx_bin_discs_kernel(const DetGrid d_arg, const Work wk) {
   extern __shared__ __align__(16) unsigned char smem[];
@@ -2058,15 +2063,32 @@ isx_bin_discs_kernel(const DetGrid d_arg, const Work wk) {
   const int nbins = d_arg.nbins;
   const int tid = threadIdx.x, lane = tid & 63;
   const int nthr = (int)blockDim.x;
-  // per wave: the batch's 64 segments (7 doubles each) and the pair list
-  double* seg = reinterpret_cast<double*>(smem + (((size_t)nbins * 4 + 15) & ~(size_t)15)) + (size_t)(tid >> 6) * (64 * 7 + kPairCap / 2);
-  uint32_t* pairs = reinterpret_cast<uint32_t*>(seg + 64 * 7);
+  // the cluster table (read once per cluster and batch by every wave: from LDS, not through a global-memory round trip per
+  // iteration), then per wave the batch's 64 segments (7 doubles each) and the pair list
+  // up to kDiscsInLds discs also keep their ordered list and permutation in LDS (the exact tests of phase 2 then wait for no
+  // global-memory round trip: measured 70 % of the wave cycles before); longer lists are read from global memory
+  const int n_clusters = d_arg.n_clusters;
+  const bool staged = nbins <= kDiscsInLds;
+  // (LDS-typed pointers throughout: through generic ones the wave-private lists became flat_load / flat_store with system
+  //  scope -- volatile -- and the kernel waited on them for 70 % of its cycles)
+  typedef __attribute__((address_space(3))) float LdsF32;
+  typedef __attribute__((address_space(3))) double LdsF64;
+  typedef __attribute__((address_space(3))) int LdsI32;
+  typedef __attribute__((address_space(3))) uint32_t LdsU32;
+  LdsF32* clusters = (LdsF32*)(smem + (((size_t)nbins * 4 + 15) & ~(size_t)15));   // [n_clusters][4]
+  LdsF64* discs_lds = (LdsF64*)(clusters + 4 * n_clusters);
+  LdsI32* perm_lds = (LdsI32*)(discs_lds + (staged ? 6 * nbins : 0));
+  LdsF64* seg = (LdsF64*)(perm_lds + (staged ? ((nbins + 1) & ~1) : 0)) + (size_t)(tid >> 6) * (64 * 7 + kPairCap / 2);
+  LdsU32* pairs = (LdsU32*)(seg + 64 * 7);
   for (int b = tid; b < nbins; b += nthr) hist[b] = 0u;
+  for (int b = tid; b < 4 * n_clusters; b += nthr) clusters[b] = d_arg.clusters[b];
+  if (staged) {
+    for (int b = tid; b < 6 * nbins; b += nthr) discs_lds[b] = d_arg.discs[b];
+    for (int b = tid; b < nbins; b += nthr) perm_lds[b] = d_arg.disc_perm[b];
+  }
   __syncthreads();
   const double* __restrict__ discs = d_arg.discs;
-  const float4* __restrict__ clusters = reinterpret_cast<const float4*>(d_arg.clusters);
   const int* __restrict__ perm = d_arg.disc_perm;
-  const int n_clusters = d_arg.n_clusters;
   const double disc_r = d_arg.disc_r, disc_h = d_arg.disc_h;
   const uint32_t n_regions = wk.ctr[Q_REGIONS];
   // phase 2: the exact test for every (pair, disc of its cluster), 64 at a time
@@ -2074,16 +2096,20 @@ isx_bin_discs_kernel(const DetGrid d_arg, const Work wk) {
 #pragma unroll 1
     for (int base = 0; base < n_pairs * 8; base += 64) {
       const int item = base + lane;
-      const uint32_t pr = item < n_pairs * 8 ? reinterpret_cast<volatile uint32_t*>(pairs)[item >> 3] : 0u;
+      const uint32_t pr = item < n_pairs * 8 ? pairs[item >> 3] : 0u;
       const int j = (int)(pr >> 8) * 8 + (item & 7);                 // disc in spatial order
       bool hit = false;
+      int bin = 0;
       if (item < n_pairs * 8 && j < nbins) {
-        const volatile double* sp = seg + 7 * (int)(pr & 63u);
+        const LdsF64* sp = seg + 7 * (int)(pr & 63u);
         V3 P0, V;
         P0.x = sp[0]; P0.y = sp[1]; P0.z = sp[2]; V.x = sp[3]; V.y = sp[4]; V.z = sp[5];
-        hit = segment_hits_tube(P0, V, sp[6], discs + 6 * (size_t)j, disc_r, disc_h);
+        double ca[6];   // (two branches so that the staged list is read with ds_read, not through a generic pointer)
+        if (staged) { for (int q = 0; q < 6; ++q) ca[q] = discs_lds[6 * j + q]; bin = perm_lds[j]; }
+        else { for (int q = 0; q < 6; ++q) ca[q] = discs[6 * (size_t)j + q]; bin = perm[j]; }
+        hit = segment_hits_tube(P0, V, sp[6], ca, disc_r, disc_h);
       }
-      if (hit) atomicAdd(&hist[perm[j]], 1u);
+      if (hit) atomicAdd(&hist[bin], 1u);
     }
   };
 #pragma unroll 1
@@ -2104,7 +2130,7 @@ isx_bin_discs_kernel(const DetGrid d_arg, const Work wk) {
       if (have) {
         const double2* src = reinterpret_cast<const double2*>(rec + 8ull * (b0 + (uint32_t)lane));
         const double2 a = src[0], b = src[1], c = src[2], e = src[3];
-        volatile double* sp = seg + 7 * lane;
+        LdsF64* sp = seg + 7 * lane;
         sp[0] = a.x; sp[1] = a.y; sp[2] = b.x; sp[3] = b.y; sp[4] = c.x; sp[5] = c.y; sp[6] = e.x;
         px = (float)a.x; py = (float)a.y; pz = (float)b.x; vx = (float)b.y; vy = (float)c.x; vz = (float)c.y;
       }
@@ -2113,7 +2139,8 @@ isx_bin_discs_kernel(const DetGrid d_arg, const Work wk) {
       int n_pairs = 0;                                               // wave-uniform
 #pragma unroll 1
       for (int k = 0; k < n_clusters; ++k) {
-        const float4 c = clusters[k];                                // (same address in every lane: a scalar load)
+        float4 c;                                                    // (same LDS address in every lane: a broadcast read)
+        c.x = clusters[4 * k]; c.y = clusters[4 * k + 1]; c.z = clusters[4 * k + 2]; c.w = clusters[4 * k + 3];
         const float wx = px - c.x, wy = py - c.y, wz = pz - c.z;
         const float wv = fmaf(wx, vx, fmaf(wy, vy, wz * vz)), ww = fmaf(wx, wx, fmaf(wy, wy, wz * wz));
         // line-to-centre distance^2 * vv = ww vv - wv^2 against R^2 vv, with 0.2 % on the radius^2 and 4e-6 of the two
@@ -2124,7 +2151,7 @@ isx_bin_discs_kernel(const DetGrid d_arg, const Work wk) {
         if (nm) {
           if (near) {
             const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(nm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)nm, 0u));
-            reinterpret_cast<volatile uint32_t*>(pairs)[n_pairs + (int)rank] = (uint32_t)lane | ((uint32_t)k << 8);
+            pairs[n_pairs + (int)rank] = (uint32_t)lane | ((uint32_t)k << 8);
           }
           n_pairs += (int)__popcll(nm);
           if (n_pairs > kPairCap - 64) { __builtin_amdgcn_wave_barrier(); flush(n_pairs); n_pairs = 0; }
@@ -2177,8 +2204,8 @@ isx_bin_lines_kernel(const DetGrid d_arg, const Work wk) {
   __syncthreads();
   typedef __attribute__((address_space(3))) DetGrid LdsDetGrid;
   const volatile LdsDetGrid& d = *(const volatile LdsDetGrid*)d_lds;
-  int* spl = split_all + (tid >> 6) * 128;   // per wave: 64 ints of long-row list + 64 ints of owner marks
-  int* mrk = spl + 64;
+  LdsInt* spl = (LdsInt*)(split_all + (tid >> 6) * 128);   // per wave: 64 ints of long-row list + 64 ints of owner marks
+  LdsInt* mrk = spl + 64;
 
   const int bin_mode = d_arg.bin_mode;
   const uint32_t n_regions = wk.ctr[Q_REGIONS];   // (the trace kernel of this launch has completed)
@@ -2291,10 +2318,10 @@ isx_bin_slots_kernel(const DetGrid d_arg, const Work wk) {
   // per wave: the class queues, their 8 + 8 counters, 64 owner marks (kSlotWaveWords 32-bit words)
   uint32_t* mine = wave_all + (size_t)(tid >> 6) * kSlotWaveWords;
   SlotQueues sq;
-  sq.q = mine;
-  sq.tail = reinterpret_cast<int*>(mine + kClasses * kQueueCap);
+  sq.q = (LdsWord*)mine;
+  sq.tail = (LdsInt*)(mine + kClasses * kQueueCap);
   sq.head = sq.tail + 8;
-  int* mrk = sq.head + 8;
+  LdsInt* mrk = sq.head + 8;
   if (lane < 16) sq.tail[lane] = 0;
   __syncthreads();
   ISX_BD_INIT(sq);
