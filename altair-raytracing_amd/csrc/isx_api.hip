@@ -60,6 +60,7 @@ struct State {
   int assist_block = ISX_ASSIST_BLOCK;          // its workgroup size: (assist_block / 64 - 1) tracer waves + 1 assist wave
   int disc_pipeline = 1;                        // 1 (default): the shared-ray disc sweep as assist-wave trace kernel + isx_bin_discs_kernel; 0: fused SINK_DISC kernel
   int assist = 1;                               // 1: trace kernels with an assist wave per workgroup (assist_body)
+  int bin_cols = 1;                             // 1: isx_bin_cols_kernel ((line, column) slots) for the pencil source where bin_slots applies
   int bin_slots = 1;                            // 1: isx_bin_slots_kernel (slot queues by window length) where the grid allows it
   // options
   int bin_mode = 1;
@@ -406,10 +407,15 @@ int enqueue(int sink, const isx_config* c, uint64_t n, uint64_t seed, uint64_t f
     // 32-bit slot records and the LDS; else the one without
     const bool slots = S.bin_slots && S.bin_mode == 1 && d.n_theta <= 256 && d.n_phi <= 255 &&
                        lds_tables + (size_t)(kBlock / 64) * kSlotWaveWords * 4 <= S.lds_limit;
+    // ... and with COLUMN slots for the pencil source (most lines on the fast path; the BRDF model's grazing lines are served
+    // better by the row slots of isx_bin_slots_kernel)
+    const bool cols = slots && S.bin_cols && !brdf &&
+                      lds_tables + (size_t)d.n_theta * sizeof(RowX) + (size_t)(kBlock / 64) * kColWaveWords * 4 <= S.lds_limit;
     typedef void (*BinFn)(const DetGrid, const Work);
-    const BinFn bin_fn = slots ? isx_bin_slots_kernel : isx_bin_lines_kernel;
+    const BinFn bin_fn = cols ? isx_bin_cols_kernel : slots ? isx_bin_slots_kernel : isx_bin_lines_kernel;
     const int pblock = assist ? S.assist_block : S.trace_block, bblock = slots ? kBlock : S.bin_block;
-    const size_t lds_bin = lds_tables + (slots ? (size_t)(bblock / 64) * kSlotWaveWords * 4 : (size_t)(bblock / 64) * 128 * 4);
+    const size_t lds_bin = lds_tables + (cols ? (size_t)d.n_theta * sizeof(RowX) + (size_t)(bblock / 64) * kColWaveWords * 4
+                                         : slots ? (size_t)(bblock / 64) * kSlotWaveWords * 4 : (size_t)(bblock / 64) * 128 * 4);
     if (lds_bin <= S.lds_limit) {
       const uint64_t chunk = n < S.pipe_chunk ? n : S.pipe_chunk;
       if (S.attr_lds[(const void*)rec_fn] != lds_trace) {   // (once per kernel and size, not once per launch)
@@ -810,6 +816,7 @@ int isx_set_option(const char* key, int64_t value) {
   if (!std::strcmp(key, "assist_block")) { if (value < 128 || value > ISX_ASSIST_BLOCK || value % 64) return ISX_ERR_BAD_ARG; S.assist_block = (int)value; return ISX_OK; }
   if (!std::strcmp(key, "disc_pipeline")) { if (value < 0 || value > 1) return ISX_ERR_BAD_ARG; S.disc_pipeline = (int)value; return ISX_OK; }
   if (!std::strcmp(key, "assist")) { if (value < 0 || value > 1) return ISX_ERR_BAD_ARG; S.assist = (int)value; return ISX_OK; }
+  if (!std::strcmp(key, "bin_cols")) { if (value < 0 || value > 1) return ISX_ERR_BAD_ARG; S.bin_cols = (int)value; return ISX_OK; }
   if (!std::strcmp(key, "bin_slots")) { if (value < 0 || value > 1) return ISX_ERR_BAD_ARG; S.bin_slots = (int)value; return ISX_OK; }
   if (!std::strcmp(key, "ray_sub")) { if (value < 0 || value > (1 << 20)) return ISX_ERR_BAD_ARG; S.ray_sub = (int)value; return ISX_OK; }
   if (!std::strcmp(key, "pipeline")) { if (value < 0 || value > 1) return ISX_ERR_BAD_ARG; S.pipeline = (int)value; return ISX_OK; }

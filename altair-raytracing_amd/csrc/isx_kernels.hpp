@@ -805,6 +805,7 @@ __device__ __forceinline__ void walk_lines_packed(const D& d, uint32_t* __restri
 // columns << 24 -- the kernel serves grids of at most 256 rows and 255 columns (anything else: isx_bin_lines_kernel).
 constexpr int kClasses = 7, kQueueCap = 128;   // a class never holds more than 63 + 64 slots
 constexpr int kSlotWaveWords = kClasses * kQueueCap + 16 + 64;   // LDS words per wave: queues, counters, owner marks
+constexpr int kColWaveWords = kClasses * kQueueCap + 16 + 64 + 64;   // the same + the long-row list of bin_culled
 constexpr int kPiece = 16, kLongest = 24;
 struct SlotQueues {
   LdsWord* q;         // [kClasses][kQueueCap]
@@ -999,6 +1000,281 @@ __device__ __forceinline__ void produce_packed(const D& d, uint32_t* __restrict_
     int jlo = 0, cnt = 0;
     if (have) cap_window(w, (float)rowt[4 * i + 2], (float)rowt[4 * i + 3], d.n_phi, jlo, cnt);
     push_slots(d, hist, rowt, colx, lines, sq, first_line + owner, i, jlo, cnt, lane);
+  }
+}
+
+// ---- COLUMN slots (isx_bin_cols_kernel).  The grid is anisotropic -- rows 0.5 deg apart, columns 4 deg -- so the cap of an exit
+// line (angular radius ~11.5 deg for the 40 cm detector) spans ~46 rows but only ~9 columns: a (line, row) slot holds ~9 candidates,
+// a (line, COLUMN) slot ~30, and everything that is paid per slot -- owner search, window, queue push and pop, line fetch,
+// coefficients -- is paid six times less often per line.  For a fixed column (cos phi, sin phi) the four forms of the hit
+// polynomial are affine in the row quantities S = sin theta_i, C = cos theta_i, T = -R cos^2 theta_i:
+//   with q = the line's point nearest to O (relative to O), c - O = (R S cph, R S sph, -R C), n = (-S sph, S cph, -C),
+//   al = Vy cph - Vx sph, be = qy cph - qx sph, ga = Vx cph + Vy sph, de = qx cph + qy sph:
+//     dot  = V.n              = al S - Vz C
+//     num  = (q - c).n        = be S - qz C + T
+//     m2dv = -2 (q - c).V     = -2 q.V + 2 R ga S - 2 R Vz C
+//     ddw  = |q-c|^2-(w/2)^2  = |q|^2 + R^2 - (w/2)^2 - 2 R de S + 2 R qz C
+// and g = dot (dot ddw + num m2dv) + num^2 < 0 is the hit, exactly as in walk_columns.  Binary32 tier with the same error
+// accounting: every coefficient and every table value carries one rounding u = 2^-24, a form is at most three fused operations,
+// so |delta form| <= 5u M_form with M_form the sum of the coefficient magnitudes times the table bounds (S, C <= 1, |T| <= R);
+// through dg as in walk_columns |delta g| <= (15 + 4) u S, S = Md (Md Mf + Mn Mv) + Mn^2; the band is 1.4e-6 S.  What tier 1
+// cannot decide goes to the binary64 tier and the reference-order test of walk_columns, unchanged.  The rows of a column inside the
+// cap (angular radius w about the piercing point F, cos w = 1 - ch^2 / 2R^2): with a = cos theta_F, b = sin theta_F cos(phi - phi_F)
+// = (cph Fx + sph Fy)/R, the cap is a cos theta + b sin theta >= cos w, i.e. |theta - atan2(b, a)| <= acos(cos w / sqrt(a^2+b^2)).
+struct __align__(16) RowX { float S, C, T; uint32_t off4; };   // sin, cos, -R cos^2 of row i; byte offset of the row's bins
+constexpr int kColPiece = 48, kColLongest = 64;
+__device__ __forceinline__ int col_class(int cnt) { return cnt <= 48 ? (cnt - 1) >> 3 : 6; }   // 1-8, 9-16, ..., 41-48, 49-64
+
+struct ColPre {     // per fast-path line: its cap as the column producer wants it
+  float fx, fy, a, cosw;   // F_xy / R, cos theta_F, cos w
+  int jlo, ncol;           // first column (in [0, n_phi)) and number of columns the cap can reach; ncol = 0: not a fast-path line
+  int kind;                // 0 fast path, -1 general (bin_culled), -2 cannot hit anything
+};
+__device__ __forceinline__ ColPre prep_cols(const GridConst& k, int n_phi, const V3& P, const V3& V) {
+  ColPre o;
+  o.fx = o.fy = o.a = o.cosw = 0.f; o.jlo = 0; o.ncol = 0; o.kind = -1;
+  // (prep_record's construction and conditions: same formulas, same margins)
+  const double wz = P.z - (double)k.portz;
+  const double wv = fma(P.x, V.x, fma(P.y, V.y, wz * V.z));
+  const double hx = fma(-wv, V.x, P.x), hy = fma(-wv, V.y, P.y), hz = fma(-wv, V.z, wz);
+  const float dO2 = (float)fma(hx, hx, fma(hy, hy, hz * hz));
+  const float R2 = k.Rf * k.Rf;
+  const float dO = sqrt_cull(dO2);
+  const float a1 = dO + k.rho;
+  if (dO - k.rho > 1.001f * k.Rf) { o.kind = -2; return o; }
+  if (!(a1 < 0.999f * k.Rf)) return o;
+  const float sF = sqrt_cull(R2 - dO2);
+  const float smin = sqrt_cull(R2 - a1 * a1);
+  const float a0 = fmaxf(0.f, dO - k.rho);
+  const float smax = sqrt_cull(R2 - a0 * a0);
+  const float ext = fmaxf(sF - smin, smax - sF);
+  const float ch2 = fmaf(ext, ext, k.rho * k.rho) * 1.0001f + 1e-3f;
+  if (!(4.0f * (R2 - dO2) > 4.04f * ch2)) return o;
+  const float ch = sqrt_cull(ch2);
+  const double s0 = (double)sF - wv, s1 = -(double)sF - wv;
+  const float Fz0 = (float)fma(s0, V.z, P.z), Fz1 = (float)fma(s1, V.z, P.z);
+  if (Fz0 - ch > k.portz || !(Fz1 - ch > k.portz)) return o;
+  if (k.n_theta > 256 || n_phi > 255) return o;                      // (the slot record holds 8-bit rows and columns)
+  const float Fx = (float)fma(s0, V.x, P.x), Fy = (float)fma(s0, V.y, P.y);
+  const float iR = rcp_cull(k.Rf);
+  o.fx = Fx * iR; o.fy = Fy * iR; o.a = (k.portz - Fz0) * iR;
+  o.cosw = fmaf(-0.5f * ch2, iR * iR, 1.0f) - 2e-6f;                 // cos w = 1 - ch^2 / 2R^2 (a little smaller: a little wider)
+  o.kind = 0;
+  // columns: sin theta_F |sin(phi - phi_F)| <= sin w
+  const float sinF = sqrt_cull(fmaf(o.fx, o.fx, o.fy * o.fy));
+  const float sinw = sqrt_cull(fmaxf(0.f, fmaf(-o.cosw, o.cosw, 1.0f)));
+  if (!(sinF > sinw * 1.01f + 1e-4f)) { o.jlo = 0; o.ncol = n_phi; return o; }   // the cap holds the pole: every column
+  const float r = fminf(1.0f, sinw * rcp_cull(sinF) * 1.001f);
+  const float dphi = (1.57079637f - acos_cull(r)) + 3e-3f;
+  float phiF = atan2_cull(Fy, Fx);
+  if (phiF < 0.f) phiF += 6.28318530718f;
+  const float jc = phiF * k.inv_dphi - 0.5f, hw = dphi * k.inv_dphi + 0.02f;
+  const int lo = (int)ceilf(jc - hw), hi = (int)floorf(jc + hw);
+  int n = hi - lo + 1;
+  if (n >= n_phi) { o.jlo = 0; o.ncol = n_phi; return o; }
+  if (n < 0) n = 0;
+  int j0 = lo;
+  if (j0 < 0) j0 += n_phi;
+  if (j0 >= n_phi) j0 -= n_phi;
+  o.jlo = j0; o.ncol = n;
+  return o;
+}
+
+// the rows [ilo, ilo + cnt) of column (c32, s32) that the cap of a line can reach
+__device__ __forceinline__ void cap_rows(float fx, float fy, float a, float cosw, float c32, float s32, float inv_dth, int n_theta,
+                                         int& ilo, int& cnt) {
+  ilo = 0; cnt = 0;
+  const float b = fmaf(c32, fx, s32 * fy);
+  const float rho2 = fmaf(a, a, b * b);
+  if (!(rho2 > 1e-12f)) return;
+  const float x = cosw * __builtin_amdgcn_rsqf(rho2);
+  if (x > 1.0f) return;                                               // the column misses the cap
+  const float dl = acos_cull(fmaxf(x, -1.0f)) + 2.5e-3f;
+  const float tc = atan2_cull(b, a);
+  const float tlo = tc - dl, thi = tc + dl;
+  if (thi < 0.f || tlo > 1.57079637f) return;
+  const int lo = max((int)floorf(tlo * inv_dth - 0.5f - 1e-3f), 0);
+  const int hi = min((int)ceilf(thi * inv_dth - 0.5f + 1e-3f), n_theta - 1);
+  if (hi >= lo) { ilo = lo; cnt = hi - lo + 1; }
+}
+
+// one pass: 64 column slots (record: line within the unit | column << 8 | first row << 16 | rows << 24), lane = slot
+template <class D>
+__device__ __forceinline__ void consume_cols(const D& d, uint32_t* __restrict__ hist, const double* __restrict__ rowt,
+                                             const ColX* __restrict__ colx, const RowX* __restrict__ rowx,
+                                             const double* __restrict__ lines, uint32_t rec, bool active, int lane) {
+  const int line = (int)(rec & 255u), j = (int)((rec >> 8) & 255u), ilo = (int)((rec >> 16) & 255u);
+  const int len = active ? (int)(rec >> 24) : 0;
+  const double* src6 = lines + 6 * line;
+  isx_f2 kA1 = {0.f, 0.f}, kA2 = {0.f, 0.f}, kB0 = {0.f, 0.f}, kB1 = {0.f, 0.f}, kB2 = {0.f, 0.f};
+  float band32 = 0.f;
+  if (len > 0) {
+    V3 P, V;
+    {
+      const double2* src = reinterpret_cast<const double2*>(src6);
+      const double2 a = src[0], b = src[1], c = src[2];
+      P.x = a.x; P.y = a.y; P.z = b.x; V.x = b.y; V.y = c.x; V.z = c.y;
+    }
+    const double wz = P.z - d.portz;
+    const double t0 = -fma(P.x, V.x, fma(P.y, V.y, wz * V.z));
+    const double qx = fma(t0, V.x, P.x), qy = fma(t0, V.y, P.y), qz = fma(t0, V.z, wz);   // nearest to O, relative to O
+    const double cph = colx[j].c, sph = colx[j].s;
+    const double al = fma(V.y, cph, -(V.x * sph)), be = fma(qy, cph, -(qx * sph));
+    const double ga = fma(V.x, cph, V.y * sph), de = fma(qx, cph, qy * sph);
+    const double R = d.R, R2x = 2.0 * R;
+    const double e0 = -2.0 * fma(qx, V.x, fma(qy, V.y, qz * V.z));
+    const double f0 = fma(qx, qx, fma(qy, qy, fma(qz, qz, R * R))) - d.half_w2;
+    const double e1 = R2x * ga, e2 = -(R2x * V.z), f1 = -(R2x * de), f2 = R2x * qz;
+    kA1.x = (float)al; kA1.y = (float)be;
+    kA2.x = (float)(-V.z); kA2.y = (float)(-qz);
+    kB0.x = (float)e0; kB0.y = (float)f0;
+    kB1.x = (float)e1; kB1.y = (float)f1;
+    kB2.x = (float)e2; kB2.y = (float)f2;
+    const double Md = fabs(al) + fabs(V.z), Mn = fabs(be) + (fabs(qz) + R);
+    const double Mv = fabs(e0) + (fabs(e1) + fabs(e2)), Mf = fabs(f0) + (fabs(f1) + fabs(f2));
+    const double Sg = fma(Md, fma(Md, Mf, Mn * Mv), Mn * Mn);
+    band32 = Sg >= 1e-6 ? (float)(1.4e-6 * Sg) * 1.000001f + 1e-30f : __builtin_inff();
+  }
+  typedef __attribute__((address_space(3))) uint32_t LdsU32;
+  typedef __attribute__((address_space(3))) unsigned char LdsByte;
+  LdsByte* const colbins = reinterpret_cast<LdsByte*>((__attribute__((address_space(3))) void*)hist) + (uint32_t)j * 4u;
+  const RowX* rp = rowx + ilo;
+  if (len > 0) ISX_DIAG_ADD_LANES(7, len);
+  ISX_DIAG_ADD(11, 1);
+  for (int k = 0;; ++k) {
+    const bool act = k < len;
+    if (__ballot(act) == 0ull) break;
+    ISX_DIAG_ADD(4, 1);
+    if (act) {
+      const RowX rx = *rp;
+      LdsByte* const bin = colbins + rx.off4;
+      const isx_f2 SS = {rx.S, rx.S}, CC = {rx.C, rx.C};
+      const isx_f2 ta = __builtin_elementwise_fma(kA1, SS, kA2 * CC);                                    // (dot, num - T)
+      const isx_f2 tb = __builtin_elementwise_fma(kB1, SS, __builtin_elementwise_fma(kB2, CC, kB0));     // (-2dv, ddw)
+      const float num = ta.y + rx.T;
+      const float g = fmaf(ta.x, fmaf(ta.x, tb.y, num * tb.x), num * num);
+      bool hit = g < 0.f;
+      if (!(fabsf(g) > band32)) {
+        // tiers 2 and 3 of walk_columns (binary64 about the original point with its 2.1e-9 band, then the reference's own test)
+        ISX_DIAG_ADD_LANES(12, 1);
+        int ir = ilo + k;
+        asm volatile("" : "+v"(ir));
+        const double sd = rowt[4 * ir + 0], cd = rowt[4 * ir + 1], zz = rowt[4 * ir + 2], ad = rowt[4 * ir + 3];
+        int jr = j;
+        asm volatile("" : "+v"(jr));
+        const double cph = colx[jr].c, sph = colx[jr].s;
+        V3 P, V;
+        {
+          const double2* src = reinterpret_cast<const double2*>(src6 + (jr - j));
+          const double2 a = src[0], b = src[1], c = src[2];
+          P.x = a.x; P.y = a.y; P.z = b.x; V.x = b.y; V.y = c.x; V.z = c.y;
+        }
+        const double pz = P.z - zz;
+        const double dot = fma(sd * V.y, cph, fma(-(sd * V.x), sph, -(cd * V.z)));
+        const double numd = fma(sd * P.y, cph, fma(-(sd * P.x), sph, -(cd * pz)));
+        const double m2dv = fma(2.0 * (ad * V.x), cph, fma(2.0 * (ad * V.y), sph, -2.0 * fma(P.x, V.x, fma(P.y, V.y, pz * V.z))));
+        const double f0 = fma(P.x, P.x, fma(P.y, P.y, fma(ad, ad, pz * pz)));
+        const double f1c = -2.0 * (ad * P.x), f2c = -2.0 * (ad * P.y);
+        const double ddw = fma(f1c, cph, fma(f2c, sph, f0 - d.half_w2));
+        const double diff = fma(dot, fma(dot, ddw, numd * m2dv), numd * numd);
+        const double bandc = 2.1e-9 * fma(2.0, f0 + (fabs(f1c) + fabs(f2c)), d.half_w2);
+        hit = diff < 0.0;
+        if (fabs(dot) < 1e-4 || fabs(diff) <= bandc) {
+          ISX_DIAG_ADD_LANES(13, 1);
+          const double* tab = d.table;
+          asm volatile("" : "+v"(tab));
+          hit = check_intersection(tab + 6 * (size_t)(ir * d.n_phi + jr), d.half_w2, P, V);
+        }
+      }
+#ifdef ISX_DIAG
+      {   // tuning builds: a decision taken by tier 1 must be the reference's
+        V3 P, V;
+        const double2* src = reinterpret_cast<const double2*>(src6);
+        const double2 a = src[0], b = src[1], c = src[2];
+        P.x = a.x; P.y = a.y; P.z = b.x; V.x = b.y; V.y = c.x; V.z = c.y;
+        const bool ref = check_intersection(d.table + 6 * (size_t)((ilo + k) * d.n_phi + j), d.half_w2, P, V);
+        if (ref != hit) ISX_DIAG_ADD_LANES(14, 1);
+      }
+#endif
+      rp++;
+      if (hit) __hip_atomic_fetch_add(reinterpret_cast<LdsU32*>(bin), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
+  }
+}
+
+template <class D>
+__device__ __forceinline__ void drain_cols(const D& d, uint32_t* __restrict__ hist, const double* __restrict__ rowt,
+                                           const ColX* __restrict__ colx, const RowX* __restrict__ rowx,
+                                           const double* __restrict__ lines, const SlotQueues& sq, int least, int lane) {
+  volatile LdsInt* tl = sq.tail;
+  volatile LdsInt* hd = sq.head;
+  const int held = lane < kClasses ? tl[lane] - hd[lane] : 0;
+  unsigned long long m = __ballot(held >= least);
+  while (m) {
+    const int c = __builtin_ctzll(m);
+    m &= m - 1ull;
+    const int h = hd[c], n = tl[c] - h;
+    const int take = n < 64 ? n : 64;
+    const uint32_t rec = lane < take ? ((volatile LdsWord*)sq.q)[c * kQueueCap + ((h + lane) & (kQueueCap - 1))] : 0u;
+    __builtin_amdgcn_wave_barrier();
+    if (lane == 0) hd[c] = h + take;
+    __builtin_amdgcn_wave_barrier();
+    consume_cols(d, hist, rowt, colx, rowx, lines, rec, lane < take, lane);
+  }
+}
+
+// every lane hands in (at most) one column slot: rows [ilo, ilo + cnt) of column j for line `line` of the unit
+template <class D>
+__device__ __forceinline__ void push_cols(const D& d, uint32_t* __restrict__ hist, const double* __restrict__ rowt,
+                                          const ColX* __restrict__ colx, const RowX* __restrict__ rowx,
+                                          const double* __restrict__ lines, const SlotQueues& sq, int line, int j, int ilo, int cnt,
+                                          int lane) {
+  int i0 = ilo, rem = cnt;
+  for (;;) {
+    const int piece = rem > kColLongest ? kColPiece : rem;
+    if (piece > 0) {
+      const int c = col_class(piece);
+      const int pos = __hip_atomic_fetch_add(sq.tail + c, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      ((volatile LdsWord*)sq.q)[c * kQueueCap + (pos & (kQueueCap - 1))] =
+          (uint32_t)line | ((uint32_t)j << 8) | ((uint32_t)i0 << 16) | ((uint32_t)piece << 24);
+    }
+    rem -= piece;
+    i0 += piece;
+    __builtin_amdgcn_wave_barrier();
+    drain_cols(d, hist, rowt, colx, rowx, lines, sq, 64, lane);
+    if (__ballot(rem > 0) == 0ull) break;
+  }
+}
+
+// producer: the columns of all fast-path lines of a batch of 64, packed over the lanes (owner search as in walk_lines_packed)
+template <class D>
+__device__ __forceinline__ void produce_cols_packed(const D& d, uint32_t* __restrict__ hist, const double* __restrict__ rowt,
+                                                    const ColX* __restrict__ colx, const RowX* __restrict__ rowx,
+                                                    const double* __restrict__ lines, const SlotQueues& sq, const ColPre& pre,
+                                                    int excl, int incl, int total, float inv_dth, int n_theta, int first_line,
+                                                    int lane, LdsInt* mark) {
+#pragma unroll 1
+  for (int base = 0; base < total; base += 64) {
+    const int g = base + lane;
+    bool have = g < total;
+    volatile LdsInt* mk = mark;
+    mk[lane] = 0;
+    __builtin_amdgcn_wave_barrier();
+    if (pre.ncol > 0 && excl < base + 64 && incl > base) mk[(excl > base ? excl : base) - base] = lane + 1;
+    __builtin_amdgcn_wave_barrier();
+    const int m = mk[lane];
+    const unsigned long long low = __ballot(m != 0) & (~0ull >> (63 - lane));
+    const int pos = 63 - __builtin_clzll(low | 1ull);
+    int owner = mk[pos] - 1;
+    if (!have || owner < 0) { owner = 0; have = false; }
+    const int o_excl = __shfl(excl, owner, 64), o_jlo = __shfl(pre.jlo, owner, 64);
+    const float fx = __shfl(pre.fx, owner, 64), fy = __shfl(pre.fy, owner, 64), a = __shfl(pre.a, owner, 64), cw = __shfl(pre.cosw, owner, 64);
+    int j = o_jlo + (g - o_excl);
+    if (j >= d.n_phi) j -= d.n_phi;
+    if (!have) j = 0;
+    int ilo = 0, cnt = 0;
+    if (have) cap_rows(fx, fy, a, cw, colx[j].c32, colx[j].s32, inv_dth, n_theta, ilo, cnt);
+    push_cols(d, hist, rowt, colx, rowx, lines, sq, first_line + owner, j, ilo, cnt, lane);
   }
 }
 
@@ -2386,6 +2662,121 @@ isx_bin_slots_kernel(const DetGrid d_arg, const Work wk) {
       produce_packed(dfast, hist, rowt, colx, lines, sq, pre, nrow, incl - nrow, incl, total, k.inv_dphi, first_line, lane, mrk);
     }
     drain_slots(dfast, hist, rowt, colx, lines, sq, 1, lane);   // the unit's leftovers, class by class
+  }
+  __syncthreads();
+  unsigned long long flushed = 0;
+  unsigned long long* ghist = wk.hist;
+  asm volatile("" : "+s"(ghist));
+  for (int b = tid; b < nbins; b += nthr) {
+    const uint32_t c = hist[b];
+    if (c) { atomicAdd(&ghist[b], (unsigned long long)c); flushed += c; }
+  }
+  if (flushed) atomicAdd(&wk.stats[5], flushed);
+}
+
+// ------------------------------------------------------------------ binning kernel with COLUMN slots (default for the pencil
+// source on grids of at most 256 x 255 bins whose LDS need fits): the fast-path lines go through (line, column) slots and the
+// wave's length-class queues (RowX / ColPre above); the few lines off the fast path take bin_culled (one line at a time, lane =
+// row) as in isx_bin_lines_kernel.  Work unit = a quarter region = up to 256 lines.
+extern "C" __global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(ISX_BIN_WAVES_PER_EU, ISX_BIN_WAVES_PER_EU)))
+isx_bin_cols_kernel(const DetGrid d_arg, const Work wk) {
+  extern __shared__ __align__(16) unsigned char smem[];
+  uint32_t* hist = reinterpret_cast<uint32_t*>(smem);
+  const int nbins = d_arg.nbins;
+  const size_t off_row = ((size_t)nbins * 4 + 15) & ~(size_t)15;
+  double* rowt = reinterpret_cast<double*>(smem + off_row);
+  ColX* colx = reinterpret_cast<ColX*>(rowt + 4 * d_arg.n_theta);
+  RowX* rowx = reinterpret_cast<RowX*>(colx + 2 * d_arg.n_phi);
+  DetGrid* d_lds = reinterpret_cast<DetGrid*>(rowx + d_arg.n_theta);
+  uint32_t* wave_all = reinterpret_cast<uint32_t*>(d_lds + 1);
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int nthr = (int)blockDim.x;
+  for (int b = tid; b < nbins; b += nthr) hist[b] = 0u;
+  for (int b = tid; b < 4 * d_arg.n_theta; b += nthr) rowt[b] = d_arg.rowtab[b];
+  for (int b = tid; b < d_arg.n_theta; b += nthr) {
+    RowX e;
+    const double sd = d_arg.rowtab[4 * b], cd = d_arg.rowtab[4 * b + 1];
+    e.S = (float)sd; e.C = (float)cd; e.T = (float)(-(d_arg.R * (cd * cd))); e.off4 = (uint32_t)(b * d_arg.n_phi) * 4u;
+    rowx[b] = e;
+  }
+  for (int b = tid; b < 2 * d_arg.n_phi; b += nthr) {
+    const int j = b < d_arg.n_phi ? b : b - d_arg.n_phi;
+    ColX e;
+    e.c = d_arg.coltab[2 * j]; e.s = d_arg.coltab[2 * j + 1]; e.off4 = (uint32_t)j * 4u; e.c32 = (float)e.c; e.s32 = (float)e.s; e.pad = 0u;
+    colx[b] = e;
+  }
+  if (tid == (nthr > 128 ? 128 : 0)) *d_lds = d_arg;
+  // per wave: the class queues, their 8 + 8 counters, 64 owner marks, 64 ints of long-row list for bin_culled
+  uint32_t* mine = wave_all + (size_t)(tid >> 6) * kColWaveWords;
+  SlotQueues sq;
+  sq.q = (LdsWord*)mine;
+  sq.tail = (LdsInt*)(mine + kClasses * kQueueCap);
+  sq.head = sq.tail + 8;
+  LdsInt* mrk = sq.head + 8;
+  LdsInt* spl = mrk + 64;
+  if (lane < 16) sq.tail[lane] = 0;
+  __syncthreads();
+  typedef __attribute__((address_space(3))) DetGrid LdsDetGrid;
+  const volatile LdsDetGrid& d = *(const volatile LdsDetGrid*)d_lds;
+
+  const uint32_t n_regions = wk.ctr[Q_REGIONS];   // (the trace kernel of this launch has completed)
+#pragma unroll 1
+  for (;;) {
+    uint32_t unit = 0;
+    if (lane == 0) unit = atomicAdd(&wk.ctr[Q_BIN], 1u);
+    unit = (uint32_t)__builtin_amdgcn_readfirstlane((int)unit);
+    const uint32_t region = unit >> 2;
+    if (region >= n_regions) break;
+    const uint32_t r_lines = (uint32_t)__builtin_amdgcn_readfirstlane((int)d_arg.rec_counts[region]);
+    const uint32_t q_first = (unit & 3u) * (kRegion / 4u);
+    const uint32_t n_lines = r_lines < q_first + kRegion / 4u ? r_lines : q_first + kRegion / 4u;
+    const double* lines = d_arg.rec_lines + 6ull * ((uint64_t)region * kRegion + q_first);   // the unit's lines
+    struct { int n_phi; double half_w2, portz, R; const double* table; } dcol;
+    dcol.n_phi = d.n_phi; dcol.half_w2 = d.half_w2; dcol.portz = d_arg.portz; dcol.R = d_arg.R; dcol.table = d.table;
+#pragma unroll 1
+    for (uint32_t b0 = q_first; b0 < n_lines; b0 += 64u) {
+      const bool have = b0 + (uint32_t)lane < n_lines;
+      const int first_line = (int)(b0 - q_first);
+      GridConst k;
+      k.Rf = (float)d.R; k.rho = (float)d.rho_d; k.portz = (float)d.portz; k.n_theta = d.n_theta;
+      k.inv_dphi = (float)d.n_phi * 0.15915494309f;
+      k.inv_dth = (float)k.n_theta * 0.63661977237f;
+      V3 lp, lv;
+      lp.x = lp.y = lp.z = 0.0; lv.x = lv.y = 0.0; lv.z = -1.0;
+      ColPre pre;
+      pre.fx = pre.fy = pre.a = pre.cosw = 0.f; pre.jlo = 0; pre.ncol = 0; pre.kind = -2;
+      if (have) {
+        const double2* src = reinterpret_cast<const double2*>(lines + 6 * (first_line + lane));
+        const double2 a = src[0], b = src[1], c = src[2];
+        lp.x = a.x; lp.y = a.y; lp.z = b.x; lv.x = b.y; lv.y = c.x; lv.z = c.y;
+        pre = prep_cols(k, dcol.n_phi, lp, lv);
+      }
+      { const int n_far = (int)__popcll(__ballot(have && pre.kind == -2)); (void)n_far; ISX_DIAG_ADD(3, n_far); }
+      // lines off the fast path: one at a time, lane = row (cap or box windows), as in isx_bin_lines_kernel
+      unsigned long long em = __ballot(have && pre.kind == -1);
+      while (em) {
+        const int src = __builtin_ctzll(em);
+        em &= em - 1ull;
+        V3 P, V;
+        P.x = readlane_f64(lp.x, src); P.y = readlane_f64(lp.y, src); P.z = readlane_f64(lp.z, src);
+        V.x = readlane_f64(lv.x, src); V.y = readlane_f64(lv.y, src); V.z = readlane_f64(lv.z, src);
+        bin_culled<true>(d, hist, rowt, colx, P, V, lane, spl);
+      }
+      // fast-path lines: their columns packed over the lanes
+      const int ncol = (have && pre.kind == 0) ? pre.ncol : 0;
+      int incl = ncol;
+#pragma unroll
+      for (int dlt = 1; dlt < 64; dlt <<= 1) {
+        const int o = __shfl_up(incl, dlt, 64);
+        if (lane >= dlt) incl += o;
+      }
+      const int total = __builtin_amdgcn_readlane(incl, 63);
+      { const int n_fast = (int)__popcll(__ballot(ncol > 0)); (void)n_fast; ISX_DIAG_ADD(0, n_fast); }
+      ColPre pc = pre;
+      pc.ncol = ncol;
+      produce_cols_packed(dcol, hist, rowt, colx, rowx, lines, sq, pc, incl - ncol, incl, total, k.inv_dth, k.n_theta, first_line, lane, mrk);
+    }
+    drain_cols(dcol, hist, rowt, colx, rowx, lines, sq, 1, lane);   // the unit's leftovers, class by class
   }
   __syncthreads();
   unsigned long long flushed = 0;
