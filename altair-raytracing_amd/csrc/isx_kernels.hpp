@@ -1025,12 +1025,16 @@ struct __align__(16) RowX { float S, C, T; uint32_t off4; };   // sin, cos, -R c
 constexpr int kColPiece = 48, kColLongest = 64;
 __device__ __forceinline__ int col_class(int cnt) { return cnt <= 48 ? (cnt - 1) >> 3 : 6; }   // 1-8, 9-16, ..., 41-48, 49-64
 
-struct ColPre {     // per fast-path line: its cap as the column producer wants it
+struct ColPre {     // per line and piercing point: its cap as the column producer wants it
   float fx, fy, a, cosw;   // F_xy / R, cos theta_F, cos w
-  int jlo, ncol;           // first column (in [0, n_phi)) and number of columns the cap can reach; ncol = 0: not a fast-path line
-  int kind;                // 0 fast path, -1 general (bin_culled), -2 cannot hit anything
+  int jlo, ncol;           // first column (in [0, n_phi)) and number of columns the cap can reach
+  int kind;                // 0 a cap with columns, -1 no caps: grazing line (bin_culled's box windows), -2 the line cannot hit
+                           // anything, -3 this side's cap lies above every detector row
 };
-__device__ __forceinline__ ColPre prep_cols(const GridConst& k, int n_phi, const V3& P, const V3& V) {
+// side 0: the piercing point at the larger line parameter (the only one of a fast-path line), side 1: the other one.  The two caps
+// of a line are disjoint (the construction requires the piercing points more than 2.01 chords apart), so a line's slots of side 0
+// and side 1 never name the same bin.
+__device__ __forceinline__ ColPre prep_cols(const GridConst& k, int n_phi, const V3& P, const V3& V, int side) {
   ColPre o;
   o.fx = o.fy = o.a = o.cosw = 0.f; o.jlo = 0; o.ncol = 0; o.kind = -1;
   // (prep_record's construction and conditions: same formulas, same margins)
@@ -1051,10 +1055,9 @@ __device__ __forceinline__ ColPre prep_cols(const GridConst& k, int n_phi, const
   const float ch2 = fmaf(ext, ext, k.rho * k.rho) * 1.0001f + 1e-3f;
   if (!(4.0f * (R2 - dO2) > 4.04f * ch2)) return o;
   const float ch = sqrt_cull(ch2);
-  const double s0 = (double)sF - wv, s1 = -(double)sF - wv;
-  const float Fz0 = (float)fma(s0, V.z, P.z), Fz1 = (float)fma(s1, V.z, P.z);
-  if (Fz0 - ch > k.portz || !(Fz1 - ch > k.portz)) return o;
-  if (k.n_theta > 256 || n_phi > 255) return o;                      // (the slot record holds 8-bit rows and columns)
+  const double s0 = side == 0 ? ((double)sF - wv) : (-(double)sF - wv);
+  const float Fz0 = (float)fma(s0, V.z, P.z);
+  if (Fz0 - ch > k.portz) { o.kind = -3; return o; }                 // cap entirely above every detector row
   const float Fx = (float)fma(s0, V.x, P.x), Fy = (float)fma(s0, V.y, P.y);
   const float iR = rcp_cull(k.Rf);
   o.fx = Fx * iR; o.fy = Fy * iR; o.a = (k.portz - Fz0) * iR;
@@ -2749,7 +2752,7 @@ isx_bin_cols_kernel(const DetGrid d_arg, const Work wk) {
         const double2* src = reinterpret_cast<const double2*>(lines + 6 * (first_line + lane));
         const double2 a = src[0], b = src[1], c = src[2];
         lp.x = a.x; lp.y = a.y; lp.z = b.x; lv.x = b.y; lv.y = c.x; lv.z = c.y;
-        pre = prep_cols(k, dcol.n_phi, lp, lv);
+        pre = prep_cols(k, dcol.n_phi, lp, lv, 0);
       }
       { const int n_far = (int)__popcll(__ballot(have && pre.kind == -2)); (void)n_far; ISX_DIAG_ADD(3, n_far); }
       // lines off the fast path: one at a time, lane = row (cap or box windows), as in isx_bin_lines_kernel
@@ -2762,19 +2765,31 @@ isx_bin_cols_kernel(const DetGrid d_arg, const Work wk) {
         V.x = readlane_f64(lv.x, src); V.y = readlane_f64(lv.y, src); V.z = readlane_f64(lv.z, src);
         bin_culled<true>(d, hist, rowt, colx, P, V, lane, spl);
       }
-      // fast-path lines: their columns packed over the lanes
-      const int ncol = (have && pre.kind == 0) ? pre.ncol : 0;
-      int incl = ncol;
+      // lines with caps: the columns of their caps packed over the lanes -- side 0 (every fast-path line has only this one),
+      // then side 1 for the few lines whose second piercing point lies low enough to reach detector rows
+#pragma unroll 1
+      for (int side = 0; side < 2; ++side) {
+        if (side == 1) {
+          const bool again = have && pre.kind != -1 && pre.kind != -2;   // (a line with caps at all)
+          if (__ballot(again) == 0ull) break;
+          ColPre p1;
+          p1.fx = p1.fy = p1.a = p1.cosw = 0.f; p1.jlo = 0; p1.ncol = 0; p1.kind = -3;
+          if (again) p1 = prep_cols(k, dcol.n_phi, lp, lv, 1);
+          pre = p1;
+        }
+        const int ncol = (have && pre.kind == 0) ? pre.ncol : 0;
+        int incl = ncol;
 #pragma unroll
-      for (int dlt = 1; dlt < 64; dlt <<= 1) {
-        const int o = __shfl_up(incl, dlt, 64);
-        if (lane >= dlt) incl += o;
+        for (int dlt = 1; dlt < 64; dlt <<= 1) {
+          const int o = __shfl_up(incl, dlt, 64);
+          if (lane >= dlt) incl += o;
+        }
+        const int total = __builtin_amdgcn_readlane(incl, 63);
+        if (side == 0) { const int n_fast = (int)__popcll(__ballot(ncol > 0)); (void)n_fast; ISX_DIAG_ADD(0, n_fast); }
+        ColPre pc = pre;
+        pc.ncol = ncol;
+        produce_cols_packed(dcol, hist, rowt, colx, rowx, lines, sq, pc, incl - ncol, incl, total, k.inv_dth, k.n_theta, first_line, lane, mrk);
       }
-      const int total = __builtin_amdgcn_readlane(incl, 63);
-      { const int n_fast = (int)__popcll(__ballot(ncol > 0)); (void)n_fast; ISX_DIAG_ADD(0, n_fast); }
-      ColPre pc = pre;
-      pc.ncol = ncol;
-      produce_cols_packed(dcol, hist, rowt, colx, rowx, lines, sq, pc, incl - ncol, incl, total, k.inv_dth, k.n_theta, first_line, lane, mrk);
     }
     drain_cols(dcol, hist, rowt, colx, rowx, lines, sq, 1, lane);   // the unit's leftovers, class by class
   }
