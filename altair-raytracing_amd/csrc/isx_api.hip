@@ -409,7 +409,7 @@ int enqueue(int sink, const isx_config* c, uint64_t n, uint64_t seed, uint64_t f
                        lds_tables + (size_t)(kBlock / 64) * kSlotWaveWords * 4 <= S.lds_limit;
     // ... and with COLUMN slots for the pencil source (most lines on the fast path; the BRDF model's grazing lines are served
     // better by the row slots of isx_bin_slots_kernel)
-    const bool cols = slots && S.bin_cols && !brdf &&
+    const bool cols = slots && S.bin_cols && (!brdf || S.bin_cols == 2) &&
                       lds_tables + (size_t)d.n_theta * sizeof(RowX) + (size_t)(kBlock / 64) * kColWaveWords * 4 <= S.lds_limit;
     typedef void (*BinFn)(const DetGrid, const Work);
     const BinFn bin_fn = cols ? isx_bin_cols_kernel : slots ? isx_bin_slots_kernel : isx_bin_lines_kernel;
@@ -816,7 +816,7 @@ int isx_set_option(const char* key, int64_t value) {
   if (!std::strcmp(key, "assist_block")) { if (value < 128 || value > ISX_ASSIST_BLOCK || value % 64) return ISX_ERR_BAD_ARG; S.assist_block = (int)value; return ISX_OK; }
   if (!std::strcmp(key, "disc_pipeline")) { if (value < 0 || value > 1) return ISX_ERR_BAD_ARG; S.disc_pipeline = (int)value; return ISX_OK; }
   if (!std::strcmp(key, "assist")) { if (value < 0 || value > 1) return ISX_ERR_BAD_ARG; S.assist = (int)value; return ISX_OK; }
-  if (!std::strcmp(key, "bin_cols")) { if (value < 0 || value > 1) return ISX_ERR_BAD_ARG; S.bin_cols = (int)value; return ISX_OK; }
+  if (!std::strcmp(key, "bin_cols")) { if (value < 0 || value > 2) return ISX_ERR_BAD_ARG; S.bin_cols = (int)value; return ISX_OK; }
   if (!std::strcmp(key, "bin_slots")) { if (value < 0 || value > 1) return ISX_ERR_BAD_ARG; S.bin_slots = (int)value; return ISX_OK; }
   if (!std::strcmp(key, "ray_sub")) { if (value < 0 || value > (1 << 20)) return ISX_ERR_BAD_ARG; S.ray_sub = (int)value; return ISX_OK; }
   if (!std::strcmp(key, "pipeline")) { if (value < 0 || value > 1) return ISX_ERR_BAD_ARG; S.pipeline = (int)value; return ISX_OK; }
