@@ -14,7 +14,7 @@ def _same(a, b):
 
 
 def _reset(isx):
-    for k, v in (("assist", 1), ("assist_block", 768), ("bin_slots", 1), ("pipeline", 1), ("ray_sub", 0), ("grid_blocks", 0),
+    for k, v in (("assist", 1), ("assist_block", 768), ("bin_slots", 1), ("bin_cols", 1), ("pipeline", 1), ("ray_sub", 0), ("grid_blocks", 0),
                  ("overlap", 0), ("overlap_trace_streams", 1), ("trace_block", 512), ("trace_blocks_per_cu", 0)):
         isx.set_option(k, v)
 
@@ -39,13 +39,14 @@ def test_assist_wave_and_slot_queues_change_nothing(isx, orc, which):
         return c
     n = 300_000 if which == "brdf" else 1_500_000
     try:
-        isx.set_option("assist", 0); isx.set_option("bin_slots", 0)
+        isx.set_option("assist", 0); isx.set_option("bin_slots", 0); isx.set_option("bin_cols", 0)
         ref, rst = isx.fluxmap(cfg(isx), n, SEED, 11)
-        for assist, block, slots, grid in ((1, 768, 1, 0), (1, 128, 1, 0), (1, 384, 0, 0), (0, 768, 1, 0), (1, 768, 1, 1), (1, 256, 1, 3)):
+        for assist, block, slots, cols, grid in ((1, 768, 1, 1, 0), (1, 128, 1, 0, 0), (1, 384, 0, 1, 0), (0, 768, 1, 2, 0), (1, 768, 1, 2, 1),
+                                                 (1, 256, 1, 1, 3)):
             isx.set_option("assist", assist); isx.set_option("assist_block", block); isx.set_option("bin_slots", slots)
-            isx.set_option("grid_blocks", grid)
+            isx.set_option("bin_cols", cols); isx.set_option("grid_blocks", grid)
             h, st = isx.fluxmap(cfg(isx), n, SEED, 11)
-            assert np.array_equal(h, ref), (assist, block, slots, grid)
+            assert np.array_equal(h, ref), (assist, block, slots, cols, grid)
             _same(st, rst)
         _reset(isx)
         m = 20000

@@ -35,7 +35,7 @@ for k in range(NG):
                 sched_mask=int(rng.choice([0, 1, 3, 7, 15, 255])), sched_min=int(rng.integers(1, 66)),
                 # round 3: ray queue, assist-wave trace kernels, slot-queue binning kernel, overlapped chunks
                 ray_sub=int(rng.choice([0, 0, 64, 100, 777, 4096, 1 << 20])), assist=int(rng.integers(0, 2)),
-                assist_block=int(rng.choice([128, 192, 256, 384, 512, 640, 768])), bin_slots=int(rng.integers(0, 2)),
+                assist_block=int(rng.choice([128, 192, 256, 384, 512, 640, 768])), bin_slots=int(rng.integers(0, 2)), bin_cols=int(rng.integers(0, 3)),
                 bin_block=int(rng.choice([256, 512, 1024])), bin_blocks_per_cu=int(rng.integers(0, 4)),
                 overlap=int(rng.choice([0, 0, 0, 2, 3, 5])), overlap_trace_streams=int(rng.integers(1, 3)))
     for key, val in opts.items():
@@ -47,7 +47,7 @@ for k in range(NG):
         if not ok:
             print("MISMATCH (schedule)", opts, c.trace_mode, c.source_model, flush=True)
 for key, val in dict(pipeline=1, pipeline_chunk=1 << 26, trace_block=512, trace_blocks_per_cu=0, blocks_per_cu=1, grid_blocks=0,
-                     sched_mask=3, sched_min=12, ray_sub=0, assist=1, assist_block=768, bin_slots=1, bin_block=512, bin_blocks_per_cu=0,
+                     sched_mask=3, sched_min=12, ray_sub=0, assist=1, assist_block=768, bin_slots=1, bin_cols=1, bin_block=512, bin_blocks_per_cu=0,
                      overlap=0, overlap_trace_streams=1).items():
     isx.set_option(key, val)
 print("schedule soak:", NG, "settings x 3 configurations,", bad, "mismatches", flush=True)

@@ -126,7 +126,7 @@ if pmc:
         # read (16 B per lane) -- the binning kernel reads its 48-byte exit lines as three 16-byte loads per lane, so its fetch
         # figure is doubled; the other kernels read a few KB of scalar/L2 traffic (no correction).  WRITE_SIZE is exact for
         # 16-B-per-lane streaming stores (the trace kernel's exit lines) and for the 8-byte atomics of the histogram flush.
-        fx = 2.0 if KERNEL in ("isx_bin_lines_kernel", "isx_bin_slots_kernel") else 1.0
+        fx = 2.0 if KERNEL in ("isx_bin_lines_kernel", "isx_bin_slots_kernel", "isx_bin_cols_kernel") else 1.0
         fetch_b, write_b = pmc["FETCH_SIZE"] * 1024 * fx, pmc["WRITE_SIZE"] * 1024
         summ.update(fetch_bytes=fetch_b, write_bytes=write_b, hbm_bytes_per_launch=fetch_b + write_b, fetch_correction=fx,
                     note="FETCH_SIZE/WRITE_SIZE are KiB; gfx950 correction of MI355X_MICROARCH.md (HBM section): FETCH_SIZE x2 for "
