@@ -178,7 +178,9 @@ int isx_last_kernel_ms(double* single_ms, double* trace_ms, double* bin_ms);
  *                  allocated once and kept until isx_shutdown(); "overlap" keeps three of them
  *   "assist"       1 (default): trace kernels with an assist wave per workgroup; 0: round 2's kernels;
  *                  "assist_block" = their workgroup size (128..768, default 768 = 11 tracer waves + 1 assist wave)
- *   "bin_slots"    1 (default): binning kernel with slot queues by window length (grids up to 256 x 255); 0: round 2's
+ *   "bin_slots"    1 (default): binning kernels with slot queues by window length (grids up to 256 x 255); 0: round 2's
+ *   "bin_cols"     1 (default): (line, COLUMN) slots for the pencil source, (line, row) slots for the BRDF source; 0: row slots
+ *                  everywhere; 2: column slots everywhere
  *   "bin_block", "bin_blocks_per_cu"  shape of round 2's binning kernel (0 workgroups per CU = what is resident)
  *   "ray_sub"      rays a wave takes off a launch's ray queue at a time (0 = default: 512, 256 for small launches)
  *   "overlap", "overlap_trace_streams"  cut a flux-map call into k chunks, binning of chunk i on a second stream while chunk
