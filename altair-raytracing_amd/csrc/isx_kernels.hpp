@@ -1021,7 +1021,10 @@ __device__ __forceinline__ void produce_packed(const D& d, uint32_t* __restrict_
 // cannot decide goes to the binary64 tier and the reference-order test of walk_columns, unchanged.  The rows of a column inside the
 // cap (angular radius w about the piercing point F, cos w = 1 - ch^2 / 2R^2): with a = cos theta_F, b = sin theta_F cos(phi - phi_F)
 // = (cph Fx + sph Fy)/R, the cap is a cos theta + b sin theta >= cos w, i.e. |theta - atan2(b, a)| <= acos(cos w / sqrt(a^2+b^2)).
-struct __align__(16) RowX { float S, C, T; uint32_t off4; };   // sin, cos, -R cos^2 of row i; byte offset of the row's bins
+// Two rows per walk step: entry i holds rows i and i+1 side by side, so that the four forms and g of BOTH candidates are packed
+// binary32 operations (8 + 4 v_pk instructions for two candidates where one at a time took 4 + 5 each).  A slot's row count is
+// made even (cap_rows); the row past the grid (i = n_theta: zeros) counts into a spare row of LDS bins that is never flushed.
+struct __align__(16) RowX { float S0, S1, C0, C1, T0, T1; uint32_t pad0, pad1; };   // sin, cos, -R cos^2 of rows i, i+1
 constexpr int kColPiece = 48, kColLongest = 64;
 __device__ __forceinline__ int col_class(int cnt) { return cnt <= 48 ? (cnt - 1) >> 3 : 6; }   // 1-8, 9-16, ..., 41-48, 49-64
 
@@ -1098,7 +1101,7 @@ __device__ __forceinline__ void cap_rows(float fx, float fy, float a, float cosw
   if (thi < 0.f || tlo > 1.57079637f) return;
   const int lo = max((int)floorf(tlo * inv_dth - 0.5f - 1e-3f), 0);
   const int hi = min((int)ceilf(thi * inv_dth - 0.5f + 1e-3f), n_theta - 1);
-  if (hi >= lo) { ilo = lo; cnt = hi - lo + 1; }
+  if (hi >= lo) { ilo = lo; cnt = (hi - lo + 2) & ~1; }   // an even number of rows (the walk takes two at a time; at most row n_theta)
 }
 
 // one pass: 64 column slots (record: line within the unit | column << 8 | first row << 16 | rows << 24), lane = slot
@@ -1109,7 +1112,7 @@ __device__ __forceinline__ void consume_cols(const D& d, uint32_t* __restrict__ 
   const int line = (int)(rec & 255u), j = (int)((rec >> 8) & 255u), ilo = (int)((rec >> 16) & 255u);
   const int len = active ? (int)(rec >> 24) : 0;
   const double* src6 = lines + 6 * line;
-  isx_f2 kA1 = {0.f, 0.f}, kA2 = {0.f, 0.f}, kB0 = {0.f, 0.f}, kB1 = {0.f, 0.f}, kB2 = {0.f, 0.f};
+  float cAl = 0.f, cBe = 0.f, cVz = 0.f, cQz = 0.f, cE0 = 0.f, cE1 = 0.f, cE2 = 0.f, cF0 = 0.f, cF1 = 0.f, cF2 = 0.f;
   float band32 = 0.f;
   if (len > 0) {
     V3 P, V;
@@ -1128,11 +1131,8 @@ __device__ __forceinline__ void consume_cols(const D& d, uint32_t* __restrict__ 
     const double e0 = -2.0 * fma(qx, V.x, fma(qy, V.y, qz * V.z));
     const double f0 = fma(qx, qx, fma(qy, qy, fma(qz, qz, R * R))) - d.half_w2;
     const double e1 = R2x * ga, e2 = -(R2x * V.z), f1 = -(R2x * de), f2 = R2x * qz;
-    kA1.x = (float)al; kA1.y = (float)be;
-    kA2.x = (float)(-V.z); kA2.y = (float)(-qz);
-    kB0.x = (float)e0; kB0.y = (float)f0;
-    kB1.x = (float)e1; kB1.y = (float)f1;
-    kB2.x = (float)e2; kB2.y = (float)f2;
+    cAl = (float)al; cBe = (float)be; cVz = (float)(-V.z); cQz = (float)(-qz);
+    cE0 = (float)e0; cF0 = (float)f0; cE1 = (float)e1; cF1 = (float)f1; cE2 = (float)e2; cF2 = (float)f2;
     const double Md = fabs(al) + fabs(V.z), Mn = fabs(be) + (fabs(qz) + R);
     const double Mv = fabs(e0) + (fabs(e1) + fabs(e2)), Mf = fabs(f0) + (fabs(f1) + fabs(f2));
     const double Sg = fma(Md, fma(Md, Mf, Mn * Mv), Mn * Mn);
@@ -1140,53 +1140,66 @@ __device__ __forceinline__ void consume_cols(const D& d, uint32_t* __restrict__ 
   }
   typedef __attribute__((address_space(3))) uint32_t LdsU32;
   typedef __attribute__((address_space(3))) unsigned char LdsByte;
-  LdsByte* const colbins = reinterpret_cast<LdsByte*>((__attribute__((address_space(3))) void*)hist) + (uint32_t)j * 4u;
+  const uint32_t row_bytes = (uint32_t)d.n_phi * 4u;
+  LdsByte* bin = reinterpret_cast<LdsByte*>((__attribute__((address_space(3))) void*)hist) + (uint32_t)j * 4u + (uint32_t)ilo * row_bytes;
   const RowX* rp = rowx + ilo;
+  const isx_f2 vAl = {cAl, cAl}, vBe = {cBe, cBe}, vVz = {cVz, cVz}, vQz = {cQz, cQz}, vE0 = {cE0, cE0}, vE1 = {cE1, cE1},
+               vE2 = {cE2, cE2}, vF0 = {cF0, cF0}, vF1 = {cF1, cF1}, vF2 = {cF2, cF2};
   if (len > 0) ISX_DIAG_ADD_LANES(7, len);
   ISX_DIAG_ADD(11, 1);
-  for (int k = 0;; ++k) {
+  for (int k = 0;; k += 2) {
     const bool act = k < len;
     if (__ballot(act) == 0ull) break;
-    ISX_DIAG_ADD(4, 1);
+    ISX_DIAG_ADD(4, 2);
     if (act) {
-      const RowX rx = *rp;
-      LdsByte* const bin = colbins + rx.off4;
-      const isx_f2 SS = {rx.S, rx.S}, CC = {rx.C, rx.C};
-      const isx_f2 ta = __builtin_elementwise_fma(kA1, SS, kA2 * CC);                                    // (dot, num - T)
-      const isx_f2 tb = __builtin_elementwise_fma(kB1, SS, __builtin_elementwise_fma(kB2, CC, kB0));     // (-2dv, ddw)
-      const float num = ta.y + rx.T;
-      const float g = fmaf(ta.x, fmaf(ta.x, tb.y, num * tb.x), num * num);
-      bool hit = g < 0.f;
-      if (!(fabsf(g) > band32)) {
+      const float4 sc = *reinterpret_cast<const float4*>(rp);
+      const float2 tt = *reinterpret_cast<const float2*>(&rp->T0);
+      const isx_f2 SS = {sc.x, sc.y}, CC = {sc.z, sc.w}, TT = {tt.x, tt.y};
+      const isx_f2 dot = __builtin_elementwise_fma(vAl, SS, vVz * CC);
+      const isx_f2 num = __builtin_elementwise_fma(vBe, SS, __builtin_elementwise_fma(vQz, CC, TT));
+      const isx_f2 mdv = __builtin_elementwise_fma(vE1, SS, __builtin_elementwise_fma(vE2, CC, vE0));
+      const isx_f2 ddw = __builtin_elementwise_fma(vF1, SS, __builtin_elementwise_fma(vF2, CC, vF0));
+      const isx_f2 g = __builtin_elementwise_fma(dot, __builtin_elementwise_fma(dot, ddw, num * mdv), num * num);
+      bool hit0 = g.x < 0.f, hit1 = g.y < 0.f;
+      if (!(fminf(fabsf(g.x), fabsf(g.y)) > band32)) {
         // tiers 2 and 3 of walk_columns (binary64 about the original point with its 2.1e-9 band, then the reference's own test)
-        ISX_DIAG_ADD_LANES(12, 1);
-        int ir = ilo + k;
-        asm volatile("" : "+v"(ir));
-        const double sd = rowt[4 * ir + 0], cd = rowt[4 * ir + 1], zz = rowt[4 * ir + 2], ad = rowt[4 * ir + 3];
-        int jr = j;
-        asm volatile("" : "+v"(jr));
-        const double cph = colx[jr].c, sph = colx[jr].s;
-        V3 P, V;
-        {
-          const double2* src = reinterpret_cast<const double2*>(src6 + (jr - j));
-          const double2 a = src[0], b = src[1], c = src[2];
-          P.x = a.x; P.y = a.y; P.z = b.x; V.x = b.y; V.y = c.x; V.z = c.y;
-        }
-        const double pz = P.z - zz;
-        const double dot = fma(sd * V.y, cph, fma(-(sd * V.x), sph, -(cd * V.z)));
-        const double numd = fma(sd * P.y, cph, fma(-(sd * P.x), sph, -(cd * pz)));
-        const double m2dv = fma(2.0 * (ad * V.x), cph, fma(2.0 * (ad * V.y), sph, -2.0 * fma(P.x, V.x, fma(P.y, V.y, pz * V.z))));
-        const double f0 = fma(P.x, P.x, fma(P.y, P.y, fma(ad, ad, pz * pz)));
-        const double f1c = -2.0 * (ad * P.x), f2c = -2.0 * (ad * P.y);
-        const double ddw = fma(f1c, cph, fma(f2c, sph, f0 - d.half_w2));
-        const double diff = fma(dot, fma(dot, ddw, numd * m2dv), numd * numd);
-        const double bandc = 2.1e-9 * fma(2.0, f0 + (fabs(f1c) + fabs(f2c)), d.half_w2);
-        hit = diff < 0.0;
-        if (fabs(dot) < 1e-4 || fabs(diff) <= bandc) {
-          ISX_DIAG_ADD_LANES(13, 1);
-          const double* tab = d.table;
-          asm volatile("" : "+v"(tab));
-          hit = check_intersection(tab + 6 * (size_t)(ir * d.n_phi + jr), d.half_w2, P, V);
+#pragma unroll 1
+        for (int t = 0; t < 2; ++t) {
+          const float gt = t == 0 ? g.x : g.y;
+          if (fabsf(gt) > band32) continue;
+          ISX_DIAG_ADD_LANES(12, 1);
+          int ir = ilo + k + t;
+          asm volatile("" : "+v"(ir));
+          bool hit = false;
+          if (ir < d.n_theta) {
+            const double sd = rowt[4 * ir + 0], cd = rowt[4 * ir + 1], zz = rowt[4 * ir + 2], ad = rowt[4 * ir + 3];
+            int jr = j;
+            asm volatile("" : "+v"(jr));
+            const double cph = colx[jr].c, sph = colx[jr].s;
+            V3 P, V;
+            {
+              const double2* src = reinterpret_cast<const double2*>(src6 + (jr - j));
+              const double2 a = src[0], b = src[1], c = src[2];
+              P.x = a.x; P.y = a.y; P.z = b.x; V.x = b.y; V.y = c.x; V.z = c.y;
+            }
+            const double pz = P.z - zz;
+            const double dotd = fma(sd * V.y, cph, fma(-(sd * V.x), sph, -(cd * V.z)));
+            const double numd = fma(sd * P.y, cph, fma(-(sd * P.x), sph, -(cd * pz)));
+            const double m2dv = fma(2.0 * (ad * V.x), cph, fma(2.0 * (ad * V.y), sph, -2.0 * fma(P.x, V.x, fma(P.y, V.y, pz * V.z))));
+            const double f0 = fma(P.x, P.x, fma(P.y, P.y, fma(ad, ad, pz * pz)));
+            const double f1c = -2.0 * (ad * P.x), f2c = -2.0 * (ad * P.y);
+            const double ddwd = fma(f1c, cph, fma(f2c, sph, f0 - d.half_w2));
+            const double diff = fma(dotd, fma(dotd, ddwd, numd * m2dv), numd * numd);
+            const double bandc = 2.1e-9 * fma(2.0, f0 + (fabs(f1c) + fabs(f2c)), d.half_w2);
+            hit = diff < 0.0;
+            if (fabs(dotd) < 1e-4 || fabs(diff) <= bandc) {
+              ISX_DIAG_ADD_LANES(13, 1);
+              const double* tab = d.table;
+              asm volatile("" : "+v"(tab));
+              hit = check_intersection(tab + 6 * (size_t)(ir * d.n_phi + jr), d.half_w2, P, V);
+            }
+          }
+          if (t == 0) hit0 = hit; else hit1 = hit;
         }
       }
 #ifdef ISX_DIAG
@@ -1195,12 +1208,17 @@ __device__ __forceinline__ void consume_cols(const D& d, uint32_t* __restrict__ 
         const double2* src = reinterpret_cast<const double2*>(src6);
         const double2 a = src[0], b = src[1], c = src[2];
         P.x = a.x; P.y = a.y; P.z = b.x; V.x = b.y; V.y = c.x; V.z = c.y;
-        const bool ref = check_intersection(d.table + 6 * (size_t)((ilo + k) * d.n_phi + j), d.half_w2, P, V);
-        if (ref != hit) ISX_DIAG_ADD_LANES(14, 1);
+        for (int t = 0; t < 2; ++t) {
+          if (ilo + k + t >= d.n_theta) continue;
+          const bool ref = check_intersection(d.table + 6 * (size_t)((ilo + k + t) * d.n_phi + j), d.half_w2, P, V);
+          if (ref != (t == 0 ? hit0 : hit1)) ISX_DIAG_ADD_LANES(14, 1);
+        }
       }
 #endif
-      rp++;
-      if (hit) __hip_atomic_fetch_add(reinterpret_cast<LdsU32*>(bin), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      rp += 2;
+      if (hit0) __hip_atomic_fetch_add(reinterpret_cast<LdsU32*>(bin), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      if (hit1) __hip_atomic_fetch_add(reinterpret_cast<LdsU32*>(bin + row_bytes), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      bin += 2u * row_bytes;
     }
   }
 }
@@ -2686,20 +2704,27 @@ isx_bin_cols_kernel(const DetGrid d_arg, const Work wk) {
   extern __shared__ __align__(16) unsigned char smem[];
   uint32_t* hist = reinterpret_cast<uint32_t*>(smem);
   const int nbins = d_arg.nbins;
-  const size_t off_row = ((size_t)nbins * 4 + 15) & ~(size_t)15;
+  const size_t off_row = ((size_t)(nbins + d_arg.n_phi) * 4 + 15) & ~(size_t)15;   // (+ the spare row of bins: never flushed)
   double* rowt = reinterpret_cast<double*>(smem + off_row);
   ColX* colx = reinterpret_cast<ColX*>(rowt + 4 * d_arg.n_theta);
   RowX* rowx = reinterpret_cast<RowX*>(colx + 2 * d_arg.n_phi);
-  DetGrid* d_lds = reinterpret_cast<DetGrid*>(rowx + d_arg.n_theta);
+  DetGrid* d_lds = reinterpret_cast<DetGrid*>(rowx + d_arg.n_theta + 1);
   uint32_t* wave_all = reinterpret_cast<uint32_t*>(d_lds + 1);
   const int tid = threadIdx.x, lane = tid & 63;
   const int nthr = (int)blockDim.x;
   for (int b = tid; b < nbins; b += nthr) hist[b] = 0u;
   for (int b = tid; b < 4 * d_arg.n_theta; b += nthr) rowt[b] = d_arg.rowtab[b];
-  for (int b = tid; b < d_arg.n_theta; b += nthr) {
+  for (int b = tid; b <= d_arg.n_theta; b += nthr) {
     RowX e;
-    const double sd = d_arg.rowtab[4 * b], cd = d_arg.rowtab[4 * b + 1];
-    e.S = (float)sd; e.C = (float)cd; e.T = (float)(-(d_arg.R * (cd * cd))); e.off4 = (uint32_t)(b * d_arg.n_phi) * 4u;
+    e.S0 = e.S1 = e.C0 = e.C1 = e.T0 = e.T1 = 0.f; e.pad0 = e.pad1 = 0u;
+    if (b < d_arg.n_theta) {
+      const double sd = d_arg.rowtab[4 * b], cd = d_arg.rowtab[4 * b + 1];
+      e.S0 = (float)sd; e.C0 = (float)cd; e.T0 = (float)(-(d_arg.R * (cd * cd)));
+    }
+    if (b + 1 < d_arg.n_theta) {
+      const double sd = d_arg.rowtab[4 * b + 4], cd = d_arg.rowtab[4 * b + 5];
+      e.S1 = (float)sd; e.C1 = (float)cd; e.T1 = (float)(-(d_arg.R * (cd * cd)));
+    }
     rowx[b] = e;
   }
   for (int b = tid; b < 2 * d_arg.n_phi; b += nthr) {
@@ -2734,8 +2759,8 @@ isx_bin_cols_kernel(const DetGrid d_arg, const Work wk) {
     const uint32_t q_first = (unit & 3u) * (kRegion / 4u);
     const uint32_t n_lines = r_lines < q_first + kRegion / 4u ? r_lines : q_first + kRegion / 4u;
     const double* lines = d_arg.rec_lines + 6ull * ((uint64_t)region * kRegion + q_first);   // the unit's lines
-    struct { int n_phi; double half_w2, portz, R; const double* table; } dcol;
-    dcol.n_phi = d.n_phi; dcol.half_w2 = d.half_w2; dcol.portz = d_arg.portz; dcol.R = d_arg.R; dcol.table = d.table;
+    struct { int n_phi, n_theta; double half_w2, portz, R; const double* table; } dcol;
+    dcol.n_phi = d.n_phi; dcol.n_theta = d.n_theta; dcol.half_w2 = d.half_w2; dcol.portz = d_arg.portz; dcol.R = d_arg.R; dcol.table = d.table;
 #pragma unroll 1
     for (uint32_t b0 = q_first; b0 < n_lines; b0 += 64u) {
       const bool have = b0 + (uint32_t)lane < n_lines;
