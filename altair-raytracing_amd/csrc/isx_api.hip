@@ -406,7 +406,7 @@ int enqueue(int sink, const isx_config* c, uint64_t n, uint64_t seed, uint64_t f
     // the binning kernel with slot queues (1024-thread workgroups: 61 KB of queues next to the histogram) if the grid fits its
     // 32-bit slot records and the LDS; else the one without
     const bool slots = S.bin_slots && S.bin_mode == 1 && d.n_theta <= 256 && d.n_phi <= 255 &&
-                       lds_tables + (size_t)(kBlock / 64) * kSlotWaveWords * 4 <= S.lds_limit;
+                       lds_tables + (size_t)(2 * d.n_phi) * sizeof(ColP) + (size_t)(kBlock / 64) * kSlotWaveWords * 4 <= S.lds_limit;
     // ... and with COLUMN slots for the pencil source (most lines on the fast path; the BRDF model's grazing lines are served
     // better by the row slots of isx_bin_slots_kernel)
     const bool cols = slots && S.bin_cols && (!brdf || S.bin_cols == 2) &&
@@ -415,7 +415,7 @@ int enqueue(int sink, const isx_config* c, uint64_t n, uint64_t seed, uint64_t f
     const BinFn bin_fn = cols ? isx_bin_cols_kernel : slots ? isx_bin_slots_kernel : isx_bin_lines_kernel;
     const int pblock = assist ? S.assist_block : S.trace_block, bblock = slots ? kBlock : S.bin_block;
     const size_t lds_bin = lds_tables + (cols ? (size_t)(d.n_theta + 1) * sizeof(RowX) + (size_t)d.n_phi * 4 + 16 + (size_t)(bblock / 64) * kColWaveWords * 4
-                                         : slots ? (size_t)(bblock / 64) * kSlotWaveWords * 4 : (size_t)(bblock / 64) * 128 * 4);
+                                         : slots ? (size_t)(2 * d.n_phi) * sizeof(ColP) + (size_t)(bblock / 64) * kSlotWaveWords * 4 : (size_t)(bblock / 64) * 128 * 4);
     if (lds_bin <= S.lds_limit) {
       const uint64_t chunk = n < S.pipe_chunk ? n : S.pipe_chunk;
       if (S.attr_lds[(const void*)rec_fn] != lds_trace) {   // (once per kernel and size, not once per launch)

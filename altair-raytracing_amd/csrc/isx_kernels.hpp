@@ -465,6 +465,121 @@ __device__ __forceinline__ void walk_columns(const D& d, uint32_t* __restrict__ 
   }
 }
 
+// Two columns per walk step (isx_bin_slots_kernel): entry b of the table holds columns b and b+1 (mod n_phi) side by side, so the
+// four forms and g of BOTH candidates are packed binary32 operations -- the same expressions in the same order as walk_columns,
+// hence the same error bound and band -- 12 v_pk instructions for two candidates where one at a time took 4 + 5 each.  The second
+// candidate of the last step of an odd window is masked.  Tiers 2 and 3 as in walk_columns, for whichever of the two needs them.
+struct __align__(16) ColP { float c0, c1, s0, s1; uint32_t off0, off1, pad0, pad1; };
+
+template <class D>
+__device__ __forceinline__ void walk_columns_pairs(const D& d, uint32_t* __restrict__ hist, const ColX* __restrict__ colx,
+                                                   const ColP* __restrict__ colp, double t0, int i, const double* __restrict__ rowt,
+                                                   int jlo, int len, const double* __restrict__ line6, int lane) {
+  float a0f = 0.f, a1f = 0.f, a2f = 0.f, b0f = 0.f, b1f = 0.f, b2f = 0.f, e0f = 0.f, e1f = 0.f, e2f = 0.f, f0f = 0.f, f1f = 0.f, f2f = 0.f;
+  float band32 = 0.f;
+  if (len > 0) {
+    V3 P, V;
+    {
+      const double2* src = reinterpret_cast<const double2*>(line6);
+      const double2 a = src[0], b = src[1], c = src[2];
+      P.x = a.x; P.y = a.y; P.z = b.x; V.x = b.y; V.y = c.x; V.z = c.y;
+    }
+    const double Sd = rowt[4 * i + 0], Cd = rowt[4 * i + 1], zd = rowt[4 * i + 2], Ad = rowt[4 * i + 3];
+    const double qx = fma(t0, V.x, P.x), qy = fma(t0, V.y, P.y), qz = fma(t0, V.z, P.z);   // Pq: same line, nearest to O
+    const double pz = qz - zd;
+    const double a0 = -(Cd * V.z), a1 = Sd * V.y, a2 = -(Sd * V.x);
+    const double b0 = -(Cd * pz), b1 = Sd * qy, b2 = -(Sd * qx);
+    const double e0 = -2.0 * fma(qx, V.x, fma(qy, V.y, pz * V.z)), e1 = 2.0 * (Ad * V.x), e2 = 2.0 * (Ad * V.y);
+    const double f0 = fma(qx, qx, fma(qy, qy, fma(Ad, Ad, pz * pz))) - d.half_w2, f1 = -2.0 * (Ad * qx), f2 = -2.0 * (Ad * qy);
+    a0f = (float)a0; a1f = (float)a1; a2f = (float)a2; b0f = (float)b0; b1f = (float)b1; b2f = (float)b2;
+    e0f = (float)e0; e1f = (float)e1; e2f = (float)e2; f0f = (float)f0; f1f = (float)f1; f2f = (float)f2;
+    const double Md = fabs(a0) + (fabs(a1) + fabs(a2)), Mn = fabs(b0) + (fabs(b1) + fabs(b2));
+    const double Mv = fabs(e0) + (fabs(e1) + fabs(e2)), Mf = fabs(f0) + (fabs(f1) + fabs(f2));
+    const double S = fma(Md, fma(Md, Mf, Mn * Mv), Mn * Mn);
+    band32 = S >= 1e-6 ? (float)(1.3e-6 * S) * 1.000001f + 1e-30f : __builtin_inff();
+    if (jlo < 0) jlo += d.n_phi;
+  }
+  const isx_f2 vA0 = {a0f, a0f}, vA1 = {a1f, a1f}, vA2 = {a2f, a2f}, vB0 = {b0f, b0f}, vB1 = {b1f, b1f}, vB2 = {b2f, b2f},
+               vE0 = {e0f, e0f}, vE1 = {e1f, e1f}, vE2 = {e2f, e2f}, vF0 = {f0f, f0f}, vF1 = {f1f, f1f}, vF2 = {f2f, f2f};
+  const ColP* cp = colp + jlo;
+  const uint32_t rowoff = (uint32_t)(i * d.n_phi) * 4u;
+  typedef __attribute__((address_space(3))) uint32_t LdsU32;
+  typedef __attribute__((address_space(3))) unsigned char LdsByte;
+  LdsByte* const rowbins = reinterpret_cast<LdsByte*>((__attribute__((address_space(3))) void*)hist) + rowoff;
+  if (len > 0) ISX_DIAG_ADD_LANES(7, len);
+  for (int k = 0;; k += 2) {
+    const bool act = k < len;
+    if (__ballot(act) == 0ull) break;
+    ISX_DIAG_ADD(4, 2);
+    if (act) {
+      const float4 cs = *reinterpret_cast<const float4*>(cp);
+      const uint2 off = *reinterpret_cast<const uint2*>(&cp->off0);
+      const bool two = k + 1 < len;
+      const isx_f2 CC = {cs.x, cs.y}, SS = {cs.z, cs.w};
+      const isx_f2 dot = __builtin_elementwise_fma(vA1, CC, __builtin_elementwise_fma(vA2, SS, vA0));
+      const isx_f2 num = __builtin_elementwise_fma(vB1, CC, __builtin_elementwise_fma(vB2, SS, vB0));
+      const isx_f2 mdv = __builtin_elementwise_fma(vE1, CC, __builtin_elementwise_fma(vE2, SS, vE0));
+      const isx_f2 ddw = __builtin_elementwise_fma(vF1, CC, __builtin_elementwise_fma(vF2, SS, vF0));
+      const isx_f2 g = __builtin_elementwise_fma(dot, __builtin_elementwise_fma(dot, ddw, num * mdv), num * num);
+      bool hit0 = g.x < 0.f, hit1 = g.y < 0.f;
+      if (!(fminf(fabsf(g.x), fabsf(g.y)) > band32)) {
+#pragma unroll 1
+        for (int t = 0; t < 2; ++t) {
+          const float gt = t == 0 ? g.x : g.y;
+          if (fabsf(gt) > band32 || (t == 1 && !two)) continue;
+          ISX_DIAG_ADD_LANES(12, 1);
+          int ir = i;
+          asm volatile("" : "+v"(ir));
+          const double sd = rowt[4 * ir + 0], cd = rowt[4 * ir + 1], zz = rowt[4 * ir + 2], ad = rowt[4 * ir + 3];
+          const uint32_t o4 = t == 0 ? off.x : off.y;
+          const int jc = (int)(o4 >> 2);
+          const double cph = colx[jc].c, sph = colx[jc].s;
+          V3 P, V;
+          {
+            const double2* src = reinterpret_cast<const double2*>(line6 + (ir - i));
+            const double2 a = src[0], b = src[1], c = src[2];
+            P.x = a.x; P.y = a.y; P.z = b.x; V.x = b.y; V.y = c.x; V.z = c.y;
+          }
+          const double pz = P.z - zz;
+          const double dotd = fma(sd * V.y, cph, fma(-(sd * V.x), sph, -(cd * V.z)));
+          const double numd = fma(sd * P.y, cph, fma(-(sd * P.x), sph, -(cd * pz)));
+          const double m2dv = fma(2.0 * (ad * V.x), cph, fma(2.0 * (ad * V.y), sph, -2.0 * fma(P.x, V.x, fma(P.y, V.y, pz * V.z))));
+          const double f0 = fma(P.x, P.x, fma(P.y, P.y, fma(ad, ad, pz * pz)));
+          const double f1c = -2.0 * (ad * P.x), f2c = -2.0 * (ad * P.y);
+          const double ddwd = fma(f1c, cph, fma(f2c, sph, f0 - d.half_w2));
+          const double diff = fma(dotd, fma(dotd, ddwd, numd * m2dv), numd * numd);
+          const double bandc = 2.1e-9 * fma(2.0, f0 + (fabs(f1c) + fabs(f2c)), d.half_w2);
+          bool hit = diff < 0.0;
+          if (fabs(dotd) < 1e-4 || fabs(diff) <= bandc) {
+            ISX_DIAG_ADD_LANES(13, 1);
+            const double* tab = d.table;
+            asm volatile("" : "+v"(tab));
+            hit = check_intersection(tab + 6 * (size_t)(ir * d.n_phi + jc), d.half_w2, P, V);
+          }
+          if (t == 0) hit0 = hit; else hit1 = hit;
+        }
+      }
+      hit1 = hit1 && two;
+#ifdef ISX_DIAG
+      {   // tuning builds: a decision taken by tier 1 must be the reference's
+        V3 P, V;
+        const double2* src = reinterpret_cast<const double2*>(line6);
+        const double2 a = src[0], b = src[1], c = src[2];
+        P.x = a.x; P.y = a.y; P.z = b.x; V.x = b.y; V.y = c.x; V.z = c.y;
+        for (int t = 0; t < (two ? 2 : 1); ++t) {
+          const int jc = (int)((t == 0 ? off.x : off.y) >> 2);
+          const bool ref = check_intersection(d.table + 6 * (size_t)(i * d.n_phi + jc), d.half_w2, P, V);
+          if (ref != (t == 0 ? hit0 : hit1)) ISX_DIAG_ADD_LANES(14, 1);
+        }
+      }
+#endif
+      cp += 2;
+      if (hit0) __hip_atomic_fetch_add(reinterpret_cast<LdsU32*>(rowbins + off.x), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      if (hit1) __hip_atomic_fetch_add(reinterpret_cast<LdsU32*>(rowbins + off.y), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
+  }
+}
+
 // angular radius of a cap of chord `ch` on the sphere of radius R: 2 asin(ch / 2R), padded (acos_cull: 1e-4 rad).  (Until
 // round 2 this was ch/R * 1.01 + 2e-3, which is below 2 asin(ch/2R) once ch > 0.55 R: detectors with rho_d > R/2 lost rows --
 // found by tools/soak_cull.py on 300 random geometries, 7 of them with rho_d/R >= 0.53; no BASELINE configuration has
@@ -811,6 +926,7 @@ struct SlotQueues {
   LdsWord* q;         // [kClasses][kQueueCap]
   LdsInt* tail;       // [8] slots pushed per class (running)
   LdsInt* head;       // [8] slots popped per class (running)
+  const ColP* colp;   // column-pair table of the workgroup (isx_bin_slots_kernel)
 };
 __device__ __forceinline__ int slot_class(int cnt) {   // cnt in 1..kLongest
   return cnt <= 4 ? 0 : (cnt <= 12 ? (cnt - 3) >> 1 : (cnt <= 16 ? 5 : 6));
@@ -824,16 +940,15 @@ __device__ __forceinline__ void consume_slots(const D& d, uint32_t* __restrict__
   const int line = (int)(rec & 255u), i = (int)((rec >> 8) & 255u), jlo = (int)((rec >> 16) & 255u);
   const int len = active ? (int)(rec >> 24) : 0;
   const double* src6 = lines + 6 * line;   // (an idle lane reads line 0 of the unit, which exists)
-  V3 P, V;
+  double t0 = 0.0;
   {
     const double2* src = reinterpret_cast<const double2*>(src6);
     const double2 a = src[0], b = src[1], c = src[2];
-    P.x = a.x; P.y = a.y; P.z = b.x; V.x = b.y; V.y = c.x; V.z = c.y;
+    t0 = -fma(a.x, b.y, fma(a.y, c.x, (b.x - d.portz) * c.y));
   }
-  const double t0 = -fma(P.x, V.x, fma(P.y, V.y, (P.z - d.portz) * V.z));
   ISX_DIAG_ADD(11, 1);
   ISX_BD_MARK(sq, 3);
-  walk_columns(d, hist, colx, P, V, t0, lane, i, rowt, jlo, 0, len, 0, src6);
+  walk_columns_pairs(d, hist, colx, sq.colp, t0, i, rowt, jlo, len, src6, lane);
   ISX_BD_MARK(sq, 4);
 }
 
@@ -2599,7 +2714,8 @@ isx_bin_slots_kernel(const DetGrid d_arg, const Work wk) {
   const size_t off_row = ((size_t)nbins * 4 + 15) & ~(size_t)15;
   double* rowt = reinterpret_cast<double*>(smem + off_row);
   ColX* colx = reinterpret_cast<ColX*>(rowt + 4 * d_arg.n_theta);
-  DetGrid* d_lds = reinterpret_cast<DetGrid*>(colx + 2 * d_arg.n_phi);
+  ColP* colp = reinterpret_cast<ColP*>(colx + 2 * d_arg.n_phi);
+  DetGrid* d_lds = reinterpret_cast<DetGrid*>(colp + 2 * d_arg.n_phi);
   uint32_t* wave_all = reinterpret_cast<uint32_t*>(d_lds + 1);
   const int tid = threadIdx.x, lane = tid & 63;
   const int nthr = (int)blockDim.x;
@@ -2607,14 +2723,20 @@ isx_bin_slots_kernel(const DetGrid d_arg, const Work wk) {
   for (int b = tid; b < 4 * d_arg.n_theta; b += nthr) rowt[b] = d_arg.rowtab[b];
   for (int b = tid; b < 2 * d_arg.n_phi; b += nthr) {
     const int j = b < d_arg.n_phi ? b : b - d_arg.n_phi;
+    const int j1 = j + 1 < d_arg.n_phi ? j + 1 : 0;
     ColX e;
     e.c = d_arg.coltab[2 * j]; e.s = d_arg.coltab[2 * j + 1]; e.off4 = (uint32_t)j * 4u; e.c32 = (float)e.c; e.s32 = (float)e.s; e.pad = 0u;
     colx[b] = e;
+    ColP q;
+    q.c0 = e.c32; q.s0 = e.s32; q.c1 = (float)d_arg.coltab[2 * j1]; q.s1 = (float)d_arg.coltab[2 * j1 + 1];
+    q.off0 = (uint32_t)j * 4u; q.off1 = (uint32_t)j1 * 4u; q.pad0 = q.pad1 = 0u;
+    colp[b] = q;
   }
   if (tid == (nthr > 128 ? 128 : 0)) *d_lds = d_arg;
   // per wave: the class queues, their 8 + 8 counters, 64 owner marks (kSlotWaveWords 32-bit words)
   uint32_t* mine = wave_all + (size_t)(tid >> 6) * kSlotWaveWords;
   SlotQueues sq;
+  sq.colp = colp;
   sq.q = (LdsWord*)mine;
   sq.tail = (LdsInt*)(mine + kClasses * kQueueCap);
   sq.head = sq.tail + 8;
@@ -2737,6 +2859,7 @@ isx_bin_cols_kernel(const DetGrid d_arg, const Work wk) {
   // per wave: the class queues, their 8 + 8 counters, 64 owner marks, 64 ints of long-row list for bin_culled
   uint32_t* mine = wave_all + (size_t)(tid >> 6) * kColWaveWords;
   SlotQueues sq;
+  sq.colp = nullptr;
   sq.q = (LdsWord*)mine;
   sq.tail = (LdsInt*)(mine + kClasses * kQueueCap);
   sq.head = sq.tail + 8;
