@@ -1137,8 +1137,10 @@ __device__ __forceinline__ void produce_packed(const D& d, uint32_t* __restrict_
 // cap (angular radius w about the piercing point F, cos w = 1 - ch^2 / 2R^2): with a = cos theta_F, b = sin theta_F cos(phi - phi_F)
 // = (cph Fx + sph Fy)/R, the cap is a cos theta + b sin theta >= cos w, i.e. |theta - atan2(b, a)| <= acos(cos w / sqrt(a^2+b^2)).
 // Two rows per walk step: entry i holds rows i and i+1 side by side, so that the four forms and g of BOTH candidates are packed
-// binary32 operations (8 + 4 v_pk instructions for two candidates where one at a time took 4 + 5 each).  A slot's row count is
-// made even (cap_rows); the row past the grid (i = n_theta: zeros) counts into a spare row of LDS bins that is never flushed.
+// binary32 operations (8 + 4 v_pk instructions for two candidates where one at a time took 4 + 5 each).  The second candidate of
+// the last step of a slot with an odd row count is masked (NOT made a real candidate: one more row could reach into the range the
+// line's other cap holds in the same column, and the bin would count twice -- tools/soak_cull.py found exactly that on 2- and
+// 3-row grids); the table has a spare zero entry so that the last pair of the grid can be read.
 struct __align__(16) RowX { float S0, S1, C0, C1, T0, T1; uint32_t pad0, pad1; };   // sin, cos, -R cos^2 of rows i, i+1
 constexpr int kColPiece = 48, kColLongest = 64;
 __device__ __forceinline__ int col_class(int cnt) { return cnt <= 48 ? (cnt - 1) >> 3 : 6; }   // 1-8, 9-16, ..., 41-48, 49-64
@@ -1214,9 +1216,10 @@ __device__ __forceinline__ void cap_rows(float fx, float fy, float a, float cosw
   const float tc = atan2_cull(b, a);
   const float tlo = tc - dl, thi = tc + dl;
   if (thi < 0.f || tlo > 1.57079637f) return;
-  const int lo = max((int)floorf(tlo * inv_dth - 0.5f - 1e-3f), 0);
-  const int hi = min((int)ceilf(thi * inv_dth - 0.5f + 1e-3f), n_theta - 1);
-  if (hi >= lo) { ilo = lo; cnt = (hi - lo + 2) & ~1; }   // an even number of rows (the walk takes two at a time; at most row n_theta)
+  // rows whose centre (i + 1/2) dtheta lies in [tlo, thi] (1e-3 of a row of slack on top of the 2.5e-3 rad above)
+  const int lo = max((int)ceilf(tlo * inv_dth - 0.5f - 1e-3f), 0);
+  const int hi = min((int)floorf(thi * inv_dth - 0.5f + 1e-3f), n_theta - 1);
+  if (hi >= lo) { ilo = lo; cnt = hi - lo + 1; }
 }
 
 // one pass: 64 column slots (record: line within the unit | column << 8 | first row << 16 | rows << 24), lane = slot
@@ -1269,6 +1272,7 @@ __device__ __forceinline__ void consume_cols(const D& d, uint32_t* __restrict__ 
     if (act) {
       const float4 sc = *reinterpret_cast<const float4*>(rp);
       const float2 tt = *reinterpret_cast<const float2*>(&rp->T0);
+      const bool two = k + 1 < len;
       const isx_f2 SS = {sc.x, sc.y}, CC = {sc.z, sc.w}, TT = {tt.x, tt.y};
       const isx_f2 dot = __builtin_elementwise_fma(vAl, SS, vVz * CC);
       const isx_f2 num = __builtin_elementwise_fma(vBe, SS, __builtin_elementwise_fma(vQz, CC, TT));
@@ -1281,12 +1285,12 @@ __device__ __forceinline__ void consume_cols(const D& d, uint32_t* __restrict__ 
 #pragma unroll 1
         for (int t = 0; t < 2; ++t) {
           const float gt = t == 0 ? g.x : g.y;
-          if (fabsf(gt) > band32) continue;
+          if (fabsf(gt) > band32 || (t == 1 && !two)) continue;
           ISX_DIAG_ADD_LANES(12, 1);
           int ir = ilo + k + t;
           asm volatile("" : "+v"(ir));
           bool hit = false;
-          if (ir < d.n_theta) {
+          {
             const double sd = rowt[4 * ir + 0], cd = rowt[4 * ir + 1], zz = rowt[4 * ir + 2], ad = rowt[4 * ir + 3];
             int jr = j;
             asm volatile("" : "+v"(jr));
@@ -1317,14 +1321,14 @@ __device__ __forceinline__ void consume_cols(const D& d, uint32_t* __restrict__ 
           if (t == 0) hit0 = hit; else hit1 = hit;
         }
       }
+      hit1 = hit1 && two;
 #ifdef ISX_DIAG
       {   // tuning builds: a decision taken by tier 1 must be the reference's
         V3 P, V;
         const double2* src = reinterpret_cast<const double2*>(src6);
         const double2 a = src[0], b = src[1], c = src[2];
         P.x = a.x; P.y = a.y; P.z = b.x; V.x = b.y; V.y = c.x; V.z = c.y;
-        for (int t = 0; t < 2; ++t) {
-          if (ilo + k + t >= d.n_theta) continue;
+        for (int t = 0; t < (two ? 2 : 1); ++t) {
           const bool ref = check_intersection(d.table + 6 * (size_t)((ilo + k + t) * d.n_phi + j), d.half_w2, P, V);
           if (ref != (t == 0 ? hit0 : hit1)) ISX_DIAG_ADD_LANES(14, 1);
         }
@@ -1388,7 +1392,7 @@ __device__ __forceinline__ void produce_cols_packed(const D& d, uint32_t* __rest
                                                     const ColX* __restrict__ colx, const RowX* __restrict__ rowx,
                                                     const double* __restrict__ lines, const SlotQueues& sq, const ColPre& pre,
                                                     int excl, int incl, int total, float inv_dth, int n_theta, int first_line,
-                                                    int lane, LdsInt* mark) {
+                                                    int lane, LdsInt* mark, const ColPre& pre0, bool second) {
 #pragma unroll 1
   for (int base = 0; base < total; base += 64) {
     const int g = base + lane;
@@ -1410,7 +1414,26 @@ __device__ __forceinline__ void produce_cols_packed(const D& d, uint32_t* __rest
     if (!have) j = 0;
     int ilo = 0, cnt = 0;
     if (have) cap_rows(fx, fy, a, cw, colx[j].c32, colx[j].s32, inv_dth, n_theta, ilo, cnt);
+    int ilo_b = 0, cnt_b = 0;
+    if (second) {
+      // the line's second cap: never a bin that its first cap already holds in this column (the two caps are disjoint as
+      // constructed, but each row range carries slack and is rounded to whole rows -- on a coarse grid they can meet), so the rows
+      // the first cap took for column j, recomputed exactly as they were pushed, are cut out; what is left is at most two pieces
+      const int jlo0 = __shfl(pre0.jlo, owner, 64), ncol0 = __shfl(pre0.kind == 0 ? pre0.ncol : 0, owner, 64);
+      const float fx0 = __shfl(pre0.fx, owner, 64), fy0 = __shfl(pre0.fy, owner, 64), a0 = __shfl(pre0.a, owner, 64), cw0 = __shfl(pre0.cosw, owner, 64);
+      int dj = j - jlo0;
+      if (dj < 0) dj += d.n_phi;
+      int i0 = 0, c0 = 0;
+      if (have && cnt > 0 && dj < ncol0) cap_rows(fx0, fy0, a0, cw0, colx[j].c32, colx[j].s32, inv_dth, n_theta, i0, c0);
+      if (c0 > 0) {
+        const int hi = ilo + cnt - 1, hi0 = i0 + c0 - 1;
+        const int a_hi = min(hi, i0 - 1), b_lo = max(ilo, hi0 + 1);
+        cnt = a_hi >= ilo ? a_hi - ilo + 1 : 0;
+        ilo_b = b_lo; cnt_b = hi >= b_lo ? hi - b_lo + 1 : 0;
+      }
+    }
     push_cols(d, hist, rowt, colx, rowx, lines, sq, first_line + owner, j, ilo, cnt, lane);
+    if (second && __ballot(cnt_b > 0) != 0ull) push_cols(d, hist, rowt, colx, rowx, lines, sq, first_line + owner, j, ilo_b, cnt_b, lane);
   }
 }
 
@@ -2826,7 +2849,7 @@ isx_bin_cols_kernel(const DetGrid d_arg, const Work wk) {
   extern __shared__ __align__(16) unsigned char smem[];
   uint32_t* hist = reinterpret_cast<uint32_t*>(smem);
   const int nbins = d_arg.nbins;
-  const size_t off_row = ((size_t)(nbins + d_arg.n_phi) * 4 + 15) & ~(size_t)15;   // (+ the spare row of bins: never flushed)
+  const size_t off_row = ((size_t)nbins * 4 + 15) & ~(size_t)15;
   double* rowt = reinterpret_cast<double*>(smem + off_row);
   ColX* colx = reinterpret_cast<ColX*>(rowt + 4 * d_arg.n_theta);
   RowX* rowx = reinterpret_cast<RowX*>(colx + 2 * d_arg.n_phi);
@@ -2915,6 +2938,7 @@ isx_bin_cols_kernel(const DetGrid d_arg, const Work wk) {
       }
       // lines with caps: the columns of their caps packed over the lanes -- side 0 (every fast-path line has only this one),
       // then side 1 for the few lines whose second piercing point lies low enough to reach detector rows
+      const ColPre pre_first = pre;
 #pragma unroll 1
       for (int side = 0; side < 2; ++side) {
         if (side == 1) {
@@ -2936,7 +2960,8 @@ isx_bin_cols_kernel(const DetGrid d_arg, const Work wk) {
         if (side == 0) { const int n_fast = (int)__popcll(__ballot(ncol > 0)); (void)n_fast; ISX_DIAG_ADD(0, n_fast); }
         ColPre pc = pre;
         pc.ncol = ncol;
-        produce_cols_packed(dcol, hist, rowt, colx, rowx, lines, sq, pc, incl - ncol, incl, total, k.inv_dth, k.n_theta, first_line, lane, mrk);
+        produce_cols_packed(dcol, hist, rowt, colx, rowx, lines, sq, pc, incl - ncol, incl, total, k.inv_dth, k.n_theta, first_line, lane, mrk,
+                            pre_first, side == 1);
       }
     }
     drain_cols(dcol, hist, rowt, colx, rowx, lines, sq, 1, lane);   // the unit's leftovers, class by class

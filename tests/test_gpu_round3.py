@@ -141,3 +141,33 @@ def test_disc_sweep_through_the_pipeline_is_bit_identical(isx, orc):
     finally:
         isx.set_option("disc_pipeline", 1)
         _reset(isx)
+
+
+@pytest.mark.parametrize("geo", [
+    dict(theta_max_deg=166.64868373391164, src=(14.515267789403936, 2.6443760109199417, 5.036017082011327),
+         dir=(2.633429897675303, 0.9605206310283019, -0.3305440463372138), n_theta=2, n_phi=123, det_distance=60.0, det_diameter=96.0,
+         box_half=200.0, seed=5122),
+    dict(theta_max_deg=152.21400311733407, src=(-47.372837775049476, -14.211074070524853, 30.24086134331928),
+         dir=(2.2308353220244728, -2.458082952769151, 0.8256848368289251), n_theta=3, n_phi=70, det_distance=30.0, det_diameter=3.0,
+         box_half=300.0, seed=5170)])
+def test_two_row_walk_never_counts_a_bin_twice(isx, geo):
+    """Regression (tools/soak_cull.py 250 777, geometries 122 and 170): the two-rows-per-step walk of the column-slot kernel once
+    padded odd slots with a REAL row, which on a 2- or 3-row grid lay inside the column range of the line's other cap."""
+    c = isx.default_config()
+    c.theta_max_deg = geo["theta_max_deg"]; c.reflectance = 0.9; c.max_points = 3000; c.trace_mode = 1
+    for k in range(3):
+        c.src[k] = geo["src"][k]; c.dir[k] = geo["dir"][k]
+    c.n_theta, c.n_phi = geo["n_theta"], geo["n_phi"]
+    c.det_distance, c.det_diameter, c.exit_port_z, c.box_half = geo["det_distance"], geo["det_diameter"], -99.0, geo["box_half"]
+    try:
+        isx.set_option("bin_mode", 0)
+        brute, sb = isx.fluxmap(c, 100000, geo["seed"])
+        isx.set_option("bin_mode", 1)
+        for cols in (1, 2, 0):
+            isx.set_option("bin_cols", cols)
+            culled, sc = isx.fluxmap(c, 100000, geo["seed"])
+            assert np.array_equal(brute, culled), cols
+            _same(sb, sc)
+    finally:
+        isx.set_option("bin_mode", 1)
+        _reset(isx)
