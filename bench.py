@@ -286,10 +286,11 @@ def main():
 
         def issue_block(kernel, live_ms, pk):
             """VALU-issue roofline of one kernel: executed SQ_INSTS_VALU per ray (its PMC pass) x rays / its LIVE time.
-            `frac` charges every wave64 VALU instruction 4 cycles (the convention of rounds 1-2; it exceeds what a mixed stream
-            can reach, so a saturated kernel reads ~1); `frac_mix` prices the executed mix by class (f64 4 cycles, 32-bit 2,
-            v_mad_u64_u32 7, f64 rcp/rsq 16: tools/summarize_profile.py) against 1024 SIMDs x 2.4 GHz; `valu_busy` is the
-            counter that says whether the VALU had idle cycles at all."""
+            `peak` / `frac` price the executed mix by class (f64 4 cycles, 32-bit 2, v_mad_u64_u32 7, f64 rcp/rsq 16, a packed
+            f32 instruction 2: tools/summarize_profile.py) against 1024 SIMDs x 2.4 GHz -- `peak` is the wave-instruction rate this
+            mix could issue at best, `frac` = achieved / peak (= `frac_mix`); `frac_4cycle` / `peak_4cycle` charge every instruction 4
+            cycles (the convention of rounds 1-2: a mixed stream can exceed it, so a saturated kernel reads > 1); `valu_busy` is
+            the counter that says whether the VALU had idle cycles at all."""
             blk = {"bound": "valu_issue", "kernel": kernel, "kernel_ms": live_ms, "peak": peak_issue, "unit": "G wave-instr/s",
                    "achieved": None, "frac": None, "traffic": (pk or {}).get("hbm_bytes_per_launch")}
             if pk and pk.get("valu_wave_insts_per_ray") and live_ms > 0:
@@ -299,8 +300,10 @@ def main():
                            profiled_kernel_ms=pk.get("kernel_ms"), profiled_clock_ghz=pk.get("clock_ghz"))
                 mix = pk.get("issue_mix")
                 if mix:
-                    blk.update(peak_mix_cycles_per_ray=mix["cycles_per_ray"],
-                               frac_mix=mix["cycles_per_ray"] * n / (cus * 4 * VALU_CLOCK_GHZ * 1e9 * live_ms * 1e-3))
+                    # the roofline proper: what THIS instruction mix can issue per second (peak), against what it did (achieved)
+                    fm = mix["cycles_per_ray"] * n / (cus * 4 * VALU_CLOCK_GHZ * 1e9 * live_ms * 1e-3)
+                    blk.update(peak_mix_cycles_per_ray=mix["cycles_per_ray"], frac_mix=fm, frac_4cycle=ach / peak_issue,
+                               peak_4cycle=peak_issue, peak=ach / fm, frac=fm)
             return blk
 
         kern = pj.get("kernels", {})
@@ -314,8 +317,10 @@ def main():
         else:
             dominant, other = issue_block("isx_trace_bin_kernel", t_single or k_ms, pj if not kern else None), None
         dominant["note"] = (f"binding resource: VALU issue (no MFMA, HBM idle).  achieved = executed SQ_INSTS_VALU per ray from "
-                            f"{pmc_note} x rays / the kernel's live time (HIP events on the library's stream); peak = {cus} CUs x 4 "
-                            f"SIMDs x {VALU_CLOCK_GHZ} GHz / 4 cycles; traffic = HBM bytes per launch (FETCH_SIZE + WRITE_SIZE passes)")
+                            f"{pmc_note} x rays / the kernel's live time (HIP events on the library's stream); peak = the rate at which "
+                            f"{cus} CUs x 4 SIMDs x {VALU_CLOCK_GHZ} GHz can issue THIS kernel's executed instruction mix (cycles per class in "
+                            f"tools/summarize_profile.py; peak_4cycle: 4 cycles for every instruction); traffic = HBM bytes per launch "
+                            f"(FETCH_SIZE + WRITE_SIZE passes)")
         out = {
             "metric": "Mrays/sec whole-node, 180x90 fluxmap src(-60,0,-75); achieved HBM GB/s vs peak",
             "value": value, "unit": "Mrays/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
