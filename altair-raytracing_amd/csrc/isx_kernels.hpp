@@ -574,6 +574,8 @@ __device__ __forceinline__ void walk_columns_pairs(const D& d, uint32_t* __restr
       }
 #endif
       cp += 2;
+      // (the column-slot walk adds 0 or 1 without a branch; here, on the BRDF source, that was measured slower -- 50.8 -> 51.4 ms:
+      //  this kernel is VALU-bound and two thirds of its candidates are misses)
       if (hit0) __hip_atomic_fetch_add(reinterpret_cast<LdsU32*>(rowbins + off.x), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
       if (hit1) __hip_atomic_fetch_add(reinterpret_cast<LdsU32*>(rowbins + off.y), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     }
@@ -1335,8 +1337,11 @@ __device__ __forceinline__ void consume_cols(const D& d, uint32_t* __restrict__ 
       }
 #endif
       rp += 2;
-      if (hit0) __hip_atomic_fetch_add(reinterpret_cast<LdsU32*>(bin), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-      if (hit1) __hip_atomic_fetch_add(reinterpret_cast<LdsU32*>(bin + row_bytes), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      // (0 or 1 added without a branch: two exec-mask branches less per step, 7.30 -> 7.02 ms.  The masked half of an odd slot's last
+      //  pair adds 0 one row further -- at most the row past the grid, i.e. the first n_phi words of the row table that follows the
+      //  bins in LDS: an atomic add of zero, no bit changes)
+      __hip_atomic_fetch_add(reinterpret_cast<LdsU32*>(bin), hit0 ? 1u : 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      __hip_atomic_fetch_add(reinterpret_cast<LdsU32*>(bin + row_bytes), hit1 ? 1u : 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
       bin += 2u * row_bytes;
     }
   }
