@@ -127,6 +127,8 @@ int prepare_geom(const isx_config* c, Geom* g) {
     const double x = std::ldexp(c->reflectance, 32) - 0.5;
     g->rho_thr = !(x > 0.0) ? 0ull : (x >= 4294967296.0 ? 4294967296ull : (unsigned long long)std::ceil(x));
     g->inv_thr = g->rho_thr ? 1.0 / (double)g->rho_thr : 0.0;
+    g->psi_k1 = g->inv_thr * 1.57079632679489655800e+00;
+    g->psi_k0 = (0.5 * g->inv_thr - 0.5) * 1.57079632679489655800e+00;
   }
   g->sigma = c->roughness_rad;
   g->lambertian = c->lambertian;

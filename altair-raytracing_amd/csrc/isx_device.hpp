@@ -33,7 +33,8 @@ struct Geom {
   int chord, pad2;          // ISX_TRACE_CHORD; sched_*: generic-search batching, flush when (iter & mask) == mask or >= min lanes parked
   double r_in;
   unsigned long long rho_thr;  // absorb test on the raw Philox word: (w + 0.5) 2^-32 < rho  <=>  w < rho_thr (exact, see prepare_geom)
-  double inv_thr;              // 1 / rho_thr: the surviving word, rescaled, is the azimuth's uniform
+  double inv_thr;              // 1 / rho_thr: the surviving word b, rescaled, is the azimuth's uniform u2 = (b + 1/2) / rho_thr
+  double psi_k1, psi_k0;       // circle_point_psi's angle straight from the word: psi = (u2 - 1/2) pi/2 = fma(b, psi_k1, psi_k0)
   // The pencil source starts every ray at the same point in the same direction, so the first boundary is one point for the
   // whole launch: the persistent kernels find it once per workgroup (next_hit_s1<true> on the source itself, the arithmetic
   // every ray would repeat) and keep it in their LDS copy of this block.  q0_ok = 0: rule S1 does not apply to the source
@@ -46,13 +47,13 @@ struct Geom {
 // on demand from an LDS copy (a `const volatile Geom&`), so it never occupies scalar registers
 // across the loop (SGPR spills were >10 % of the issued instructions before this split).
 struct Hot {
-  double zcut_in, ninv_rin, r_in, inv_thr;
+  double zcut_in, ninv_rin, r_in, psi_k1, psi_k0;
   unsigned long long rho_thr;
   int lambertian, limit, source_model, surface_model, chord;
 };
 __device__ __forceinline__ Hot make_hot(const Geom& g) {
   Hot h;
-  h.zcut_in = g.zcut_in; h.ninv_rin = g.ninv_rin; h.rho_thr = g.rho_thr; h.inv_thr = g.inv_thr;
+  h.zcut_in = g.zcut_in; h.ninv_rin = g.ninv_rin; h.rho_thr = g.rho_thr; h.psi_k1 = g.psi_k1; h.psi_k0 = g.psi_k0;
   h.lambertian = g.lambertian; h.limit = g.limit; h.source_model = g.source_model; h.surface_model = g.surface_model;
   h.r_in = g.r_in; h.chord = g.chord;
   return h;
@@ -117,8 +118,8 @@ __device__ __forceinline__ void bounce_words(uint64_t seed, uint64_t ray, uint32
 __device__ __forceinline__ double u01(uint32_t w) { return ((double)w + 0.5) * 0x1.0p-32; }
 
 // ---------------------------------------------------------------- elementary functions
-// IEEE sqrt and 1/x for operands KNOWN to be normal and far from the exponent limits (u in [2^-33,1), 1-u,
-// sg+n.z in +-[1,2]).  The arithmetic is the compiler's own f64 expansion (v_rsq/v_rcp seed, Goldschmidt/Newton
+// IEEE sqrt and 1/x for operands KNOWN to be normal and far from the exponent limits (1 - z^2 in [2^-31, 1]; the squared
+// length of an emitted direction n + s, in [~1e-32, 4]).  The arithmetic is the compiler's own f64 expansion (v_rsq/v_rcp seed, Goldschmidt/Newton
 // steps in fma, final residual correction) without the range scaling and special-case fix-ups those operands
 // never need, so the results are the correctly rounded ones -- checked against the CPU over the whole input
 // family in tests/test_gpu_parity.py::test_unit_range_sqrt_rcp_are_ieee.
@@ -187,20 +188,23 @@ __device__ __forceinline__ void sincos2pi(double u, double& s, double& c) {
   const double x = r * PIO2;
   quadrant((int)kd, kern_sin(x), kern_cos(x), s, c);
 }
-// Uniform point of the unit circle from u in (0,1) (same construction as the test oracle): psi = (u - 1/2) pi/2 in (-pi/4, pi/4),
-// polynomial kernels without quadrant logic, two angle doublings.  25 instructions where sincos2pi takes 45.
-__device__ __forceinline__ void circle_point(double u, double& c, double& s) {
-  const double PIO2 = sconst(1.57079632679489655800e+00);
+// Uniform point of the unit circle (same construction as the test oracle): psi in (-pi/4, pi/4), polynomial kernels without
+// quadrant logic, two angle doublings.  23 instructions where sincos2pi takes 45.
+__device__ __forceinline__ void circle_point_psi(double psi, double& c, double& s) {
   const double C1 = sconst(4.16666666666666019037e-02), C2 = sconst(-1.38888888888741095749e-03),
                C3 = sconst(2.48015872894767294178e-05), C4 = sconst(-2.75573143513906633035e-07),
                C5 = sconst(2.08757232129817482790e-09), C6 = sconst(-1.13596475577881948265e-11);
-  const double psi = (u - 0.5) * PIO2;
   const double z = psi * psi;
   const double sn = kern_sin(psi);
   const double cs = fma(z, fma(z, fma(z, fma(z, fma(z, fma(z, fma(z, C6, C5), C4), C3), C2), C1), -0.5), 1.0);
   const double c2 = fma(cs, cs, -(sn * sn)), s2 = fma(cs, sn, cs * sn);
   c = fma(c2, c2, -(s2 * s2));
   s = fma(c2, s2, c2 * s2);
+}
+// the same from u in (0,1): psi = (u - 1/2) pi/2
+__device__ __forceinline__ void circle_point(double u, double& c, double& s) {
+  const double PIO2 = sconst(1.57079632679489655800e+00);
+  circle_point_psi((u - 0.5) * PIO2, c, s);
 }
 __device__ __forceinline__ void sincos_cw(double x, double& s, double& c) {
   const double INVPIO2 = sconst(6.36619772367581382433e-01);
@@ -327,10 +331,10 @@ __device__ inline int next_hit_generic(const G& gg, const V3 p, const V3 v, cons
 }
 
 // Rules S1/S1' alone: returns true (and q) if the far root of the inner sphere is the hit.
-// S1' (the bounce-to-bounce case): on the inner sphere heading inwards the far root is -2b - the root of
-// t^2 + 2bt = 0 since p is on the sphere and |v| = 1 to rounding - so the hot path needs no square root
-// (an IEEE f64 sqrt costs ~91 cycles per wave here).  If the generic search has to take over it re-derives
-// the same -2b first, so both routes always agree.
+// S1' (the bounce-to-bounce case): leaving a point p of the inner sphere inwards (p.v < 0) the ray meets the sphere again at
+// t = -2 (p.v)/(v.v) - the non-zero root of |p + t v|^2 = |p|^2 for a direction of ANY length - so the hot path needs
+// neither a square root nor a unit vector: the cosine emission hands over n + s un-normalised (interact()).  A ray that
+// leaves the rule gets a unit direction (unit_dir) before the generic search; the oracle takes the same two steps.
 // FIRST: also the first segment of a ray (on == K_NONE: starts inside the ball; needs rin2 and a square root).  The
 // persistent kernels pass FIRST only on step 0 of a loop trip -- rays start there -- and read rin2 from the LDS copy of
 // the geometry when they need it; a case this function does not take simply falls to the generic search.
@@ -339,7 +343,8 @@ __device__ __forceinline__ bool next_hit_s1(const Hot& h, const G& g, const V3& 
   const double b = dot3(p, v);
   if (on == K_INNER) {
     if (!(b < 0.0)) return false;
-    const V3 q = axpy(-2.0 * b, v, p);
+    const double ia = neg_rcp_unit(dot3(v, v));
+    const V3 q = axpy((2.0 * b) * ia, v, p);
     if (q.z >= h.zcut_in) { q_out = q; return true; }
     return false;
   }
@@ -356,9 +361,15 @@ __device__ __forceinline__ bool next_hit_s1(const Hot& h, const G& g, const V3& 
 }
 
 // Rule S1 first (hot path); anything else falls to the generic search (which re-derives the same numbers).
+// unit vector of v (three divisions by the length, as the oracle's unit_dir): what a direction becomes when the ray leaves rule S1'
+__device__ __forceinline__ void unit_dir(V3& v) {
+  const double mag = sqrt(dot3(v, v));
+  v.x = v.x / mag; v.y = v.y / mag; v.z = v.z / mag;
+}
 template <class G>
-__device__ __forceinline__ int next_hit(const Hot& h, const G& g, const V3& p, const V3& v, const int on, V3& q_out) {
+__device__ __forceinline__ int next_hit(const Hot& h, const G& g, const V3& p, V3& v, const int on, V3& q_out) {
   if (next_hit_s1<true>(h, g, p, v, on, q_out)) return K_INNER;
+  if (on == K_INNER) unit_dir(v);
   return next_hit_generic(g, p, v, on, q_out);
 }
 // ---------------------------------------------------------------- TVector3 arithmetic in ROOT's own op order (no fma)
@@ -456,12 +467,14 @@ __device__ __forceinline__ V3 surface_normal(const Hot& h, const G& g, int kind,
 // emission from a point of a sphere the far intersection is uniform over the sphere's area, so the next wall
 // point T is sampled directly: no direction, no orthonormal basis, no intersection.  Same Philox words as the
 // explicit bounce (a -> z, b -> absorb + azimuth).  Returns false if absorbed.
+// z of a uniform point of the unit sphere from a Philox word: 1 - 2 (w + 1/2) 2^-32 (every operation exact)
+__device__ __forceinline__ double sphere_z(uint32_t w) { return fma(-2.0, ((double)w + 0.5) * 0x1.0p-32, 1.0); }
 __device__ __forceinline__ bool interact_chord(const Hot& h, V3& T, uint32_t wa, uint32_t wb) {
   if (!((unsigned long long)wb < h.rho_thr)) return false;   // u01(wb) < rho, decided on the integer
-  const double zz = fma(-2.0, u01(wa), 1.0);
-  const double s2 = sqrt_unit(fma(-zz, zz, 1.0));   // 1 - zz^2 in [2^-32, 1]
+  const double zz = sphere_z(wa);
+  const double s2 = sqrt_unit(fma(-zz, zz, 1.0));   // 1 - zz^2 in [2^-31, 1]
   double sf, cf;
-  circle_point(((double)wb + 0.5) * h.inv_thr, cf, sf);
+  circle_point_psi(fma((double)wb, h.psi_k1, h.psi_k0), cf, sf);
   const double rxy = h.r_in * s2;
   T.x = rxy * cf; T.y = rxy * sf; T.z = h.r_in * zz;
   return true;
@@ -473,29 +486,35 @@ template <bool LEAN, class G>
 __device__ __forceinline__ bool interact(const Hot& h, const G& g, int kind, const V3& q, V3& v, uint64_t seed,
                                          uint64_t ray, uint32_t j, uint32_t stream, uint32_t wa, uint32_t wb) {
   if (!((unsigned long long)wb < h.rho_thr)) return false;   // u01(wb) < rho, decided on the integer
-  const V3 n = surface_normal(h, g, kind, q);
   V3 w;
-  if (!LEAN && h.surface_model == 1) {
-    w = lobe_sample(n, seed, ray, j, stream);
-  } else if (LEAN || h.lambertian) {
-    // cosine-law re-emission about the geometric normal; roughness does not act on a
-    // Lambertian border
-    const double u1 = u01(wa), u2 = ((double)wb + 0.5) * h.inv_thr;
-    const double r = sqrt_unit(u1);      // u1, 1-u1 in [2^-33, 1)
-    const double z = sqrt_unit(1.0 - u1);
+  if (LEAN || (h.surface_model != 1 && h.lambertian)) {
+    // cosine-law re-emission about the geometric normal; roughness does not act on a Lambertian border.
+    // w = n + s, s uniform on the unit sphere in WORLD coordinates (z from word a, azimuth from word b): the direction of
+    // n + s follows the cosine law about n exactly; no local frame, and w stays UN-NORMALISED on the inner sphere, where
+    // the next step is rule S1' (any length): there w = r_in (n + s) = r_in s - q and the normal is never formed; anywhere
+    // else (rim, outer sphere) n + s is normalised here.  (oracle: cosine_emission())
+    const double zs = sphere_z(wa);
+    const double rs = sqrt_unit(fma(-zs, zs, 1.0));   // 1 - zs^2 in [2^-31, 1]
     double sf, cf;
-    circle_point(u2, cf, sf);
-    const double x = r * cf, y = r * sf;
-    // Householder reflection sp*e_z -> n applied to (x, y, sp z), sp = -sign(n.z) (oracle: interact()):
-    // t = n.x x + n.y y, c = z - t/(1+|n.z|), w = (x + c n.x, y + c n.y, sp t + n.z z).  16 instructions where the
-    // orthonormal-basis form took 31; 1+|n.z| is in [1,2].
-    const double sp = -copysign(1.0, n.z);
-    const double t = fma(n.x, x, n.y * y);
-    const double ia = neg_rcp_unit(1.0 + fabs(n.z));
-    const double c = fma(t, ia, z);
-    w.x = fma(c, n.x, x);
-    w.y = fma(c, n.y, y);
-    w.z = fma(n.z, z, sp * t);
+    circle_point_psi(fma((double)wb, h.psi_k1, h.psi_k0), cf, sf);
+    if (kind == K_INNER) {
+      const double Rrs = h.r_in * rs;
+      w.x = fma(Rrs, cf, -q.x);
+      w.y = fma(Rrs, sf, -q.y);
+      w.z = fma(h.r_in, zs, -q.z);
+    } else {
+      const V3 n = surface_normal(h, g, kind, q);
+      w.x = fma(rs, cf, n.x);
+      w.y = fma(rs, sf, n.y);
+      w.z = n.z + zs;
+      unit_dir(w);
+    }
+    v = w;
+    return true;
+  }
+  const V3 n = surface_normal(h, g, kind, q);
+  if (h.surface_model == 1) {
+    w = lobe_sample(n, seed, ray, j, stream);
   } else {
     V3 M = n;
     const double sigma = g.sigma;
@@ -519,12 +538,10 @@ __device__ __forceinline__ bool interact(const Hot& h, const G& g, int kind, con
     const double d2 = -2.0 * dot3(v, M);
     w = axpy(d2, M, v);
   }
-  // into-wall fix.  Cosine emission cannot need it: w.n = z + O(1e-16) with z >= 2^-16.5, so the lean
-  // kernel (Lambertian only) does not evaluate it; the oracle always does and never takes the branch there.
-  if (!LEAN) {
-    const double dn = dot3(w, n);
-    if (dn <= 0.0) w = axpy(-2.0 * dn, n, w);
-  }
+  // (only the lobe and rough-specular surfaces get here: the cosine emission returned above)
+  // into-wall fix
+  const double dn = dot3(w, n);
+  if (dn <= 0.0) w = axpy(-2.0 * dn, n, w);
   // one Newton step towards unit length (keeps the |v| error at rounding level instead of letting it
   // random-walk multiplicatively through hit point -> normal -> new direction)
   const double k = fma(-0.5, dot3(w, w), sconst(1.5));

@@ -1533,8 +1533,10 @@ template <bool KEEP_PREV, class G>
 __device__ __forceinline__ int ray_step(const Hot& h, const G& g, Ray& r, uint64_t seed, uint64_t id_base) {
   V3 q;
   int kind;
-  if (r.tgt && chord_arrive(h, r, q)) kind = K_INNER;
-  else kind = next_hit(h, g, r.p, r.v, r.on, q);
+  if (r.tgt) {   // (a chord whose end point lies in the port opening leaves along its unit direction: generic search)
+    if (chord_arrive(h, r, q)) kind = K_INNER;
+    else kind = next_hit_generic(g, r.p, r.v, r.on, q);
+  } else kind = next_hit(h, g, r.p, r.v, r.on, q);
   return ray_arrive<KEEP_PREV, false, 2>(h, g, r, seed, id_base, kind, q);
 }
 
@@ -1768,6 +1770,7 @@ __device__ __forceinline__ void persistent_body(const Geom& g_arg, const DetGrid
         if (flush) { ISX_TD_ADD(13, 1); ISX_TD_ADD(14, __popcll(pm)); }
         if (flush && parked) {
           if (CH != 0 && r.tgt) chord_leave(r);   // a chord whose end point lies in the port opening (chord_arrive<DEFER>)
+          else if (r.on == K_INNER) unit_dir(r.v);   // it left rule S1' (next_hit_s1): the generic search takes a unit direction
           kind = next_hit_generic(g, r.p, r.v, r.on, q);
           arrived = true;
           parked = false;
@@ -2338,6 +2341,7 @@ __device__ __forceinline__ void assist_body(const Geom& g_arg, const DetGrid& d_
       for (;;) {
         if (go) {
           if (CH != 0 && r.tgt) chord_leave(r);
+          else if (r.on == K_INNER) unit_dir(r.v);   // handed over by a tracer whose rule S1' failed: unit direction from here on
           V3 q;
           const int kind = next_hit_generic(g, r.p, r.v, r.on, q);
           st = ray_arrive<DISC, LEAN, CH, PH_DIRECT>(h, g, r, seed, first, kind, q);   // (DISC: r.prev = start of this segment)

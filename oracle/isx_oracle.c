@@ -118,22 +118,25 @@ void isxo_sincos2pi(double u, double* s, double* c) {
   double x = r * PIO2;
   quadrant((int)kd, kern_sin(x), kern_cos(x), s, c);
 }
-/* A point uniformly distributed on the unit circle from u in (0,1), for the azimuth of the cosine emission (only
- * uniformity matters there, not which angle a given u maps to): psi = (u - 1/2) pi/2 lies in (-pi/4, pi/4), where
- * the polynomial kernels need no quadrant logic, and two angle doublings carry it to 4 psi, uniform on (-pi, pi).
- * The cosine is the plain Horner form (no fdlibm tail correction): |c^2 + s^2 - 1| < 3e-15, and every direction
- * built from it is renormalised by the Newton step of interact(). */
-void isxo_circle_point(double u, double* c, double* s) {
-  const double PIO2 = 1.57079632679489655800e+00;
+/* A point uniformly distributed on the unit circle, for the azimuth of the cosine emission (only uniformity matters
+ * there, not which angle a given word maps to): psi lies in (-pi/4, pi/4), where the polynomial kernels need no quadrant
+ * logic, and two angle doublings carry it to 4 psi, uniform on (-pi, pi).  The cosine is the plain Horner form (no
+ * fdlibm tail correction): |c^2 + s^2 - 1| < 3e-15 -- the emission adds this point, scaled, to the surface normal and
+ * the intersection that follows is exact for a direction of any length, so nothing relies on it being exactly unit. */
+static inline void circle_point_psi(double psi, double* c, double* s) {
   const double C1 = 4.16666666666666019037e-02, C2 = -1.38888888888741095749e-03, C3 = 2.48015872894767294178e-05,
                C4 = -2.75573143513906633035e-07, C5 = 2.08757232129817482790e-09, C6 = -1.13596475577881948265e-11;
-  double psi = (u - 0.5) * PIO2;
   double z = psi * psi;
   double sn = kern_sin(psi);
   double cs = fma(z, fma(z, fma(z, fma(z, fma(z, fma(z, fma(z, C6, C5), C4), C3), C2), C1), -0.5), 1.0);
   double c2 = fma(cs, cs, -(sn * sn)), s2 = fma(cs, sn, cs * sn);
   *c = fma(c2, c2, -(s2 * s2));
   *s = fma(c2, s2, c2 * s2);
+}
+/* the same from u in (0,1): psi = (u - 1/2) pi/2 */
+void isxo_circle_point(double u, double* c, double* s) {
+  const double PIO2 = 1.57079632679489655800e+00;
+  circle_point_psi((u - 0.5) * PIO2, c, s);
 }
 /* general argument, Cody-Waite two-constant reduction by pi/2 */
 void isxo_sincos(double x, double* s, double* c) {
@@ -186,7 +189,8 @@ typedef struct {
   int lambertian, limit, surface_model, chord;
   double r_in;
   uint64_t rho_thr;   /* survive iff word < rho_thr  <=>  (word + 0.5) 2^-32 < rho */
-  double inv_thr;     /* 1 / rho_thr: the surviving word, rescaled, is the azimuth's uniform */
+  double inv_thr;     /* 1 / rho_thr: the surviving word b, rescaled, is the azimuth's uniform u2 = (b + 1/2) / rho_thr */
+  double psi_k1, psi_k0;   /* circle_point_psi's angle straight from the word: psi = (u2 - 1/2) pi/2 = fma(b, psi_k1, psi_k0) */
   v3 src, dir0;
 } geom;
 
@@ -212,6 +216,8 @@ static int prepare(const isxo_config* c, geom* g) {
     double x = ldexp(c->reflectance, 32) - 0.5;
     g->rho_thr = !(x > 0.0) ? 0ull : (x >= 4294967296.0 ? 4294967296ull : (uint64_t)ceil(x));
     g->inv_thr = g->rho_thr ? 1.0 / (double)g->rho_thr : 0.0;
+    g->psi_k1 = g->inv_thr * 1.57079632679489655800e+00;
+    g->psi_k0 = (0.5 * g->inv_thr - 0.5) * 1.57079632679489655800e+00;
   }
   g->sigma = c->roughness_rad;
   g->lambertian = c->lambertian;
@@ -239,7 +245,32 @@ static inline void consider(double t, v3 q, int kind, double* best, v3* bq, int*
   if (t > 0.0 && t < *best) { *best = t; *bq = q; *bk = kind; }
 }
 
-static int next_hit(const geom* g, v3 p, v3 v, int on, v3* q_out) {
+/* Rule S1' in its general form: a ray that leaves a point p of the inner sphere inwards (p.v < 0) meets the sphere again at
+ * t = -2 (p.v)/(v.v) -- the non-zero root of |p + t v|^2 = |p|^2, for a direction v of ANY length -- and if that point lies
+ * on the mirror patch nothing can be nearer.  The cosine emission of interact() hands over an un-normalised direction, so
+ * the bounce-to-bounce step needs neither a square root nor a unit vector; |q| - r_in random-walks at the 1e-16 level
+ * (|q|^2 = |p|^2 + t (2 p.v + t v.v), and the bracket vanishes to rounding) instead of being re-solved.
+ * Returns 1 and q if the rule applies. */
+static inline int s1_inner(const geom* g, v3 p, v3 v, v3* q_out) {
+  double b = dot3(p, v);
+  if (!(b < 0.0)) return 0;
+  double vv = dot3(v, v);
+  double ia = -1.0 / vv;
+  double t = (2.0 * b) * ia;
+  v3 q = axpy(t, v, p);
+  if (q.z >= g->zcut_in) { *q_out = q; return 1; }
+  return 0;
+}
+/* unit vector of v (three divisions by the length, as the ARay constructor does it): what a direction becomes when the
+ * ray leaves rule S1' for the general search */
+static inline v3 unit_dir(v3 v) {
+  double mag = sqrt(dot3(v, v));
+  v3 r = { v.x / mag, v.y / mag, v.z / mag };
+  return r;
+}
+
+/* general search; v is a UNIT vector */
+static int next_hit_general(const geom* g, v3 p, v3 v, int on, v3* q_out) {
   double b = dot3(p, v);
   double pp = dot3(p, p);
   double best = INFINITY;
@@ -254,10 +285,9 @@ static int next_hit(const geom* g, v3 p, v3 v, int on, v3* q_out) {
     double tn = -b - s, tf = s - b;
     /* Rule S1: a ray inside (or on, heading into) the inner ball whose far root lies on
      * the mirror patch hits there; nothing else can be nearer.
-     * Rule S1': leaving the inner sphere inwards the far root is taken as -2b (the root of
-     * t^2 + 2bt = 0: p is on the sphere, |v| = 1 to rounding thanks to the Newton step in
-     * interact()); |q|-r_in then random-walks at the 1e-16 level instead of being re-solved,
-     * and the bounce needs no square root. */
+     * Rule S1' for a unit direction: leaving the inner sphere inwards the far root is taken as -2b (the root of
+     * t^2 + 2bt = 0).  trace_one() tries s1_inner() first; this branch is reached only by a ray whose s1_inner() point
+     * missed the mirror patch (it re-derives the point from the unit direction). */
     if (on == K_INNER && b < 0.0) {
       v3 q = axpy(-2.0 * b, v, p);
       if (q.z >= g->zcut_in) { *q_out = q; return K_INNER; }
@@ -316,6 +346,16 @@ static int next_hit(const geom* g, v3 p, v3 v, int on, v3* q_out) {
   if (tz < t) t = tz;
   *q_out = axpy(t, v, p);
   return K_BOX;
+}
+
+/* One boundary step: rule S1' while the ray bounces inside the inner sphere, else the general search along the unit
+ * direction (*v is replaced by it: the direction of an exiting ray is a unit vector, as ROBAST's is). */
+static int next_hit(const geom* g, v3 p, v3* v, int on, v3* q_out) {
+  if (on == K_INNER) {
+    if (s1_inner(g, p, *v, q_out)) return K_INNER;
+    *v = unit_dir(*v);
+  }
+  return next_hit_general(g, p, *v, on, q_out);
 }
 
 /* ------------------------------------------------------------------------- */
@@ -380,6 +420,29 @@ static v3 lobe_sample(v3 normal, uint64_t seed, uint64_t ray, uint32_t j, uint32
   return sc;
 }
 
+/* cosine-law emission from the surface point q of boundary `kind` for the two Philox words of the interaction
+ * (a: z of the sphere point, b: its azimuth; b is a surviving word, b < rho_thr) -- see interact() */
+static inline v3 cosine_emission(const geom* g, int kind, v3 q, uint32_t wa, uint32_t wb) {
+  double zs = fma(-0x1.0p-31, (double)wa, 1.0 - 0x1.0p-32);   /* = 1 - 2 (wa + 1/2) 2^-32, exact */
+  double rs = sqrt(fma(-zs, zs, 1.0));                         /* 1 - zs^2 in [2^-31, 1] */
+  double sf, cf;
+  circle_point_psi(fma((double)wb, g->psi_k1, g->psi_k0), &cf, &sf);
+  v3 w;
+  if (kind == K_INNER) {
+    double Rrs = g->r_in * rs;
+    w.x = fma(Rrs, cf, -q.x);
+    w.y = fma(Rrs, sf, -q.y);
+    w.z = fma(g->r_in, zs, -q.z);
+  } else {
+    v3 n = surface_normal(g, kind, q);
+    w.x = fma(rs, cf, n.x);
+    w.y = fma(rs, sf, n.y);
+    w.z = n.z + zs;
+    w = unit_dir(w);
+  }
+  return w;
+}
+
 /* returns 0 if absorbed, 1 otherwise (v updated) */
 static int interact(const geom* g, int kind, v3 q, v3* v, uint64_t seed, uint64_t ray, uint32_t j, uint32_t stream) {
   /* Random words of interaction j: block j/2 of the trace's stream serves two interactions, words
@@ -398,23 +461,14 @@ static int interact(const geom* g, int kind, v3 q, v3* v, uint64_t seed, uint64_
      * roughness does not act on a Lambertian border: the reference's own sigma=0.5 map
      * (flux_at_observer/fluxmap_data.csv) is reproduced with the roughness ignored and is
      * missed by 9.5 % on axis with a roughness-tilted normal. */
-    double u1 = isxo_u01(wa), u2 = ((double)wb + 0.5) * g->inv_thr;
-    double r = sqrt(u1);
-    double z = sqrt(1.0 - u1);
-    double sf, cf;
-    isxo_circle_point(u2, &cf, &sf);
-    double x = r * cf, y = r * sf;
-    /* local sample (x, y, z), z = cos(polar) > 0, carried to the normal by the Householder reflection that maps
-     * sp*e_z onto n, sp = -sign(n.z) (the well-conditioned choice: |u|^2 = 2(1+|n.z|) for u = sp*e_z - n):
-     *   w = H (x, y, sp z),  H = I - 2 u u^T / |u|^2
-     * written out:  t = n.x x + n.y y,  c = z - t/(1+|n.z|),  w = (x + c n.x, y + c n.y, sp t + n.z z);  w.n = z. */
-    double sp = -copysign(1.0, n.z);
-    double t = fma(n.x, x, n.y * y);
-    double ia = -1.0 / (1.0 + fabs(n.z));
-    double c = fma(t, ia, z);
-    w.x = fma(c, n.x, x);
-    w.y = fma(c, n.y, y);
-    w.z = fma(n.z, z, sp * t);
+    /* w = n + s with s uniformly distributed on the unit sphere: the direction of n + s follows the cosine law about n
+     * exactly (the sphere of radius 1 about the tip of n touches the surface at the emission point: the integrating-sphere
+     * identity in the small).  s is sampled in WORLD coordinates -- z uniform in (-1, 1), azimuth uniform -- so no
+     * local frame is needed, and w is left UN-NORMALISED on the inner sphere, where the next step is s1_inner(), which
+     * takes a direction of any length: there w = r_in (n + s) = r_in s - q for the inward normal n = -q / r_in, and the
+     * normal itself is never formed.  Anywhere else (rim, outer sphere) w = n + s is normalised here. */
+    *v = cosine_emission(g, kind, q, wa, wb);
+    return 1;
   } else {
     /* specular reflection about the normal, tilted by a Gaussian polar angle (SetGaussianRoughness) */
     v3 M = n;
@@ -462,10 +516,10 @@ static int interact_chord(const geom* g, v3* T, uint64_t seed, uint64_t ray, uin
   draw_block(seed, ray, j >> 1, stream, wl);
   const uint32_t wa = wl[2u * (j & 1u)], wb = wl[2u * (j & 1u) + 1u];
   if (!((uint64_t)wb < g->rho_thr)) return 0;
-  double zz = fma(-2.0, isxo_u01(wa), 1.0);
+  double zz = fma(-0x1.0p-31, (double)wa, 1.0 - 0x1.0p-32);   /* = 1 - 2 (wa + 1/2) 2^-32, exact */
   double s2 = sqrt(fma(-zz, zz, 1.0));
   double sf, cf;
-  isxo_circle_point(((double)wb + 0.5) * g->inv_thr, &cf, &sf);
+  circle_point_psi(fma((double)wb, g->psi_k1, g->psi_k0), &cf, &sf);
   double rxy = g->r_in * s2;
   T->x = rxy * cf; T->y = rxy * sf; T->z = g->r_in * zz;
   return 1;
@@ -487,12 +541,11 @@ static void trace_one(const geom* g, uint64_t seed, uint64_t ray, uint32_t strea
       if (v.z >= g->zcut_in) {
         kind = K_INNER; q = v; v = d;              /* arrived; v keeps the (unnormalised) last chord */
       } else {                                     /* T lies in the port opening: leave along the chord */
-        double mag = sqrt(dot3(d, d));
-        v.x = d.x / mag; v.y = d.y / mag; v.z = d.z / mag;
-        kind = next_hit(g, p, v, on, &q);
+        v = unit_dir(d);
+        kind = next_hit_general(g, p, v, on, &q);
       }
     } else {
-      kind = next_hit(g, p, v, on, &q);
+      kind = next_hit(g, p, &v, on, &q);
     }
     p = q;
     npts++;
@@ -661,12 +714,13 @@ int isxo_check_intersection(const double det[6], double width, const double last
 /* ------------------------------------------------------------------------- */
 /* ---- hooks for the reference-side bounce dump (tools/ref_dump/dumpBounces.C -> tests/test_robast_dump.py): the pieces of
  * the trace loop one bounce at a time, so that ROBAST's own points and random draws can be replayed through them. */
-int isxo_next_boundary(const isxo_config* c, const double p[3], const double v[3], int on, double q_out[3]) {
+int isxo_next_boundary(const isxo_config* c, const double p[3], const double v[3], int on, double q_out[3], double v_out[3]) {
   geom g;
   if (prepare(c, &g)) return -1;
   v3 q, P = { p[0], p[1], p[2] }, V = { v[0], v[1], v[2] };
-  const int kind = next_hit(&g, P, V, on, &q);
+  const int kind = next_hit(&g, P, &V, on, &q);
   q_out[0] = q.x; q_out[1] = q.y; q_out[2] = q.z;
+  if (v_out) { v_out[0] = V.x; v_out[1] = V.y; v_out[2] = V.z; }   /* (the unit direction, if the step left rule S1') */
   return kind;
 }
 /* unit surface normal (towards the free side) of boundary `kind` at q */
@@ -678,19 +732,16 @@ int isxo_surface_normal(const isxo_config* c, int kind, const double q[3], doubl
   n_out[0] = n.x; n_out[1] = n.y; n_out[2] = n.z;
   return 0;
 }
-/* the cosine-law emission of interact(), Newton step included, for given uniforms (u1: polar, u2: azimuth) about the unit normal n */
-void isxo_cosine_emission(const double n[3], double u1, double u2, double w_out[3]) {
-  const double r = sqrt(u1), z = sqrt(1.0 - u1);
-  double sf, cf;
-  isxo_circle_point(u2, &cf, &sf);
-  const double x = r * cf, y = r * sf;
-  const double sp = -copysign(1.0, n[2]);
-  const double t = fma(n[0], x, n[1] * y);
-  const double ia = -1.0 / (1.0 + fabs(n[2]));
-  const double cc = fma(t, ia, z);
-  v3 w = { fma(cc, n[0], x), fma(cc, n[1], y), fma(n[2], z, sp * t) };
-  const double k = fma(-0.5, dot3(w, w), 1.5);   /* the Newton step of interact() */
-  w_out[0] = w.x * k; w_out[1] = w.y * k; w_out[2] = w.z * k;
+/* the cosine-law emission of interact() from the point q of surface `kind` for the two Philox words of an interaction (a: z of
+ * the sphere point, b: azimuth; b must be a surviving word, b < rho_thr): r_in s - q, un-normalised, on the inner sphere
+ * (kind 1), the unit vector of n + s elsewhere */
+int isxo_cosine_emission(const isxo_config* c, int kind, const double q[3], uint32_t wa, uint32_t wb, double w_out[3]) {
+  geom g;
+  if (prepare(c, &g)) return -1;
+  v3 Q = { q[0], q[1], q[2] };
+  const v3 w = cosine_emission(&g, kind, Q, wa, wb);
+  w_out[0] = w.x; w_out[1] = w.y; w_out[2] = w.z;
+  return 0;
 }
 
 void isxo_default_config(isxo_config* c) {

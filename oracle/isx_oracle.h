@@ -95,11 +95,12 @@ int isxo_exit_directions(const isxo_config* cfg, uint64_t n_rays, uint64_t seed,
                          uint64_t* ray_ids, double* directions, uint64_t* count);
 
 /* One bounce at a time (replay of a reference-side dump, tests/test_robast_dump.py): next boundary from p along v when the
- * ray sits on boundary `on` (0 none, 1 inner sphere, 2 outer sphere, 3 rim cone, 4 box) -> kind, point; the surface normal
- * there; the cosine-law emission for given uniforms. */
-int isxo_next_boundary(const isxo_config* cfg, const double p[3], const double v[3], int on, double q_out[3]);
+ * ray sits on boundary `on` (0 none, 1 inner sphere, 2 outer sphere, 3 rim cone, 4 box) -> kind, point (v_out, if not NULL:
+ * the direction the step was taken along -- v itself, or its unit vector if the step left rule S1'); the surface normal
+ * there; the cosine-law emission from surface point q for the two Philox words of an interaction. */
+int isxo_next_boundary(const isxo_config* cfg, const double p[3], const double v[3], int on, double q_out[3], double v_out[3]);
 int isxo_surface_normal(const isxo_config* cfg, int kind, const double q[3], double n_out[3]);
-void isxo_cosine_emission(const double n[3], double u1, double u2, double w_out[3]);
+int isxo_cosine_emission(const isxo_config* cfg, int kind, const double q[3], uint32_t wa, uint32_t wb, double w_out[3]);
 
 int isxo_max_threads(void);
 

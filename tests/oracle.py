@@ -89,10 +89,9 @@ def lib():
         L.isxo_trace_rays_detector.argtypes = [P(Config), P(dbl), dbl, u64, u64, u64, P(u64), P(Stats)]
         L.isxo_exit_directions.argtypes = [P(Config), u64, u64, u64, u64, P(u64), P(dbl), P(u64)]
         L.isxo_max_threads.restype = C.c_int
-        L.isxo_next_boundary.argtypes = [P(Config), P(dbl), P(dbl), C.c_int, P(dbl)]
+        L.isxo_next_boundary.argtypes = [P(Config), P(dbl), P(dbl), C.c_int, P(dbl), P(dbl)]
         L.isxo_surface_normal.argtypes = [P(Config), C.c_int, P(dbl), P(dbl)]
-        L.isxo_cosine_emission.argtypes = [P(dbl), dbl, dbl, P(dbl)]
-        L.isxo_cosine_emission.restype = None
+        L.isxo_cosine_emission.argtypes = [P(Config), C.c_int, P(dbl), C.c_uint32, C.c_uint32, P(dbl)]
         _lib = L
     return _lib
 
@@ -133,10 +132,13 @@ def sincos(x):
     return s.value, c.value
 
 
-def next_boundary(cfg, p, v, on):
-    """(kind, point) of the next boundary from p along v for a ray sitting on boundary `on` (isxo_next_boundary)."""
-    P3, V3, Q3 = (C.c_double * 3)(*p), (C.c_double * 3)(*v), (C.c_double * 3)()
-    kind = lib().isxo_next_boundary(C.byref(cfg), P3, V3, int(on), Q3)
+def next_boundary(cfg, p, v, on, with_direction=False):
+    """(kind, point) of the next boundary from p along v for a ray sitting on boundary `on` (isxo_next_boundary);
+    with_direction: also the direction the step was taken along (the unit vector of v once the ray leaves rule S1')."""
+    P3, V3, Q3, W3 = (C.c_double * 3)(*p), (C.c_double * 3)(*v), (C.c_double * 3)(), (C.c_double * 3)()
+    kind = lib().isxo_next_boundary(C.byref(cfg), P3, V3, int(on), Q3, W3)
+    if with_direction:
+        return kind, np.array(Q3[:]), np.array(W3[:])
     return kind, np.array(Q3[:])
 
 
@@ -146,9 +148,11 @@ def surface_normal(cfg, kind, q):
     return np.array(N3[:])
 
 
-def cosine_emission(n, u1, u2):
-    N3, W3 = (C.c_double * 3)(*n), (C.c_double * 3)()
-    lib().isxo_cosine_emission(N3, float(u1), float(u2), W3)
+def cosine_emission(cfg, kind, q, wa, wb):
+    """interact()'s cosine emission from surface point q for the two Philox words of an interaction (r_in s - q, un-normalised,
+    on the inner sphere, kind 1; the unit vector of n + s elsewhere)"""
+    Q3, W3 = (C.c_double * 3)(*q), (C.c_double * 3)()
+    assert lib().isxo_cosine_emission(C.byref(cfg), int(kind), Q3, int(wa), int(wb), W3) == 0
     return np.array(W3[:])
 
 

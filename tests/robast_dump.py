@@ -8,8 +8,11 @@ Test infrastructure.  `replay()` walks every ray of a dump through the CPU oracl
                    bounces, in log order: the cosine law about the GEOMETRIC normal, pinned draw by draw;
   * final state -- the dumped direction is the last segment's direction, the end status matches where the track stops;
   * detector    -- Detector::checkIntersection's dumped answers equal the oracle's, bit for bit.
-`write_synthetic()` writes a file of the same format from the oracle's own trace (its Philox draws in place of gRandom's):
-the committed tests/golden/robast_bounces_synthetic.txt keeps the reader and the replay honest while no ROBAST dump exists.
+`write_synthetic()` writes a file of the same format from the oracle's own trace: the committed
+tests/golden/robast_bounces_synthetic.txt keeps the reader and the replay honest while no ROBAST dump exists.  The oracle
+draws its cosine-law direction as n + s (s uniform on the unit sphere, two Philox words; oracle/isx_oracle.c interact()),
+not from a polar angle, so the "polar uniform" the synthetic file logs for an emission is the one a sqrt(1-u) sampler would
+have needed for the same direction, u = 1 - cos^2; navigation, end states and detector answers are the oracle's own.
 """
 import numpy as np
 
@@ -153,7 +156,8 @@ def write_synthetic(path, n_rays=24, seed=12345):
     st, npts, lps, dirs = oracle.trace_endstates(c, n_rays, seed)
     rho_thr = int(np.ceil(c.reflectance * 2.0 ** 32 - 0.5))
     with open(path, "w") as f:
-        f.write("# isx-robast-bounce-dump 1\n# synthetic : written by tests/robast_dump.py from the CPU oracle, NOT by ROBAST\n")
+        f.write("# isx-robast-bounce-dump 1\n# synthetic : written by tests/robast_dump.py from the CPU oracle, NOT by ROBAST "
+                "(U: per emission 1 - cos^2 of its polar angle, then the azimuth uniform)\n")
         f.write("# seed %d rays %d reflectance %.17g roughness %.17g theta_max %.17g r_in %.17g r_out %.17g box_half %.17g limit %d "
                 "port_z %.17g src %.17g %.17g %.17g dir %.17g %.17g %.17g cm 1\n" % (
                     seed, n_rays, c.reflectance, c.roughness_rad, c.theta_max_deg, c.r_in, c.r_out, c.box_half, c.max_points,
@@ -165,7 +169,7 @@ def write_synthetic(path, n_rays=24, seed=12345):
             v = np.array([c.dir[0], c.dir[1], c.dir[2]]) / np.linalg.norm([c.dir[0], c.dir[1], c.dir[2]])
             on, j, pts, us, status = K_NONE, 0, [p.copy()], [], "?"
             while True:
-                kind, q = oracle.next_boundary(c, p, v, on)
+                kind, q, v = oracle.next_boundary(c, p, v, on, with_direction=True)   # (v: the unit direction once S1' is left)
                 p = q; pts.append(p.copy())
                 if kind == K_BOX:
                     status = "E"; break
@@ -175,9 +179,10 @@ def write_synthetic(path, n_rays=24, seed=12345):
                 j += 1
                 if not wb < rho_thr:
                     us.append((wb + 0.5) / 2.0 ** 32); status = "A"; break
-                u1, u2 = (wa + 0.5) / 2.0 ** 32, (wb + 0.5) * (1.0 / rho_thr)   # (the oracle multiplies by the reciprocal)
-                us += [u1, u2]
-                v = oracle.cosine_emission(oracle.surface_normal(c, kind, p), u1, u2)
+                n = oracle.surface_normal(c, kind, p)
+                v = oracle.cosine_emission(c, kind, p, wa, wb)                 # ~ n + s (un-normalised on the inner sphere)
+                ct = float(np.dot(v, n) / np.linalg.norm(v))
+                us += [1.0 - ct * ct, (wb + 0.5) * (1.0 / rho_thr)]
                 if len(pts) > c.max_points:
                     status = "U"; break
             want = {1: "E", 2: "A", 3: "U"}[int(st[i])]
