@@ -412,11 +412,11 @@ int enqueue(int sink, const isx_config* c, uint64_t n, uint64_t seed, uint64_t f
     // ... and with COLUMN slots for the pencil source (most lines on the fast path; the BRDF model's grazing lines are served
     // better by the row slots of isx_bin_slots_kernel)
     const bool cols = slots && S.bin_cols && (!brdf || S.bin_cols == 2) &&
-                      lds_tables + (size_t)(d.n_theta + 1) * sizeof(RowX) + (size_t)(kBlock / 64) * kColWaveWords * 4 <= S.lds_limit;
+                      lds_tables + (size_t)(d.n_theta + 4) * sizeof(RowX) + (size_t)(kBlock / 64) * kColWaveWords * 4 <= S.lds_limit;
     typedef void (*BinFn)(const DetGrid, const Work);
     const BinFn bin_fn = cols ? isx_bin_cols_kernel : slots ? isx_bin_slots_kernel : isx_bin_lines_kernel;
     const int pblock = assist ? S.assist_block : S.trace_block, bblock = slots ? kBlock : S.bin_block;
-    const size_t lds_bin = lds_tables + (cols ? (size_t)(d.n_theta + 1) * sizeof(RowX) + (size_t)(bblock / 64) * kColWaveWords * 4
+    const size_t lds_bin = lds_tables + (cols ? (size_t)(d.n_theta + 4) * sizeof(RowX) + (size_t)(bblock / 64) * kColWaveWords * 4
                                          : slots ? (size_t)(2 * d.n_phi) * sizeof(ColP) + (size_t)(bblock / 64) * kSlotWaveWords * 4 : (size_t)(bblock / 64) * 128 * 4);
     if (lds_bin <= S.lds_limit) {
       const uint64_t chunk = n < S.pipe_chunk ? n : S.pipe_chunk;

@@ -125,6 +125,12 @@ constexpr uint32_t kRegion = 1024;
 #define ISX_WAVES_PER_EU 0   // 0: let the compiler choose
 #endif
 constexpr int kBlock = ISX_BLOCK;
+#ifndef ISX_ABL
+#define ISX_ABL 0
+#endif
+#ifndef ISX_WALK4
+#define ISX_WALK4 1
+#endif
 #ifndef ISX_STEPS
 #define ISX_STEPS 6
 #endif
@@ -1208,6 +1214,9 @@ __device__ __forceinline__ ColPre prep_cols(const GridConst& k, int n_phi, const
 // the rows [ilo, ilo + cnt) of column (c32, s32) that the cap of a line can reach
 __device__ __forceinline__ void cap_rows(float fx, float fy, float a, float cosw, float c32, float s32, float inv_dth, int n_theta,
                                          int& ilo, int& cnt) {
+#if ISX_ABL == 3
+  ilo = 20; cnt = 30; return;
+#endif
   ilo = 0; cnt = 0;
   const float b = fmaf(c32, fx, s32 * fy);
   const float rho2 = fmaf(a, a, b * b);
@@ -1228,7 +1237,16 @@ __device__ __forceinline__ void cap_rows(float fx, float fy, float a, float cosw
 template <class D>
 __device__ __forceinline__ void consume_cols(const D& d, uint32_t* __restrict__ hist, const double* __restrict__ rowt,
                                              const ColX* __restrict__ colx, const RowX* __restrict__ rowx,
-                                             const double* __restrict__ lines, uint32_t rec, bool active, int lane) {
+                                             const double* __restrict__ lines, uint32_t rec, bool active, int lane,
+                                             const SlotQueues& sq) {
+  // (-DISX_DIAG, tools/diag_binning.py: wave cycles [16] batch preparation, [17] cap rows + what the compiler sinks to the push,
+  //  [18] push, [19] pop, [20] slot prologue (line fetch, coefficients), [21] walk, [22] owner search, [23] the owner's cap
+  //  through ds_bpermute, [24] (cap rows as placed in the source), [25] producer loop control + drain check.
+  //  -DISX_DIAG_TIMING_ONLY: the timers without the per-candidate re-decision and counters, which inflate the walk tenfold)
+  ISX_BD_MARK(sq, 3);
+#if ISX_ABL == 2
+  return;
+#endif
   const int line = (int)(rec & 255u), j = (int)((rec >> 8) & 255u), ilo = (int)((rec >> 16) & 255u);
   const int len = active ? (int)(rec >> 24) : 0;
   const double* src6 = lines + 6 * line;
@@ -1262,15 +1280,137 @@ __device__ __forceinline__ void consume_cols(const D& d, uint32_t* __restrict__ 
   typedef __attribute__((address_space(3))) unsigned char LdsByte;
   const uint32_t row_bytes = (uint32_t)d.n_phi * 4u;
   LdsByte* bin = reinterpret_cast<LdsByte*>((__attribute__((address_space(3))) void*)hist) + (uint32_t)j * 4u + (uint32_t)ilo * row_bytes;
+#if !ISX_WALK4
   const RowX* rp = rowx + ilo;
+#endif
   const isx_f2 vAl = {cAl, cAl}, vBe = {cBe, cBe}, vVz = {cVz, cVz}, vQz = {cQz, cQz}, vE0 = {cE0, cE0}, vE1 = {cE1, cE1},
                vE2 = {cE2, cE2}, vF0 = {cF0, cF0}, vF1 = {cF1, cF1}, vF2 = {cF2, cF2};
   if (len > 0) ISX_DIAG_ADD_LANES(7, len);
   ISX_DIAG_ADD(11, 1);
+  ISX_BD_MARK(sq, 4);
+#if ISX_ABL == 1
+  if (band32 == 12345.f) hist[0] = (uint32_t)(cAl + cBe + cVz + cQz + cE0 + cE1 + cE2 + cF0 + cF1 + cF2);
+  return;
+#endif
+#if ISX_WALK4
+  // Two row pairs per step: rows k, k+1 (table entry rp) and k+2, k+3 (entry rp + 2) as two INDEPENDENT packed chains, so
+  // that a wave has two LDS reads and two dependent chains in flight instead of one (the walk is latency-bound at four
+  // waves per SIMD) and pays the loop control once per four candidates.  Rows past the slot's last one are masked (their
+  // table entry may be one past the table and their bin up to three rows past the grid: harmless reads, atomic adds of zero).
+  // (the row table as two arrays -- {S_i, S_i+1, C_i, C_i+1} at 16 bytes per row, {T_i, T_i+1} at 8 -- instead of one 32-byte
+  //  entry: a 16-byte read then spreads over sixteen bank groups instead of eight, and the ablation that reads one entry for
+  //  all lanes says that bank conflicts of these reads cost 1.1 of the kernel's 7.0 ms)
+  const float4* rowA = reinterpret_cast<const float4*>(rowx);
+  const float2* rowB = reinterpret_cast<const float2*>(rowA + (d.n_theta + 4));
+  auto classify = [&](int ie, int kk, bool& h0, bool& h1) {
+    const float4 sc = rowA[ie];
+    const float2 tt = rowB[ie];
+    const bool one = kk < len, two = kk + 1 < len;
+    const isx_f2 SS = {sc.x, sc.y}, CC = {sc.z, sc.w}, TT = {tt.x, tt.y};
+    const isx_f2 dot = __builtin_elementwise_fma(vAl, SS, vVz * CC);
+    const isx_f2 num = __builtin_elementwise_fma(vBe, SS, __builtin_elementwise_fma(vQz, CC, TT));
+    const isx_f2 mdv = __builtin_elementwise_fma(vE1, SS, __builtin_elementwise_fma(vE2, CC, vE0));
+    const isx_f2 ddw = __builtin_elementwise_fma(vF1, SS, __builtin_elementwise_fma(vF2, CC, vF0));
+    const isx_f2 g = __builtin_elementwise_fma(dot, __builtin_elementwise_fma(dot, ddw, num * mdv), num * num);
+    bool hit0 = g.x < 0.f, hit1 = g.y < 0.f;
+    if (one && !(fminf(fabsf(g.x), fabsf(g.y)) > band32)) {
+      // tiers 2 and 3 of walk_columns (binary64 about the original point with its 2.1e-9 band, then the reference's own test)
+#pragma unroll 1
+      for (int t = 0; t < 2; ++t) {
+        const float gt = t == 0 ? g.x : g.y;
+        if (fabsf(gt) > band32 || (t == 1 && !two)) continue;
+#ifndef ISX_DIAG_TIMING_ONLY
+        ISX_DIAG_ADD_LANES(12, 1);
+#endif
+        int ir = ilo + kk + t;
+        asm volatile("" : "+v"(ir));
+        bool hit = false;
+        {
+          const double sd = rowt[4 * ir + 0], cd = rowt[4 * ir + 1], zz = rowt[4 * ir + 2], ad = rowt[4 * ir + 3];
+          int jr = j;
+          asm volatile("" : "+v"(jr));
+          const double cph = colx[jr].c, sph = colx[jr].s;
+          V3 P, V;
+          {
+            const double2* src = reinterpret_cast<const double2*>(src6 + (jr - j));
+            const double2 a = src[0], b = src[1], c = src[2];
+            P.x = a.x; P.y = a.y; P.z = b.x; V.x = b.y; V.y = c.x; V.z = c.y;
+          }
+          const double pz = P.z - zz;
+          const double dotd = fma(sd * V.y, cph, fma(-(sd * V.x), sph, -(cd * V.z)));
+          const double numd = fma(sd * P.y, cph, fma(-(sd * P.x), sph, -(cd * pz)));
+          const double m2dv = fma(2.0 * (ad * V.x), cph, fma(2.0 * (ad * V.y), sph, -2.0 * fma(P.x, V.x, fma(P.y, V.y, pz * V.z))));
+          const double f0 = fma(P.x, P.x, fma(P.y, P.y, fma(ad, ad, pz * pz)));
+          const double f1c = -2.0 * (ad * P.x), f2c = -2.0 * (ad * P.y);
+          const double ddwd = fma(f1c, cph, fma(f2c, sph, f0 - d.half_w2));
+          const double diff = fma(dotd, fma(dotd, ddwd, numd * m2dv), numd * numd);
+          const double bandc = 2.1e-9 * fma(2.0, f0 + (fabs(f1c) + fabs(f2c)), d.half_w2);
+          hit = diff < 0.0;
+          if (fabs(dotd) < 1e-4 || fabs(diff) <= bandc) {
+            ISX_DIAG_ADD_LANES(13, 1);
+            const double* tab = d.table;
+            asm volatile("" : "+v"(tab));
+            hit = check_intersection(tab + 6 * (size_t)(ir * d.n_phi + jr), d.half_w2, P, V);
+          }
+        }
+        if (t == 0) hit0 = hit; else hit1 = hit;
+      }
+    }
+    h0 = hit0 && one;
+    h1 = hit1 && two;
+#if defined(ISX_DIAG) && !defined(ISX_DIAG_TIMING_ONLY)
+    {   // tuning builds: a decision taken by tier 1 must be the reference's
+      V3 P, V;
+      const double2* src = reinterpret_cast<const double2*>(src6);
+      const double2 a = src[0], b = src[1], c = src[2];
+      P.x = a.x; P.y = a.y; P.z = b.x; V.x = b.y; V.y = c.x; V.z = c.y;
+      for (int t = 0; t < (two ? 2 : (one ? 1 : 0)); ++t) {
+        const bool ref = check_intersection(d.table + 6 * (size_t)((ilo + kk + t) * d.n_phi + j), d.half_w2, P, V);
+        if (ref != (t == 0 ? h0 : h1)) ISX_DIAG_ADD_LANES(14, 1);
+      }
+    }
+#endif
+  };
+  int ie = ilo;
+  for (int k = 0;; k += 4) {
+    const bool act = k < len;
+    if (__ballot(act) == 0ull) break;
+#ifndef ISX_DIAG_TIMING_ONLY
+    ISX_DIAG_ADD(4, 4);
+#endif
+    if (act) {
+      bool a0, a1, b0, b1;
+#if ISX_ABL == 5
+      classify((k & 3), k, a0, a1);
+      classify(2 + (k & 3), k + 2, b0, b1);
+#else
+      classify(ie, k, a0, a1);
+      classify(ie + 2, k + 2, b0, b1);
+#endif
+      ie += 4;
+#if ISX_ABL == 4
+      if (a0 && a1 && b0 && b1 && band32 == 12345.f)
+#endif
+      __hip_atomic_fetch_add(reinterpret_cast<LdsU32*>(bin), a0 ? 1u : 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+#if ISX_ABL == 4
+      if (a0 && a1 && b0 && b1 && band32 == 12345.f) {
+#endif
+      __hip_atomic_fetch_add(reinterpret_cast<LdsU32*>(bin + row_bytes), a1 ? 1u : 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      __hip_atomic_fetch_add(reinterpret_cast<LdsU32*>(bin + 2u * row_bytes), b0 ? 1u : 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      __hip_atomic_fetch_add(reinterpret_cast<LdsU32*>(bin + 3u * row_bytes), b1 ? 1u : 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+#if ISX_ABL == 4
+      }
+#endif
+      bin += 4u * row_bytes;
+    }
+  }
+#else
   for (int k = 0;; k += 2) {
     const bool act = k < len;
     if (__ballot(act) == 0ull) break;
+#ifndef ISX_DIAG_TIMING_ONLY
     ISX_DIAG_ADD(4, 2);
+#endif
     if (act) {
       const float4 sc = *reinterpret_cast<const float4*>(rp);
       const float2 tt = *reinterpret_cast<const float2*>(&rp->T0);
@@ -1288,7 +1428,9 @@ __device__ __forceinline__ void consume_cols(const D& d, uint32_t* __restrict__ 
         for (int t = 0; t < 2; ++t) {
           const float gt = t == 0 ? g.x : g.y;
           if (fabsf(gt) > band32 || (t == 1 && !two)) continue;
+#ifndef ISX_DIAG_TIMING_ONLY
           ISX_DIAG_ADD_LANES(12, 1);
+#endif
           int ir = ilo + k + t;
           asm volatile("" : "+v"(ir));
           bool hit = false;
@@ -1324,7 +1466,7 @@ __device__ __forceinline__ void consume_cols(const D& d, uint32_t* __restrict__ 
         }
       }
       hit1 = hit1 && two;
-#ifdef ISX_DIAG
+#if defined(ISX_DIAG) && !defined(ISX_DIAG_TIMING_ONLY)
       {   // tuning builds: a decision taken by tier 1 must be the reference's
         V3 P, V;
         const double2* src = reinterpret_cast<const double2*>(src6);
@@ -1345,6 +1487,8 @@ __device__ __forceinline__ void consume_cols(const D& d, uint32_t* __restrict__ 
       bin += 2u * row_bytes;
     }
   }
+#endif
+  ISX_BD_MARK(sq, 5);
 }
 
 template <class D>
@@ -1364,7 +1508,7 @@ __device__ __forceinline__ void drain_cols(const D& d, uint32_t* __restrict__ hi
     __builtin_amdgcn_wave_barrier();
     if (lane == 0) hd[c] = h + take;
     __builtin_amdgcn_wave_barrier();
-    consume_cols(d, hist, rowt, colx, rowx, lines, rec, lane < take, lane);
+    consume_cols(d, hist, rowt, colx, rowx, lines, rec, lane < take, lane, sq);
   }
 }
 
@@ -1375,6 +1519,7 @@ __device__ __forceinline__ void push_cols(const D& d, uint32_t* __restrict__ his
                                           const double* __restrict__ lines, const SlotQueues& sq, int line, int j, int ilo, int cnt,
                                           int lane) {
   int i0 = ilo, rem = cnt;
+  ISX_BD_MARK(sq, 1);
   for (;;) {
     const int piece = rem > kColLongest ? kColPiece : rem;
     if (piece > 0) {
@@ -1386,6 +1531,7 @@ __device__ __forceinline__ void push_cols(const D& d, uint32_t* __restrict__ his
     rem -= piece;
     i0 += piece;
     __builtin_amdgcn_wave_barrier();
+    ISX_BD_MARK(sq, 2);
     drain_cols(d, hist, rowt, colx, rowx, lines, sq, 64, lane);
     if (__ballot(rem > 0) == 0ull) break;
   }
@@ -1402,6 +1548,7 @@ __device__ __forceinline__ void produce_cols_packed(const D& d, uint32_t* __rest
   for (int base = 0; base < total; base += 64) {
     const int g = base + lane;
     bool have = g < total;
+    ISX_BD_MARK(sq, 9);
     volatile LdsInt* mk = mark;
     mk[lane] = 0;
     __builtin_amdgcn_wave_barrier();
@@ -1412,8 +1559,10 @@ __device__ __forceinline__ void produce_cols_packed(const D& d, uint32_t* __rest
     const int pos = 63 - __builtin_clzll(low | 1ull);
     int owner = mk[pos] - 1;
     if (!have || owner < 0) { owner = 0; have = false; }
+    ISX_BD_MARK(sq, 6);
     const int o_excl = __shfl(excl, owner, 64), o_jlo = __shfl(pre.jlo, owner, 64);
     const float fx = __shfl(pre.fx, owner, 64), fy = __shfl(pre.fy, owner, 64), a = __shfl(pre.a, owner, 64), cw = __shfl(pre.cosw, owner, 64);
+    ISX_BD_MARK(sq, 7);
     int j = o_jlo + (g - o_excl);
     if (j >= d.n_phi) j -= d.n_phi;
     if (!have) j = 0;
@@ -2862,7 +3011,7 @@ isx_bin_cols_kernel(const DetGrid d_arg, const Work wk) {
   double* rowt = reinterpret_cast<double*>(smem + off_row);
   ColX* colx = reinterpret_cast<ColX*>(rowt + 4 * d_arg.n_theta);
   RowX* rowx = reinterpret_cast<RowX*>(colx + 2 * d_arg.n_phi);
-  DetGrid* d_lds = reinterpret_cast<DetGrid*>(rowx + d_arg.n_theta + 1);
+  DetGrid* d_lds = reinterpret_cast<DetGrid*>(rowx + d_arg.n_theta + 4);   // (the walk reads up to three entries past its slot's rows)
   uint32_t* wave_all = reinterpret_cast<uint32_t*>(d_lds + 1);
   const int tid = threadIdx.x, lane = tid & 63;
   const int nthr = (int)blockDim.x;
@@ -2879,7 +3028,12 @@ isx_bin_cols_kernel(const DetGrid d_arg, const Work wk) {
       const double sd = d_arg.rowtab[4 * b + 4], cd = d_arg.rowtab[4 * b + 5];
       e.S1 = (float)sd; e.C1 = (float)cd; e.T1 = (float)(-(d_arg.R * (cd * cd)));
     }
+#if ISX_WALK4
+    reinterpret_cast<float4*>(rowx)[b] = make_float4(e.S0, e.S1, e.C0, e.C1);
+    reinterpret_cast<float2*>(reinterpret_cast<float4*>(rowx) + (d_arg.n_theta + 4))[b] = make_float2(e.T0, e.T1);
+#else
     rowx[b] = e;
+#endif
   }
   for (int b = tid; b < 2 * d_arg.n_phi; b += nthr) {
     const int j = b < d_arg.n_phi ? b : b - d_arg.n_phi;
@@ -2903,6 +3057,7 @@ isx_bin_cols_kernel(const DetGrid d_arg, const Work wk) {
   const volatile LdsDetGrid& d = *(const volatile LdsDetGrid*)d_lds;
 
   const uint32_t n_regions = wk.ctr[Q_REGIONS];   // (the trace kernel of this launch has completed)
+  ISX_BD_INIT(sq);
 #pragma unroll 1
   for (;;) {
     uint32_t unit = 0;
@@ -2934,6 +3089,7 @@ isx_bin_cols_kernel(const DetGrid d_arg, const Work wk) {
         lp.x = a.x; lp.y = a.y; lp.z = b.x; lv.x = b.y; lv.y = c.x; lv.z = c.y;
         pre = prep_cols(k, dcol.n_phi, lp, lv, 0);
       }
+      ISX_BD_MARK(sq, 0);
       { const int n_far = (int)__popcll(__ballot(have && pre.kind == -2)); (void)n_far; ISX_DIAG_ADD(3, n_far); }
       // lines off the fast path: one at a time, lane = row (cap or box windows), as in isx_bin_lines_kernel
       unsigned long long em = __ballot(have && pre.kind == -1);

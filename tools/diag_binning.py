@@ -25,8 +25,13 @@ def run(name, c, n):
            "WRONG_DECISIONS": int(d[14]), "candidates_total": int(d[7] + d[8] + d[9]),
            "lane_fill": {"fast": d[7] / max(d[4] * 64, 1), "caps": d[8] / max(d[5] * 64, 1), "fallback": d[9] / max(d[6] * 64, 1)}}
     if d[16:22].sum() > 0:   # binning kernel with slot queues: share of the waves' cycles per region (ISX_BD_MARK)
-        names = ["batch_prep", "producers", "push", "pop_fetch_t0", "coefficients_and_walk", "unit_bookkeeping"]
-        out["slot_kernel_wave_cycle_share"] = {n: round(float(v / d[16:22].sum()), 4) for n, v in zip(names, d[16:22])}
+        # isx_bin_slots_kernel (BRDF source) / isx_bin_cols_kernel (pencil source): what the six marks bracket
+        names = (["batch_prep", "producers", "push", "pop_fetch_t0", "coefficients_and_walk", "unit_bookkeeping"] if name == "brdf" else
+                 ["batch_prep", "producers", "push", "pop", "slot_prologue", "walk"])
+        if name != "brdf":   # finer marks inside the column producer
+            names += ["owner_search", "cap_through_bpermute", "cap_rows", "producer_loop_and_drain_check"]
+        tot = d[16:16 + len(names)].sum()
+        out["slot_kernel_wave_cycle_share"] = {n: round(float(v / tot), 4) for n, v in zip(names, d[16:16 + len(names)])}
         out["slot_kernel_wave_cycles_per_pass"] = float(d[16:22].sum() / max(d[11], 1))
     print(name, json.dumps(out, indent=1))
 c = isx.default_config()
