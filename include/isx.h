@@ -40,8 +40,11 @@ extern "C" {
 /* Results are a pure function of (configuration, seed, ray indices) AND of the random-number layout below; a build with
  * another ISX_STREAM_VERSION gives different (equally valid) histograms for the same seed.
  * 3: Philox4x32-10, counter (ray lo, ray hi, block, stream); interaction j takes words (2(j&1), 2(j&1)+1) of block j/2;
- *    absorption and azimuth share one word; Householder cosine emission. */
-#define ISX_STREAM_VERSION 3
+ *    absorption and azimuth share one word; Householder cosine emission.
+ * 4: the same generator and word layout; the cosine emission is n + s with s a uniform point of the unit sphere in world
+ *    coordinates (first word: its z, second word: its azimuth), left un-normalised on the inner sphere, and the next wall point
+ *    is p - 2 (p.v)/(v.v) v.  The explicit and the chord trace mode visit the same wall points since. */
+#define ISX_STREAM_VERSION 4
 
 typedef enum isx_status {
   ISX_OK = 0,

@@ -34,7 +34,7 @@ def test_library_exports_every_declared_symbol(mod):
 
 def test_abi_version_and_struct_layout(mod):
     assert mod.load().isx_abi_version() == 3
-    assert mod.load().isx_stream_version() == 3
+    assert mod.load().isx_stream_version() == 4
     # isx_config: 2 u32, 6 dbl, 2 i32, 6 dbl, 2 i32, 3 dbl, 2 i32, 3 dbl, 2 i32 ; isx_stats: 7 u64 + dbl
     assert C.sizeof(mod.Config) == 8 + 8 * 6 + 8 + 8 * 6 + 8 + 8 * 3 + 8 + 8 * 3 + 8
     assert mod.Config.struct_size.offset == 0
