@@ -1667,10 +1667,15 @@ __device__ __forceinline__ void chord_leave(Ray& r) {   // T lies in the port op
 template <bool DEFER = false>
 __device__ __forceinline__ bool chord_arrive(const Hot& h, Ray& r, V3& q) {
   if (r.v.z >= h.zcut_in) {
-    V3 d;
-    d.x = r.v.x - r.p.x; d.y = r.v.y - r.p.y; d.z = r.v.z - r.p.z;
     r.tgt = false;
-    q = r.v; r.v = d;
+    q = r.v;
+    if (!DEFER) {   // the last chord P -> T as the ray's direction: only the end-state interface reports the direction of a ray
+                    // that is absorbed at T; the persistent kernels (DEFER) never look at it, and forming it cost them three
+                    // subtractions and a register shuffle per bounce
+      V3 d;
+      d.x = r.v.x - r.p.x; d.y = r.v.y - r.p.y; d.z = r.v.z - r.p.z;
+      r.v = d;
+    }
     return true;
   }
   if (!DEFER) chord_leave(r);
