@@ -108,3 +108,39 @@ def test_circle_point_is_a_uniform_unit_circle_point(orc):
     assert np.abs((cs ** 2).sum(1) - 1).max() < 3e-15
     ang = 2 * np.pi * (u - 0.5)
     assert np.abs(cs[:, 0] - np.cos(ang)).max() < 2e-15 and np.abs(cs[:, 1] - np.sin(ang)).max() < 2e-15
+
+
+def test_cosine_emission_is_the_cosine_law_about_the_normal(orc):
+    """interact()'s emission n + s (s uniform on the unit sphere, world coordinates; oracle/isx_oracle.c cosine_emission):
+    cos^2 of the polar angle about the geometric normal is uniform (the cosine law: P(cos <= x) = x^2), the azimuth about the
+    normal is uniform and independent of it, nothing is emitted into the wall; on the inner sphere the vector is r_in s - q
+    (un-normalised, |w| <= 2 r_in), elsewhere a unit vector."""
+    from scipy import stats
+    c = orc.default_config()
+    rng = np.random.default_rng(41)
+    rho_thr = int(np.ceil(c.reflectance * 2.0 ** 32 - 0.5))
+    for kind, radius in ((1, c.r_in), (2, c.r_out)):
+        # one surface point with a generic normal; the two words are the random input
+        th, ph = 0.7, 2.1
+        q = radius * np.array([np.sin(th) * np.cos(ph), np.sin(th) * np.sin(ph), np.cos(th)])
+        n = orc.surface_normal(c, kind, q)
+        assert abs(np.linalg.norm(n) - 1) < 1e-12
+        m = 40000
+        wa = rng.integers(0, 2 ** 32, m, dtype=np.uint64)
+        wb = rng.integers(0, rho_thr, m, dtype=np.uint64)
+        w = np.array([orc.cosine_emission(c, kind, q, int(a), int(b)) for a, b in zip(wa, wb)])
+        ln = np.linalg.norm(w, axis=1)
+        if kind == 1:
+            assert ln.max() <= 2 * c.r_in * (1 + 1e-12) and ln.min() > 0
+        else:
+            assert np.abs(ln - 1).max() < 4e-16
+        u = w / ln[:, None]
+        ct = u @ n
+        assert ct.min() > 0                                            # never into the wall
+        assert stats.kstest(ct * ct, "uniform").pvalue > 1e-3           # cosine law
+        assert abs(ct.mean() - 2.0 / 3.0) < 4 * np.sqrt(1.0 / 18.0 / m)  # E cos = 2/3, Var cos = 1/18
+        e1 = np.cross(n, [0.0, 0.0, 1.0]); e1 /= np.linalg.norm(e1)
+        e2 = np.cross(n, e1)
+        az = (np.arctan2(u @ e2, u @ e1) + np.pi) / (2 * np.pi)
+        assert stats.kstest(az, "uniform").pvalue > 1e-3                # azimuth uniform
+        assert abs(np.corrcoef(az, ct * ct)[0, 1]) < 4 / np.sqrt(m)     # ... and independent of the polar angle
