@@ -308,7 +308,7 @@ def main():
 
         kern = pj.get("kernels", {})
         k_trace = next((k for k in kern if "trace" in k), "isx_trace_assist_kernel")
-        k_bin = next((k for k in kern if "bin" in k), "isx_bin_slots_kernel")
+        k_bin = next((k for k in kern if "bin" in k), "isx_bin_cols_kernel")
         if pipeline:
             b_trace = issue_block(k_trace, t_trace, kern.get(k_trace))
             b_bin = issue_block(k_bin, t_bin, kern.get(k_bin))
