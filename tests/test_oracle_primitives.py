@@ -144,3 +144,21 @@ def test_cosine_emission_is_the_cosine_law_about_the_normal(orc):
         az = (np.arctan2(u @ e2, u @ e1) + np.pi) / (2 * np.pi)
         assert stats.kstest(az, "uniform").pvalue > 1e-3                # azimuth uniform
         assert abs(np.corrcoef(az, ct * ct)[0, 1]) < 4 / np.sqrt(m)     # ... and independent of the polar angle
+
+
+def test_exit_directions_are_unit_vectors_in_both_trace_modes(orc):
+    """The bounce works with un-normalised directions (rule S1' takes any length); a ray that leaves the rule is given a unit
+    direction first, so what leaves the port -- the direction Detector::checkIntersection is handed -- is a unit vector to
+    1 ulp, as ROBAST's is.  And the explicit and the chord mode visit the same wall points (to rounding)."""
+    out = []
+    for mode in (0, 1):
+        c = orc.default_config()
+        c.trace_mode = mode
+        ids, d, cnt = orc.exit_directions(c, 40000, 77)
+        assert cnt > 10000 and np.abs(np.linalg.norm(d, axis=1) - 1).max() < 3e-16
+        out.append((ids, d))
+    common = np.intersect1d(out[0][0], out[1][0])
+    assert len(common) > 0.999 * max(len(out[0][0]), len(out[1][0]))   # the same rays leave ...
+    a = out[0][1][np.isin(out[0][0], common)]
+    b = out[1][1][np.isin(out[1][0], common)]
+    assert np.abs(a - b).max() < 1e-9                                  # ... along the same directions
