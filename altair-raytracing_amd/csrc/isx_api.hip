@@ -550,6 +550,27 @@ int enqueue(int sink, const isx_config* c, uint64_t n, uint64_t seed, uint64_t f
     }
     return ISX_OK;
   }
+  // ---- the per-position sinks (one launch for all positions: the reference's 12 524 s map, the macro's own disc loop) with an
+  // assist wave per workgroup as well: the one exact test per exiting ray is per-lane work the assist wave does on the spot
+  if ((sink == SINK_PERPOS || sink == SINK_DISCPOS) && lean_explicit && S.pipeline && S.assist) {
+    const KernelFn afn = sink == SINK_PERPOS ? isx_trace_assist_perpos_kernel : isx_trace_assist_discpos_kernel;
+    const int pblock = S.assist_block;
+    const size_t lds_trace = 16 + 64 + sizeof(Geom) + sizeof(DetGrid) + 16 + sizeof(AssistQueues) + (size_t)(kResumeCap + kPendCap) * 64;
+    if (S.attr_lds[(const void*)afn] != lds_trace) {
+      HIPCHK(hipFuncSetAttribute((const void*)afn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_trace));
+      S.attr_lds[(const void*)afn] = lds_trace;
+    }
+    const int tres = S.trace_blocks_per_cu > 0 ? S.trace_blocks_per_cu : resident_per_cu(afn, pblock, lds_trace);
+    rc = span(0, &e0); if (rc) return rc;
+    for (uint64_t off = 0; off < n; off += kLaunchMax) {
+      Work w2 = wk;
+      w2.first = first + off; w2.n = n - off < kLaunchMax ? n - off : kLaunchMax; w2.sub = pick_sub(w2.n);
+      rc = next_ctr(&w2.ctr); if (rc) return rc;
+      hipLaunchKernelGGL(afn, dim3(pick_grid(w2.n, pblock, tres)), dim3(pblock), lds_trace, S.stream, g, d, w2);
+      HIPCHK(hipGetLastError());
+    }
+    return span(0, nullptr);
+  }
   if (S.attr_lds[(const void*)fn] != lds) {
     HIPCHK(hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     S.attr_lds[(const void*)fn] = lds;

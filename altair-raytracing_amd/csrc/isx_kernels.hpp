@@ -2249,7 +2249,10 @@ enum : uint32_t { IDO_SCATTERED = 0x80000000u, IDO_TARGET = 0x40000000u };   // 
 // DISC (the shared-ray physical-disc sweep, integratingSphereDetectorSweep.C:134-172 / SINK_DISC): the assist wave writes, for
 // EVERY ray that leaves for the world box, its forward exit segment -- start point, direction, length (8 doubles per slot) --
 // and isx_bin_discs_kernel tests the segments against the discs.
-template <int CH, bool RESC, bool DISC = false>
+// PP (the per-position sinks, one launch for all positions): 1 = SINK_PERPOS (a ray is tested against the detector(s) of its own
+// group only), 2 = SINK_DISCPOS (its forward exit segment against its own disc only) -- per-lane work at the exit, so the
+// assist wave does it on the spot and adds the rare hit to the global bins; no exit lines, no second kernel.
+template <int CH, bool RESC, bool DISC = false, int PP = 0>
 __device__ __forceinline__ void assist_body(const Geom& g_arg, const DetGrid& d_arg, const Work& wk) {
   constexpr bool LEAN = true;
   extern __shared__ __align__(16) unsigned char smem[];
@@ -2285,6 +2288,7 @@ __device__ __forceinline__ void assist_body(const Geom& g_arg, const DetGrid& d_
   auto add = [](uint32_t* p, uint32_t v) { return __hip_atomic_fetch_add(p, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP); };
   uint32_t n_wall = 0;                                   // per lane
   uint32_t n_exited = 0, n_counted = 0, n_susp = 0, n_ended = 0, n_taken = 0;   // per wave
+  unsigned long long n_inc = 0;                           // per wave: bin increments of the per-position sinks
 
   if ((tid >> 6) < n_tracers) {
     // =============================================================== tracer waves
@@ -2516,7 +2520,7 @@ __device__ __forceinline__ void assist_body(const Geom& g_arg, const DetGrid& d_
           else if (r.on == K_INNER) unit_dir(r.v);   // handed over by a tracer whose rule S1' failed: unit direction from here on
           V3 q;
           const int kind = next_hit_generic(g, r.p, r.v, r.on, q);
-          st = ray_arrive<DISC, LEAN, CH, PH_DIRECT>(h, g, r, seed, first, kind, q);   // (DISC: r.prev = start of this segment)
+          st = ray_arrive<DISC || PP == 2, LEAN, CH, PH_DIRECT>(h, g, r, seed, first, kind, q);   // (DISC: r.prev = start of this segment)
           if (RESC && st != 0 && h.source_model == 1 && !r.scattered()) {   // nonLambertianFlux.C:253-268
             n_wall += r.j;
             ray_rescatter(g, r, seed, first);
@@ -2566,8 +2570,39 @@ __device__ __forceinline__ void assist_body(const Geom& g_arg, const DetGrid& d_
       n_exited += (uint32_t)__popcll(__ballot(exited));
       n_susp += (uint32_t)__popcll(__ballot(have && st == ST_SUSPENDED));
       n_counted += (uint32_t)__popcll(__ballot(below));
-      const bool keep = DISC ? exited : below;                        // what goes to the binning kernel
-      const unsigned long long m = __ballot(keep);
+      const bool keep = (DISC || PP == 2) ? exited : below;           // what goes to the binning kernel (or is binned here: PP)
+      if (PP != 0) {
+        // persistent_body's SINK_PERPOS / SINK_DISCPOS, per lane: the ray's own detector group (disc) only
+        bool hit0 = false, hit1 = false;
+        int b0 = 0, b1 = 0;
+        if (keep) {
+          const uint64_t rel = (first + (uint64_t)r.offset()) - d_arg.map_first, rpg = d_arg.rays_per_group;
+          uint64_t grp = (uint64_t)((double)rel / (double)rpg);
+          if (grp * rpg > rel) grp--;
+          else if ((grp + 1) * rpg <= rel) grp++;
+          if (PP == 1) {
+            const double* table = d_arg.table;
+            if (d_arg.fold == 2) {
+              const int nphi = d_arg.n_phi, half = nphi / 2;
+              const int i = (int)(grp / (uint64_t)half), j = (int)(grp % (uint64_t)half);
+              b0 = i * nphi + j;
+              b1 = b0 + half;
+              hit1 = check_intersection(table + 6 * (size_t)b1, d_arg.half_w2, r.p, r.v);
+            } else {
+              b0 = (int)grp;
+            }
+            hit0 = check_intersection(table + 6 * (size_t)b0, d_arg.half_w2, r.p, r.v);
+          } else {
+            b0 = (int)grp;
+            V3 dl; dl.x = r.p.x - r.prev.x; dl.y = r.p.y - r.prev.y; dl.z = r.p.z - r.prev.z;
+            hit0 = segment_hits_tube(r.prev, r.v, dot3(dl, r.v), d_arg.discs + 6 * (size_t)b0, d_arg.disc_r, d_arg.disc_h);
+          }
+        }
+        if (hit0) atomicAdd(&wk.hist[b0], 1ull);
+        if (hit1) atomicAdd(&wk.hist[b1], 1ull);
+        n_inc += (unsigned long long)__popcll(__ballot(hit0)) + (unsigned long long)__popcll(__ballot(hit1));
+      }
+      const unsigned long long m = PP != 0 ? 0ull : __ballot(keep);
       if (m) {
         const uint32_t cnt = (uint32_t)__popcll(m);
         if (cnt > reg_left) {   // close the open region, reserve the next one (kRegion)
@@ -2631,6 +2666,7 @@ __device__ __forceinline__ void assist_body(const Geom& g_arg, const DetGrid& d_
   // ---- census (persistent_body's epilogue)
   atomicAdd(&sstat[6], (unsigned long long)n_wall);
   if (lane == 0) {
+    if (PP != 0 && n_inc) atomicAdd(&sstat[5], n_inc);
     atomicAdd(&sstat[1], (unsigned long long)n_exited);
     atomicAdd(&sstat[2], (unsigned long long)n_counted);
     atomicAdd(&sstat[3], (unsigned long long)(n_ended - n_exited - n_susp));  // absorbed
@@ -2661,6 +2697,10 @@ extern "C" __global__ void ISX_ASSIST_ATTR
 isx_trace_assist_brdf_kernel(const Geom g, const DetGrid d, const Work wk) { assist_body<0, true>(g, d, wk); }
 extern "C" __global__ void ISX_ASSIST_ATTR
 isx_trace_assist_disc_kernel(const Geom g, const DetGrid d, const Work wk) { assist_body<0, false, true>(g, d, wk); }
+extern "C" __global__ void ISX_ASSIST_ATTR
+isx_trace_assist_perpos_kernel(const Geom g, const DetGrid d, const Work wk) { assist_body<0, false, false, 1>(g, d, wk); }
+extern "C" __global__ void ISX_ASSIST_ATTR
+isx_trace_assist_discpos_kernel(const Geom g, const DetGrid d, const Work wk) { assist_body<0, false, false, 2>(g, d, wk); }
 
 // ------------------------------------------------------------------ disc-binning kernel of the shared-ray disc sweep
 // Persistent waves take quarter regions of exit segments (isx_trace_assist_disc_kernel) off the launch's queue, 64 segments at a

@@ -171,3 +171,32 @@ def test_two_row_walk_never_counts_a_bin_twice(isx, geo):
     finally:
         isx.set_option("bin_mode", 1)
         _reset(isx)
+
+
+@pytest.mark.gpu
+def test_per_position_sinks_with_and_without_the_assist_wave(isx, orc):
+    """The per-position map (fluxAtObserverOptimize.C:542-579, also twofold) and the per-position disc sweep
+    (integratingSphereDetectorSweep.C:54-77) run with an assist wave per workgroup by default: the one exact test per exiting
+    ray is done by the assist wave, the hit goes straight to the global bins ("assist" = 0: round 2's persistent kernels with
+    their batched generic search).  Same maps, same census, == oracle, for several workgroup shapes and tiny grids."""
+    from test_gpu_round2 import _disc_cfg, _disc_positions
+    c = isx.default_config(); c.n_theta, c.n_phi = 12, 10
+    co = orc.default_config(); co.n_theta, co.n_phi = 12, 10
+    ca = _disc_positions(dtheta=5.0)
+    try:
+        for fold in (1, 2):
+            oh, ost = orc.fluxmap_per_position(co, 900, 4242, fold, first=10 ** 9)
+            for assist, block, grid in ((0, 768, 0), (1, 768, 0), (1, 256, 3), (1, 512, 1)):
+                isx.set_option("assist", assist); isx.set_option("assist_block", block); isx.set_option("grid_blocks", grid)
+                gh, gst = isx.fluxmap_per_position(c, 900, 4242, fold, first_ray=10 ** 9)
+                assert np.array_equal(gh, oh), (fold, assist, block, grid)
+                _same(gst, ost)
+                assert gst.bin_increments == int(gh.sum())
+        od, odst = orc.disc_sweep_per_position(_disc_cfg(orc), ca, 5.0, 0.1, 15000, 7, 123)
+        for assist, block, grid in ((0, 768, 0), (1, 768, 0), (1, 384, 2)):
+            isx.set_option("assist", assist); isx.set_option("assist_block", block); isx.set_option("grid_blocks", grid)
+            gd, gdst = isx.disc_sweep_per_position(_disc_cfg(isx), ca, 5.0, 0.1, 15000, 7, 123)
+            assert np.array_equal(gd, od) and gd.sum() > 0, (assist, block, grid)
+            _same(gdst, odst)
+    finally:
+        _reset(isx)
