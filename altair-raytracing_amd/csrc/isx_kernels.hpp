@@ -481,12 +481,46 @@ __device__ __forceinline__ void walk_columns(const D& d, uint32_t* __restrict__ 
 // four forms and g of BOTH candidates are packed binary32 operations -- the same expressions in the same order as walk_columns,
 // hence the same error bound and band -- 12 v_pk instructions for two candidates where one at a time took 4 + 5 each.  The second
 // candidate of the last step of an odd window is masked.  Tiers 2 and 3 as in walk_columns, for whichever of the two needs them.
+constexpr int kDeferCapW = 124;   // (the deferred list of a wave: 128 words, two entries per lane)
+// Tiers 2 and 3 of the decision for candidate (row ir, column jr) of the line at src6 (walk_columns: binary64 about the original point
+// with its 2.1e-9 band, then the reference's own test from the detector table).
+template <class D>
+__device__ __forceinline__ bool decide_exact(const D& d, const double* __restrict__ rowt, const ColX* __restrict__ colx,
+                                             const double* __restrict__ src6, int ir, int jr) {
+  const double sd = rowt[4 * ir + 0], cd = rowt[4 * ir + 1], zz = rowt[4 * ir + 2], ad = rowt[4 * ir + 3];
+  const double cph = colx[jr].c, sph = colx[jr].s;
+  V3 P, V;
+  {
+    const double2* src = reinterpret_cast<const double2*>(src6);
+    const double2 a = src[0], b = src[1], c = src[2];
+    P.x = a.x; P.y = a.y; P.z = b.x; V.x = b.y; V.y = c.x; V.z = c.y;
+  }
+  const double pz = P.z - zz;
+  const double dotd = fma(sd * V.y, cph, fma(-(sd * V.x), sph, -(cd * V.z)));
+  const double numd = fma(sd * P.y, cph, fma(-(sd * P.x), sph, -(cd * pz)));
+  const double m2dv = fma(2.0 * (ad * V.x), cph, fma(2.0 * (ad * V.y), sph, -2.0 * fma(P.x, V.x, fma(P.y, V.y, pz * V.z))));
+  const double f0 = fma(P.x, P.x, fma(P.y, P.y, fma(ad, ad, pz * pz)));
+  const double f1c = -2.0 * (ad * P.x), f2c = -2.0 * (ad * P.y);
+  const double ddwd = fma(f1c, cph, fma(f2c, sph, f0 - d.half_w2));
+  const double diff = fma(dotd, fma(dotd, ddwd, numd * m2dv), numd * numd);
+  const double bandc = 2.1e-9 * fma(2.0, f0 + (fabs(f1c) + fabs(f2c)), d.half_w2);
+  bool hit = diff < 0.0;
+  if (fabs(dotd) < 1e-4 || fabs(diff) <= bandc) {
+    ISX_DIAG_ADD_LANES(13, 1);
+    const double* tab = d.table;
+    asm volatile("" : "+v"(tab));
+    hit = check_intersection(tab + 6 * (size_t)(ir * d.n_phi + jr), d.half_w2, P, V);
+  }
+  return hit;
+}
+
 struct __align__(16) ColP { float c0, c1, s0, s1; uint32_t off0, off1, pad0, pad1; };
 
 template <class D>
 __device__ __forceinline__ void walk_columns_pairs(const D& d, uint32_t* __restrict__ hist, const ColX* __restrict__ colx,
                                                    const ColP* __restrict__ colp, double t0, int i, const double* __restrict__ rowt,
-                                                   int jlo, int len, const double* __restrict__ line6, int lane) {
+                                                   int jlo, int len, const double* __restrict__ line6, int lane,
+                                                   LdsWord* defer = nullptr, int line = 0) {
   float a0f = 0.f, a1f = 0.f, a2f = 0.f, b0f = 0.f, b1f = 0.f, b2f = 0.f, e0f = 0.f, e1f = 0.f, e2f = 0.f, f0f = 0.f, f1f = 0.f, f2f = 0.f;
   float band32 = 0.f;
   if (len > 0) {
@@ -542,32 +576,20 @@ __device__ __forceinline__ void walk_columns_pairs(const D& d, uint32_t* __restr
           ISX_DIAG_ADD_LANES(12, 1);
           int ir = i;
           asm volatile("" : "+v"(ir));
-          const double sd = rowt[4 * ir + 0], cd = rowt[4 * ir + 1], zz = rowt[4 * ir + 2], ad = rowt[4 * ir + 3];
           const uint32_t o4 = t == 0 ? off.x : off.y;
           const int jc = (int)(o4 >> 2);
-          const double cph = colx[jc].c, sph = colx[jc].s;
-          V3 P, V;
-          {
-            const double2* src = reinterpret_cast<const double2*>(line6 + (ir - i));
-            const double2 a = src[0], b = src[1], c = src[2];
-            P.x = a.x; P.y = a.y; P.z = b.x; V.x = b.y; V.y = c.x; V.z = c.y;
-          }
-          const double pz = P.z - zz;
-          const double dotd = fma(sd * V.y, cph, fma(-(sd * V.x), sph, -(cd * V.z)));
-          const double numd = fma(sd * P.y, cph, fma(-(sd * P.x), sph, -(cd * pz)));
-          const double m2dv = fma(2.0 * (ad * V.x), cph, fma(2.0 * (ad * V.y), sph, -2.0 * fma(P.x, V.x, fma(P.y, V.y, pz * V.z))));
-          const double f0 = fma(P.x, P.x, fma(P.y, P.y, fma(ad, ad, pz * pz)));
-          const double f1c = -2.0 * (ad * P.x), f2c = -2.0 * (ad * P.y);
-          const double ddwd = fma(f1c, cph, fma(f2c, sph, f0 - d.half_w2));
-          const double diff = fma(dotd, fma(dotd, ddwd, numd * m2dv), numd * numd);
-          const double bandc = 2.1e-9 * fma(2.0, f0 + (fabs(f1c) + fabs(f2c)), d.half_w2);
-          bool hit = diff < 0.0;
-          if (fabs(dotd) < 1e-4 || fabs(diff) <= bandc) {
-            ISX_DIAG_ADD_LANES(13, 1);
-            const double* tab = d.table;
-            asm volatile("" : "+v"(tab));
-            hit = check_intersection(tab + 6 * (size_t)(ir * d.n_phi + jc), d.half_w2, P, V);
-          }
+          // put aside for flush_deferred (a miss here), or -- no list (the kernels that walk one line at a time), list full,
+          // tuning build -- decided on the spot
+          bool hit = false;
+          typedef __attribute__((address_space(3))) uint32_t LdsCnt;
+#ifdef ISX_DIAG
+          const uint32_t pos = (uint32_t)kDeferCapW;
+#else
+          const uint32_t pos = defer ? __hip_atomic_fetch_add(reinterpret_cast<LdsCnt*>(defer), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)
+                                     : (uint32_t)kDeferCapW;
+#endif
+          if (pos < (uint32_t)kDeferCapW) ((volatile LdsWord*)defer)[4 + pos] = (uint32_t)line | ((uint32_t)jc << 8) | ((uint32_t)ir << 16);
+          else hit = decide_exact(d, rowt, colx, line6 + (ir - i), ir, jc);
           if (t == 0) hit0 = hit; else hit1 = hit;
         }
       }
@@ -934,16 +956,47 @@ __device__ __forceinline__ void walk_lines_packed(const D& d, uint32_t* __restri
 // columns << 24 -- the kernel serves grids of at most 256 rows and 255 columns (anything else: isx_bin_lines_kernel).
 constexpr int kClasses = 7, kQueueCap = 128;   // a class never holds more than 63 + 64 slots
 constexpr int kSlotWaveWords = kClasses * kQueueCap + 16 + 64;   // LDS words per wave: queues, counters, owner marks
-constexpr int kColWaveWords = kClasses * kQueueCap + 16 + 64 + 64;   // the same + the long-row list of bin_culled
+constexpr int kDeferCap = kDeferCapW;   // candidates a wave can put aside for tiers 2 and 3
+constexpr int kColWaveWords = kClasses * kQueueCap + 16 + 64 + 64 + 4 + kDeferCap;   // the same + the long-row list of bin_culled + the deferred list (count, 3 spare, entries)
 constexpr int kPiece = 16, kLongest = 24;
 struct SlotQueues {
   LdsWord* q;         // [kClasses][kQueueCap]
   LdsInt* tail;       // [8] slots pushed per class (running)
   LdsInt* head;       // [8] slots popped per class (running)
   const ColP* colp;   // column-pair table of the workgroup (isx_bin_slots_kernel)
+  LdsWord* defer;     // [4 + kDeferCap] isx_bin_cols_kernel: [0] = entries held, [4..] = candidates that wait for tiers 2 and 3
 };
 __device__ __forceinline__ int slot_class(int cnt) {   // cnt in 1..kLongest
   return cnt <= 4 ? 0 : (cnt <= 12 ? (cnt - 3) >> 1 : (cnt <= 16 ? 5 : 6));
+}
+
+// The candidates a wave has put aside for tiers 2 and 3 (consume_cols): every lane owns two entries of the wave's deferred list
+// (0xffffffff = free), fills them as its walks meet candidates that tier 1 cannot decide -- a plain LDS write, nothing to wait
+// for -- and here, twice per unit, the wave decides them: lane = candidate, one line fetch and one exact decision per lane with
+// the whole wave at it, instead of one lane of a diverged wave waiting for its line to come back from L2 while the other 63
+// stand still (the ablation without tiers 2 and 3 runs 1.16 of 6.9 ms shorter, for 8e-4 of the candidates).
+// Entry: line within the unit | column << 8 | row << 16.  A hit goes to the bin; the walk added 0 for the candidate.
+constexpr uint32_t kDeferFree = 0xffffffffu;
+template <class D>
+__device__ __forceinline__ void flush_deferred(const D& d, uint32_t* __restrict__ hist, const double* __restrict__ rowt,
+                                               const ColX* __restrict__ colx, const double* __restrict__ lines, const SlotQueues& sq,
+                                               int lane) {
+  volatile LdsWord* df = sq.defer;
+  typedef __attribute__((address_space(3))) uint32_t LdsU32;
+#pragma unroll 1
+  for (int k = 0; k < 2; ++k) {
+    const uint32_t e = df[2 * lane + k];
+    const bool have = e != kDeferFree;
+    if (__ballot(have) == 0ull) continue;
+    const int line = (int)(e & 255u), jr = (int)((e >> 8) & 255u), ir = (int)((e >> 16) & 255u);
+    bool hit = false;
+    if (have) {
+      hit = decide_exact(d, rowt, colx, lines + 6 * line, ir, jr);
+      df[2 * lane + k] = kDeferFree;
+    }
+    if (hit) __hip_atomic_fetch_add(reinterpret_cast<LdsU32*>((__attribute__((address_space(3))) void*)hist) + (ir * d.n_phi + jr), 1u,
+                                    __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+  }
 }
 
 // one pass: 64 slots (fewer when a unit's leftovers are flushed), lane = slot
@@ -962,7 +1015,7 @@ __device__ __forceinline__ void consume_slots(const D& d, uint32_t* __restrict__
   }
   ISX_DIAG_ADD(11, 1);
   ISX_BD_MARK(sq, 3);
-  walk_columns_pairs(d, hist, colx, sq.colp, t0, i, rowt, jlo, len, src6, lane);
+  walk_columns_pairs(d, hist, colx, sq.colp, t0, i, rowt, jlo, len, src6, lane, sq.defer, line);
   ISX_BD_MARK(sq, 4);
 }
 
@@ -1306,6 +1359,11 @@ __device__ __forceinline__ void consume_cols(const D& d, uint32_t* __restrict__ 
   // (the row table as two arrays -- {S_i, S_i+1, C_i, C_i+1} at 16 bytes per row, {T_i, T_i+1} at 8 -- instead of one 32-byte
   //  entry: a 16-byte read then spreads over sixteen bank groups instead of eight, and the ablation that reads one entry for
   //  all lanes says that bank conflicts of these reads cost 1.1 of the kernel's 7.0 ms)
+  uint32_t dcnt;   // this lane's entries of the deferred list that are taken
+  {
+    const uint32_t e0 = ((volatile LdsWord*)sq.defer)[2 * lane], e1 = ((volatile LdsWord*)sq.defer)[2 * lane + 1];
+    dcnt = (e0 != kDeferFree ? 1u : 0u) + (e1 != kDeferFree ? 1u : 0u);   // (filled in order: entry 1 is never taken alone)
+  }
   const float4* rowA = reinterpret_cast<const float4*>(rowx);
   const float2* rowB = reinterpret_cast<const float2*>(rowA + (d.n_theta + 4));
   auto classify = [&](int ie, int kk, bool& h0, bool& h1) {
@@ -1320,7 +1378,10 @@ __device__ __forceinline__ void consume_cols(const D& d, uint32_t* __restrict__ 
     const isx_f2 g = __builtin_elementwise_fma(dot, __builtin_elementwise_fma(dot, ddw, num * mdv), num * num);
     bool hit0 = g.x < 0.f, hit1 = g.y < 0.f;
     if (one && !(fminf(fabsf(g.x), fabsf(g.y)) > band32)) {
-      // tiers 2 and 3 of walk_columns (binary64 about the original point with its 2.1e-9 band, then the reference's own test)
+      // What tier 1 cannot decide waits in the lane's two entries of the wave's deferred list (flush_deferred) and counts as a
+      // miss here; if both are taken -- a slot whose band is infinite sends every candidate this way -- it is decided on the
+      // spot.  (One list per wave with positions from an LDS atomic: 6.42 ms, the lane waits for the atomic's return; with
+      // positions from a wave-uniform count, ballot + mbcnt: 6.77 -- two more compares and ballots in EVERY step.)
 #pragma unroll 1
       for (int t = 0; t < 2; ++t) {
         const float gt = t == 0 ? g.x : g.y;
@@ -1331,33 +1392,18 @@ __device__ __forceinline__ void consume_cols(const D& d, uint32_t* __restrict__ 
         int ir = ilo + kk + t;
         asm volatile("" : "+v"(ir));
         bool hit = false;
-        {
-          const double sd = rowt[4 * ir + 0], cd = rowt[4 * ir + 1], zz = rowt[4 * ir + 2], ad = rowt[4 * ir + 3];
+#if defined(ISX_DIAG) && !defined(ISX_DIAG_TIMING_ONLY)
+        const bool room = false;   // (the tuning build re-decides every candidate right here: nothing is put aside)
+#else
+        const bool room = dcnt < 2u;
+#endif
+        if (room) {
+          ((volatile LdsWord*)sq.defer)[2 * lane + (int)dcnt] = (uint32_t)line | ((uint32_t)j << 8) | ((uint32_t)ir << 16);
+          dcnt += 1u;
+        } else {
           int jr = j;
           asm volatile("" : "+v"(jr));
-          const double cph = colx[jr].c, sph = colx[jr].s;
-          V3 P, V;
-          {
-            const double2* src = reinterpret_cast<const double2*>(src6 + (jr - j));
-            const double2 a = src[0], b = src[1], c = src[2];
-            P.x = a.x; P.y = a.y; P.z = b.x; V.x = b.y; V.y = c.x; V.z = c.y;
-          }
-          const double pz = P.z - zz;
-          const double dotd = fma(sd * V.y, cph, fma(-(sd * V.x), sph, -(cd * V.z)));
-          const double numd = fma(sd * P.y, cph, fma(-(sd * P.x), sph, -(cd * pz)));
-          const double m2dv = fma(2.0 * (ad * V.x), cph, fma(2.0 * (ad * V.y), sph, -2.0 * fma(P.x, V.x, fma(P.y, V.y, pz * V.z))));
-          const double f0 = fma(P.x, P.x, fma(P.y, P.y, fma(ad, ad, pz * pz)));
-          const double f1c = -2.0 * (ad * P.x), f2c = -2.0 * (ad * P.y);
-          const double ddwd = fma(f1c, cph, fma(f2c, sph, f0 - d.half_w2));
-          const double diff = fma(dotd, fma(dotd, ddwd, numd * m2dv), numd * numd);
-          const double bandc = 2.1e-9 * fma(2.0, f0 + (fabs(f1c) + fabs(f2c)), d.half_w2);
-          hit = diff < 0.0;
-          if (fabs(dotd) < 1e-4 || fabs(diff) <= bandc) {
-            ISX_DIAG_ADD_LANES(13, 1);
-            const double* tab = d.table;
-            asm volatile("" : "+v"(tab));
-            hit = check_intersection(tab + 6 * (size_t)(ir * d.n_phi + jr), d.half_w2, P, V);
-          }
+          hit = decide_exact(d, rowt, colx, src6 + (jr - j), ir, jr);
         }
         if (t == 0) hit0 = hit; else hit1 = hit;
       }
@@ -1410,6 +1456,7 @@ __device__ __forceinline__ void consume_cols(const D& d, uint32_t* __restrict__ 
       bin += 4u * row_bytes;
     }
   }
+  __builtin_amdgcn_wave_barrier();
 #else
   for (int k = 0;; k += 2) {
     const bool act = k < len;
@@ -2985,6 +3032,8 @@ isx_bin_slots_kernel(const DetGrid d_arg, const Work wk) {
   sq.tail = (LdsInt*)(mine + kClasses * kQueueCap);
   sq.head = sq.tail + 8;
   LdsInt* mrk = sq.head + 8;
+  sq.defer = nullptr;   // (a deferred list for tiers 2 and 3 as in isx_bin_cols_kernel was measured here: 50.93 against 50.91 ms on the
+                        //  BRDF source -- this kernel is VALU-bound, a diverged lane's wait for its line is covered by the other waves)
   if (lane < 16) sq.tail[lane] = 0;
   __syncthreads();
   ISX_BD_INIT(sq);
@@ -3114,7 +3163,9 @@ isx_bin_cols_kernel(const DetGrid d_arg, const Work wk) {
   sq.head = sq.tail + 8;
   LdsInt* mrk = sq.head + 8;
   LdsInt* spl = mrk + 64;
+  sq.defer = (LdsWord*)(spl + 64);
   if (lane < 16) sq.tail[lane] = 0;
+  sq.defer[2 * lane] = kDeferFree; sq.defer[2 * lane + 1] = kDeferFree;
   __syncthreads();
   typedef __attribute__((address_space(3))) DetGrid LdsDetGrid;
   const volatile LdsDetGrid& d = *(const volatile LdsDetGrid*)d_lds;
@@ -3191,8 +3242,10 @@ isx_bin_cols_kernel(const DetGrid d_arg, const Work wk) {
         produce_cols_packed(dcol, hist, rowt, colx, rowx, lines, sq, pc, incl - ncol, incl, total, k.inv_dth, k.n_theta, first_line, lane, mrk,
                             pre_first, side == 1);
       }
+      if (first_line == 64) flush_deferred(dcol, hist, rowt, colx, lines, sq, lane);   // half-way through the unit (and at its end)
     }
     drain_cols(dcol, hist, rowt, colx, rowx, lines, sq, 1, lane);   // the unit's leftovers, class by class
+    flush_deferred(dcol, hist, rowt, colx, lines, sq, lane);        // ... and what its walks put aside for tiers 2 and 3
   }
   __syncthreads();
   unsigned long long flushed = 0;
