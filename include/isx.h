@@ -179,7 +179,9 @@ int isx_last_kernel_ms(double* single_ms, double* trace_ms, double* bin_ms);
  *   "pipeline_chunk"  rays per trace / binning pair, default and maximum 2^26.  WORKSPACE: exit lines live in regions of 1024
  *                  slots; a chunk of n rays traced by W waves is given n/961 + W + 1 regions of 48 KB (3.4 GB for 2^26 rays),
  *                  allocated once and kept until isx_shutdown(); "overlap" keeps three of them
- *   "assist"       1 (default): trace kernels with an assist wave per workgroup; 0: round 2's kernels;
+ *   "assist"       1 (default): trace kernels with an assist wave per workgroup -- the flux-map pipelines, the
+ *                  shared-ray disc sweep and the per-position sinks (isx_fluxmap_per_position, isx_disc_sweep_per_position);
+ *                  0: round 2's kernels;
  *                  "assist_block" = their workgroup size (128..768, default 768 = 11 tracer waves + 1 assist wave)
  *   "bin_slots"    1 (default): binning kernels with slot queues by window length (grids up to 256 x 255); 0: round 2's
  *   "bin_cols"     1 (default): (line, COLUMN) slots for the pencil source, (line, row) slots for the BRDF source; 0: row slots
