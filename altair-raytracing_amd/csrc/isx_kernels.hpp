@@ -1068,6 +1068,70 @@ __device__ __forceinline__ void push_slots(const D& d, uint32_t* __restrict__ hi
   }
 }
 
+// What produce_general decides about a line before it touches a row, for the lane's OWN line (lane = line, once per batch of 64):
+// 0 = the line has caps (produce_general's cap construction), 1 = a grazing line: its box (box_line) and row range,
+// 2 = the line cannot hit anything.  Same formulas, same margins.
+template <class D>
+__device__ __forceinline__ int general_pre(const D& d, const V3& P, const V3& V, float inv_dth, BoxLine& bx, int& ilo, int& ihi) {
+  const double wz = P.z - d.portz;
+  const double wv = fma(P.x, V.x, fma(P.y, V.y, wz * V.z));
+  const double hx = fma(-wv, V.x, P.x), hy = fma(-wv, V.y, P.y), hz = fma(-wv, V.z, wz);
+  const float dO2 = (float)fma(hx, hx, fma(hy, hy, hz * hz));
+  const float Rf = (float)d.R, rho = (float)d.rho_d;
+  const float R2 = Rf * Rf;
+  const float dO = sqrt_cull(dO2);
+  const float a1 = dO + rho;
+  bool caps = a1 < 0.999f * Rf;
+  if (caps) {
+    const float sF = sqrt_cull(R2 - dO2);
+    const float smin = sqrt_cull(R2 - a1 * a1);
+    const float a0 = fmaxf(0.f, dO - rho);
+    const float smax = sqrt_cull(R2 - a0 * a0);
+    const float ext = fmaxf(sF - smin, smax - sF);
+    const float ch2 = fmaf(ext, ext, rho * rho) * 1.0001f + 1e-3f;
+    caps = 4.0f * (R2 - dO2) > 4.04f * ch2;
+  }
+  if (caps) return 0;
+  return box_line(d, P, V, inv_dth, bx, ilo, ihi) ? 1 : 2;
+}
+
+// producer: the rows of all GRAZING lines of a batch of 64 (general_pre = 1) packed over the lanes, as produce_packed packs the rows of
+// the fast-path lines: lane = (line, row); the line's box comes from its own lane through ds_bpermute.  produce_general took these lines
+// one at a time (lane = row: a third of the BRDF source's lines, ~900 instructions each, half of that kernel's time).
+// Same windows (box_window on the same box), each (line, row) once: same slots, other order.
+template <class D>
+__device__ __forceinline__ void produce_boxes_packed(const D& d, uint32_t* __restrict__ hist, const double* __restrict__ rowt,
+                                                     const ColX* __restrict__ colx, const double* __restrict__ lines, const SlotQueues& sq,
+                                                     const BoxLine& gbx, int gilo, int nrow, int excl, int incl, int total,
+                                                     float inv_dphi, float portz, int first_line, int lane, LdsInt* mark) {
+#pragma unroll 1
+  for (int base = 0; base < total; base += 64) {
+    const int g = base + lane;
+    bool have = g < total;
+    volatile LdsInt* mk = mark;
+    mk[lane] = 0;
+    __builtin_amdgcn_wave_barrier();
+    if (nrow > 0 && excl < base + 64 && incl > base) mk[(excl > base ? excl : base) - base] = lane + 1;
+    __builtin_amdgcn_wave_barrier();
+    const int m = mk[lane];
+    const unsigned long long low = __ballot(m != 0) & (~0ull >> (63 - lane));
+    const int pos = 63 - __builtin_clzll(low | 1ull);
+    int owner = mk[pos] - 1;
+    if (!have || owner < 0) { owner = 0; have = false; }
+    const int o_excl = __shfl(excl, owner, 64), o_ilo = __shfl(gilo, owner, 64);
+    BoxLine b;
+    b.smax = __shfl(gbx.smax, owner, 64); b.smin = __shfl(gbx.smin, owner, 64); b.vxy = __shfl(gbx.vxy, owner, 64);
+    b.avz = __shfl(gbx.avz, owner, 64); b.ivz = __shfl(gbx.ivz, owner, 64); b.dn = __shfl(gbx.dn, owner, 64);
+    b.Hm = __shfl(gbx.Hm, owner, 64); b.Hz = __shfl(gbx.Hz, owner, 64); b.phin = __shfl(gbx.phin, owner, 64);
+    b.rs = __shfl(gbx.rs, owner, 64); b.sig = __shfl(gbx.sig, owner, 64);
+    const int i = have ? o_ilo + (g - o_excl) : 0;
+    int j0 = 0, c0 = 0, j1 = 0, c1 = 0;
+    if (have) box_window(b, (float)rowt[4 * i + 2] - portz, (float)rowt[4 * i + 3], d.n_phi, inv_dphi, j0, c0, j1, c1);
+    push_slots(d, hist, rowt, colx, lines, sq, first_line + owner, i, j0, c0, lane);
+    if (__ballot(c1 > 0) != 0ull) push_slots(d, hist, rowt, colx, lines, sq, first_line + owner, i, j1, c1, lane);
+  }
+}
+
 // producer: a line off the fast path (wave-uniform P, V; lane = row), cap windows around its two piercing points or box windows
 template <class DG, class D>
 __device__ inline void produce_general(const DG& dd, const D& dfast, uint32_t* __restrict__ hist, const double* __restrict__ rowt,
@@ -3067,8 +3131,32 @@ isx_bin_slots_kernel(const DetGrid d_arg, const Work wk) {
       }
       { const int n_far = (int)__popcll(__ballot(have && pre.rows == -2)); (void)n_far; ISX_DIAG_ADD(3, n_far); }
       ISX_BD_MARK(sq, 0);
-      // lines off the fast path: one at a time, lane = row (cap or box windows)
-      unsigned long long em = __ballot(have && pre.rows == -1);
+      // lines off the fast path.  What is decided about such a line before its rows -- caps or a box, the box, its row range --
+      // is evaluated by the line's own lane (general_pre); the grazing lines' rows are then packed over the lanes
+      // (produce_boxes_packed); the lines with general caps are taken one at a time, lane = row (produce_general)
+      BoxLine gbx;
+      gbx.smax = gbx.smin = gbx.vxy = gbx.avz = gbx.ivz = gbx.dn = gbx.Hm = gbx.Hz = gbx.phin = gbx.rs = gbx.sig = 0.f;
+      int gk = 2, gilo = 0, gihi = -1;
+      if (have && pre.rows == -1) {
+        struct { int n_theta; double rho_d, R, portz; } dg;
+        dg.n_theta = d.n_theta; dg.rho_d = d.rho_d; dg.R = d.R; dg.portz = d.portz;
+        gk = general_pre(dg, lp, lv, k.inv_dth, gbx, gilo, gihi);
+      }
+      { const int n_box = (int)__popcll(__ballot(gk == 1 && have && pre.rows == -1)); (void)n_box; ISX_DIAG_ADD(2, n_box); }
+      {
+        const int nrow = (have && pre.rows == -1 && gk == 1) ? gihi - gilo + 1 : 0;
+        int incl = nrow;
+#pragma unroll
+        for (int dlt = 1; dlt < 64; dlt <<= 1) {
+          const int o = __shfl_up(incl, dlt, 64);
+          if (lane >= dlt) incl += o;
+        }
+        const int total = __builtin_amdgcn_readlane(incl, 63);
+        if (total > 0)
+          produce_boxes_packed(dfast, hist, rowt, colx, lines, sq, gbx, gilo, nrow, incl - nrow, incl, total, k.inv_dphi, k.portz, first_line,
+                               lane, mrk);
+      }
+      unsigned long long em = __ballot(have && pre.rows == -1 && gk == 0);
       while (em) {
         const int src = __builtin_ctzll(em);
         em &= em - 1ull;
