@@ -2346,6 +2346,7 @@ constexpr uint32_t kPendCap = 512, kResumeCap = 128;
 constexpr uint32_t kSpinLimit = 1u << 22;
 struct AssistQueues {   // LDS, one per workgroup
   uint32_t pend_res, pend_pub, pend_head, resume_pub, resume_head, busy, tracers_done, failed;
+  uint32_t drain, pad0, pad1, pad2;   // drain: a tracer wave has no ray left and none to get (the assist wave stops waiting for full batches)
 };
 enum : uint32_t { IDO_SCATTERED = 0x80000000u, IDO_TARGET = 0x40000000u };   // Ray::ido flags in a queue record (offsets < 2^30)
 
@@ -2380,7 +2381,7 @@ __device__ __forceinline__ void assist_body(const Geom& g_arg, const DetGrid& d_
     g_lds->q0[0] = q0.x; g_lds->q0[1] = q0.y; g_lds->q0[2] = q0.z;
     g_lds->q0_ok = ok ? 1 : 0;
   }
-  if (tid == 0) { *d_lds = d_arg; AssistQueues z = {0, 0, 0, 0, 0, 0, 0, 0}; *Q = z; }
+  if (tid == 0) { *d_lds = d_arg; AssistQueues z = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}; *Q = z; }
   __syncthreads();
   typedef __attribute__((address_space(3))) Geom LdsGeom;
   const volatile LdsGeom& g = *(const volatile LdsGeom*)g_lds;
@@ -2468,6 +2469,7 @@ __device__ __forceinline__ void assist_body(const Geom& g_arg, const DetGrid& d_
         if (__ballot(run || hand) == 0ull) {
           // no ray in this wave and none to be had from the launch; rays of this workgroup may still come back
           if (ld(&Q->busy) == 0u) break;
+          if (spins == 0u && lane == 0) __hip_atomic_store(&Q->drain, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
           if (++spins > kSpinLimit) { if (lane == 0) add(&Q->failed, 1u); break; }
           ISX_TD_ADD(13, 1);
           __builtin_amdgcn_s_sleep(8);
@@ -2587,10 +2589,11 @@ __device__ __forceinline__ void assist_body(const Geom& g_arg, const DetGrid& d_
       // A few rays only: wait a little for more.  A batch costs the same ~500 instructions whether it holds 8 rays or 64, and
       // taken as they came the batches held ~8 (this wave has priority on its SIMD and was back at the queue before the eleven
       // tracers had handed over more).  Bounded (ISX_ASSIST_LAZY polls of 512 cycles: the last rays of a launch are held back
-      // by 27 us at most per generation), and over as soon as the first tracer wave of the workgroup has left.  (Ending it
-      // when a tracer finds the launch's ray queue empty was measured: 11.48 against 11.35 ms -- the waves still hold
-      // sub-ranges then.)  Scheduling only.
-      if (n < (uint32_t)ISX_ASSIST_MIN && lazy < (uint32_t)ISX_ASSIST_LAZY && ld(&Q->tracers_done) == 0u) {
+      // by 27 us at most per generation), and over as soon as a tracer wave of the workgroup stands idle -- no ray left, none
+      // to get from the launch's queue: from then on every batch that waits keeps a wave waiting.  (Ending it earlier, when a
+      // tracer finds the launch's ray queue empty, was measured: 11.48 against 11.35 ms -- the waves still hold sub-ranges
+      // then.)  Scheduling only.
+      if (n < (uint32_t)ISX_ASSIST_MIN && lazy < (uint32_t)ISX_ASSIST_LAZY && ld(&Q->drain) == 0u) {
         ++lazy;
         __builtin_amdgcn_s_sleep(8);
         continue;
