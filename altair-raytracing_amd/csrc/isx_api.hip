@@ -435,6 +435,7 @@ int enqueue(int sink, const isx_config* c, uint64_t n, uint64_t seed, uint64_t f
       const int bres = S.bin_blocks_per_cu > 0 ? S.bin_blocks_per_cu : resident_per_cu(bin_fn, bblock, lds_bin);
       // one trace launch + one binning launch of `cnt` rays from `off`, through workspace `buf`, on streams st / sb
       auto launch_pair = [&](uint64_t off, uint64_t cnt, int buf, hipStream_t st, hipStream_t sb, hipEvent_t traced) -> int {
+        if (cnt > kLaunchMax) return ISX_ERR_TOO_LARGE;   // (cannot happen: pipeline_chunk <= 2^26)
         Work w2 = wk;
         w2.first = first + off; w2.n = cnt; w2.sub = pick_sub(cnt);
         int r = next_ctr(&w2.ctr); if (r) return r;
@@ -507,14 +508,17 @@ int enqueue(int sink, const isx_config* c, uint64_t n, uint64_t seed, uint64_t f
   }
   // ---- the shared-ray disc sweep as a pipeline as well: assist-wave trace kernel -> exit segments in HBM (8 doubles each) ->
   // disc-binning kernel (lane = segment, the discs one after the other)
+  // (a disc list whose histogram + cluster table + per-wave lists exceed the workgroup's LDS -- above ~16 000 discs on gfx950 --
+  //  takes the fused SINK_DISC kernel below, which needs the histogram only)
+  constexpr int kDiscBinBlock = 512;
+  const size_t lds_disc_bin = (((size_t)d.nbins * 4 + 15) & ~(size_t)15) + (size_t)g_disc_clusters.n_clusters * 16 +
+                              (d.nbins <= kDiscsInLds ? (size_t)d.nbins * 48 + (size_t)((d.nbins + 1) & ~1) * 4 : 0) +
+                              (size_t)(kDiscBinBlock / 64) * (64 * 7 + kPairCap / 2) * sizeof(double);
   if (sink == SINK_DISC && lean_explicit && S.pipeline && S.assist && S.disc_pipeline && g_disc_clusters.n == (size_t)d.nbins &&
-      d_discs == S.d_aux) {
-    const int pblock = S.assist_block, bblock = 512;
+      d_discs == S.d_aux && lds_disc_bin <= S.lds_limit) {
+    const int pblock = S.assist_block, bblock = kDiscBinBlock;
     const size_t lds_trace = 16 + 64 + sizeof(Geom) + sizeof(DetGrid) + 16 + sizeof(AssistQueues) + (size_t)(kResumeCap + kPendCap) * 64;
-    const size_t lds_bin = (((size_t)d.nbins * 4 + 15) & ~(size_t)15) + (size_t)g_disc_clusters.n_clusters * 16 +
-                           (d.nbins <= kDiscsInLds ? (size_t)d.nbins * 48 + (size_t)((d.nbins + 1) & ~1) * 4 : 0) +
-                           (size_t)(bblock / 64) * (64 * 7 + kPairCap / 2) * sizeof(double);
-    if (lds_bin > S.lds_limit) return ISX_ERR_BAD_CONFIG;
+    const size_t lds_bin = lds_disc_bin;
     const KernelFn rec_fn = isx_trace_assist_disc_kernel;
     if (S.attr_lds[(const void*)rec_fn] != lds_trace) {
       HIPCHK(hipFuncSetAttribute((const void*)rec_fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_trace));
@@ -531,6 +535,7 @@ int enqueue(int sink, const isx_config* c, uint64_t n, uint64_t seed, uint64_t f
     rc = span(0, &e0); if (rc) return rc;
     for (uint64_t off = 0; off < n; off += chunk) {
       const uint64_t cnt = n - off < chunk ? n - off : chunk;
+      if (cnt > kLaunchMax) return ISX_ERR_TOO_LARGE;     // (cannot happen: pipeline_chunk <= 2^26)
       Work w2 = wk;
       w2.first = first + off; w2.n = cnt; w2.sub = pick_sub(cnt);
       rc = next_ctr(&w2.ctr); if (rc) return rc;
@@ -845,7 +850,9 @@ int isx_set_option(const char* key, int64_t value) {
   if (!std::strcmp(key, "bin_slots")) { if (value < 0 || value > 1) return ISX_ERR_BAD_ARG; S.bin_slots = (int)value; return ISX_OK; }
   if (!std::strcmp(key, "ray_sub")) { if (value < 0 || value > (1 << 20)) return ISX_ERR_BAD_ARG; S.ray_sub = (int)value; return ISX_OK; }
   if (!std::strcmp(key, "pipeline")) { if (value < 0 || value > 1) return ISX_ERR_BAD_ARG; S.pipeline = (int)value; return ISX_OK; }
-  if (!std::strcmp(key, "pipeline_chunk")) { if (value < 4096 || value > (1ll << 32)) return ISX_ERR_BAD_ARG; S.pipe_chunk = (uint64_t)value; return ISX_OK; }
+  // (a launch addresses its rays by 30-bit offsets -- bits 30 and 31 of Ray::ido are flags in the queue records -- and counts
+  //  them in 32 bits: the documented maximum of a chunk is 2^26 rays, 3.4 GB of exit-line workspace)
+  if (!std::strcmp(key, "pipeline_chunk")) { if (value < 4096 || value > (1ll << 26)) return ISX_ERR_BAD_ARG; S.pipe_chunk = (uint64_t)value; return ISX_OK; }
   if (!std::strcmp(key, "grid_blocks")) { if (value < 0 || value > 65535) return ISX_ERR_BAD_ARG; S.grid_blocks = (int)value; return ISX_OK; }
   return ISX_ERR_BAD_ARG;
 }

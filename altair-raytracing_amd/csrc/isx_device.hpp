@@ -19,6 +19,29 @@ namespace isx {
 
 struct V3 { double x, y, z; };
 
+// GLOBAL-typed views of device buffers.  A pointer that reaches a kernel through the LDS copy of a parameter block (or through
+// a compiler barrier) is a generic pointer to hipcc, and an access through it is a flat_load / flat_atomic: flat operations
+// complete out of order, so the wave waits with s_waitcnt vmcnt(0) lgkmcnt(0) -- a detector-table read then also drains the
+// wave's LDS queue.  Through these types the same access is a global_load / global_atomic (tools/isa_stats.py --check).
+typedef double isx_d2 __attribute__((ext_vector_type(2)));
+typedef __attribute__((address_space(1))) const isx_d2 GlbD2;
+typedef __attribute__((address_space(1))) const double GlbF64;
+typedef __attribute__((address_space(1))) unsigned long long GlbU64;
+// six consecutive doubles (an exit line: last point + direction; a detector or disc entry) from global memory
+__device__ __forceinline__ void load6(const double* p6, double (&o)[6]) {
+  const GlbF64* s = (const GlbF64*)p6;
+  o[0] = s[0]; o[1] = s[1]; o[2] = s[2]; o[3] = s[3]; o[4] = s[4]; o[5] = s[5];
+}
+__device__ __forceinline__ void load_line(const double* p6, V3& P, V3& V) {   // (16-byte aligned: three 16-byte loads)
+  const GlbD2* s = (const GlbD2*)p6;
+  const isx_d2 a = s[0], b = s[1], c = s[2];
+  P.x = a.x; P.y = a.y; P.z = b.x; V.x = b.y; V.y = c.x; V.z = c.y;
+}
+// += on a 64-bit global accumulator (device scope, relaxed: the histogram flush and the census)
+__device__ __forceinline__ void global_add_u64(unsigned long long* p, unsigned long long v) {
+  __hip_atomic_fetch_add((GlbU64*)p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 enum : int { K_NONE = 0, K_INNER = 1, K_OUTER = 2, K_CONE = 3, K_BOX = 4 };
 enum : int { ST_EXITED = 1, ST_ABSORBED = 2, ST_SUSPENDED = 3 };
 
@@ -594,7 +617,9 @@ __device__ inline V3 brdf_sample(const G& g, const V3 normal, const V3 incident,
 // det = x,y,z,nx,ny,nz exactly as Detector::setPosition stores them; plain +,-,*,/ in source order.
 __device__ __forceinline__ bool check_intersection(const double* __restrict__ det, double half_w2, const V3& lp,
                                                    const V3& dir) {
-  const double x = det[0], y = det[1], z = det[2], nx = det[3], ny = det[4], nz = det[5];
+  double e[6];
+  load6(det, e);   // (the detector table lives in global memory whatever pointer type reached this point)
+  const double x = e[0], y = e[1], z = e[2], nx = e[3], ny = e[4], nz = e[5];
   const double dot = dir.x * nx + dir.y * ny + dir.z * nz;
   if (fabs(dot) < 1e-10) return false;
   const double dx = lp.x - x;

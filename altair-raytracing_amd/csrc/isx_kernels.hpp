@@ -437,9 +437,7 @@ __device__ __forceinline__ void walk_columns(const D& d, uint32_t* __restrict__ 
         const double sd = rowt[4 * ir + 0], cd = rowt[4 * ir + 1], zz = rowt[4 * ir + 2], ad = rowt[4 * ir + 3];
         V3 P, V;
         if (refetch != nullptr) {
-          const double2* src = reinterpret_cast<const double2*>(refetch + (ir - i));   // (ir - i = 0, behind the barrier: no CSE with the first read)
-          const double2 a = src[0], b = src[1], c = src[2];
-          P.x = a.x; P.y = a.y; P.z = b.x; V.x = b.y; V.y = c.x; V.z = c.y;
+          load_line(refetch + (ir - i), P, V);   // (ir - i = 0, behind the barrier: no CSE with the first read)
         } else { P = P0; V = V0; }
         const double pz = P.z - zz;
         const double dot = fma(sd * V.y, cph, fma(-(sd * V.x), sph, -(cd * V.z)));
@@ -491,9 +489,7 @@ __device__ __forceinline__ bool decide_exact(const D& d, const double* __restric
   const double cph = colx[jr].c, sph = colx[jr].s;
   V3 P, V;
   {
-    const double2* src = reinterpret_cast<const double2*>(src6);
-    const double2 a = src[0], b = src[1], c = src[2];
-    P.x = a.x; P.y = a.y; P.z = b.x; V.x = b.y; V.y = c.x; V.z = c.y;
+    load_line(src6, P, V);
   }
   const double pz = P.z - zz;
   const double dotd = fma(sd * V.y, cph, fma(-(sd * V.x), sph, -(cd * V.z)));
@@ -526,9 +522,7 @@ __device__ __forceinline__ void walk_columns_pairs(const D& d, uint32_t* __restr
   if (len > 0) {
     V3 P, V;
     {
-      const double2* src = reinterpret_cast<const double2*>(line6);
-      const double2 a = src[0], b = src[1], c = src[2];
-      P.x = a.x; P.y = a.y; P.z = b.x; V.x = b.y; V.y = c.x; V.z = c.y;
+      load_line(line6, P, V);
     }
     const double Sd = rowt[4 * i + 0], Cd = rowt[4 * i + 1], zd = rowt[4 * i + 2], Ad = rowt[4 * i + 3];
     const double qx = fma(t0, V.x, P.x), qy = fma(t0, V.y, P.y), qz = fma(t0, V.z, P.z);   // Pq: same line, nearest to O
@@ -597,9 +591,7 @@ __device__ __forceinline__ void walk_columns_pairs(const D& d, uint32_t* __restr
 #ifdef ISX_DIAG
       {   // tuning builds: a decision taken by tier 1 must be the reference's
         V3 P, V;
-        const double2* src = reinterpret_cast<const double2*>(line6);
-        const double2 a = src[0], b = src[1], c = src[2];
-        P.x = a.x; P.y = a.y; P.z = b.x; V.x = b.y; V.y = c.x; V.z = c.y;
+        load_line(line6, P, V);
         for (int t = 0; t < (two ? 2 : 1); ++t) {
           const int jc = (int)((t == 0 ? off.x : off.y) >> 2);
           const bool ref = check_intersection(d.table + 6 * (size_t)(i * d.n_phi + jc), d.half_w2, P, V);
@@ -908,9 +900,7 @@ __device__ __forceinline__ void walk_lines_packed(const D& d, uint32_t* __restri
       w.jf = __shfl(pre.jf, owner, 64); w.ch2 = __shfl(pre.ch2, owner, 64);
       V3 P, V;   // (read again from the batch's 3 KB of exit lines: lanes of one owner share the cache lines)
       {
-        const double2* src = reinterpret_cast<const double2*>(lines + 6 * owner);
-        const double2 a = src[0], b = src[1], c = src[2];
-        P.x = a.x; P.y = a.y; P.z = b.x; V.x = b.y; V.y = c.x; V.z = c.y;
+        load_line(lines + 6 * owner, P, V);
       }
       int jlo = 0, cnt = 0;
       if (have) cap_window(w, (float)rowt[4 * i + 2], (float)rowt[4 * i + 3], d.n_phi, jlo, cnt);
@@ -1009,9 +999,9 @@ __device__ __forceinline__ void consume_slots(const D& d, uint32_t* __restrict__
   const double* src6 = lines + 6 * line;   // (an idle lane reads line 0 of the unit, which exists)
   double t0 = 0.0;
   {
-    const double2* src = reinterpret_cast<const double2*>(src6);
-    const double2 a = src[0], b = src[1], c = src[2];
-    t0 = -fma(a.x, b.y, fma(a.y, c.x, (b.x - d.portz) * c.y));
+    V3 P, V;
+    load_line(src6, P, V);
+    t0 = -fma(P.x, V.x, fma(P.y, V.y, (P.z - d.portz) * V.z));
   }
   ISX_DIAG_ADD(11, 1);
   ISX_BD_MARK(sq, 3);
@@ -1068,153 +1058,91 @@ __device__ __forceinline__ void push_slots(const D& d, uint32_t* __restrict__ hi
   }
 }
 
-// What produce_general decides about a line before it touches a row, for the lane's OWN line (lane = line, once per batch of 64):
-// 0 = the line has caps (produce_general's cap construction), 1 = a grazing line: its box (box_line) and row range,
-// 2 = the line cannot hit anything.  Same formulas, same margins.
-template <class D>
-__device__ __forceinline__ int general_pre(const D& d, const V3& P, const V3& V, float inv_dth, BoxLine& bx, int& ilo, int& ihi) {
-  const double wz = P.z - d.portz;
+// What the two caps of a line share (prep_record's construction and conditions: same formulas, same margins).
+struct CapShared {
+  double wv;         // line parameter of the foot of O, negated: the piercing points are at +-sF - wv
+  float sF, ch, ch2;
+  int kind;          // 0 the line has caps, -1 no caps: grazing line (box windows), -2 the line cannot hit anything
+};
+__device__ __forceinline__ CapShared prep_shared(const GridConst& k, const V3& P, const V3& V) {
+  CapShared o;
+  o.wv = 0.0; o.sF = o.ch = o.ch2 = 0.f; o.kind = -1;
+  const double wz = P.z - (double)k.portz;
   const double wv = fma(P.x, V.x, fma(P.y, V.y, wz * V.z));
   const double hx = fma(-wv, V.x, P.x), hy = fma(-wv, V.y, P.y), hz = fma(-wv, V.z, wz);
   const float dO2 = (float)fma(hx, hx, fma(hy, hy, hz * hz));
-  const float Rf = (float)d.R, rho = (float)d.rho_d;
-  const float R2 = Rf * Rf;
+  const float R2 = k.Rf * k.Rf;
   const float dO = sqrt_cull(dO2);
-  const float a1 = dO + rho;
-  bool caps = a1 < 0.999f * Rf;
-  if (caps) {
-    const float sF = sqrt_cull(R2 - dO2);
-    const float smin = sqrt_cull(R2 - a1 * a1);
-    const float a0 = fmaxf(0.f, dO - rho);
-    const float smax = sqrt_cull(R2 - a0 * a0);
-    const float ext = fmaxf(sF - smin, smax - sF);
-    const float ch2 = fmaf(ext, ext, rho * rho) * 1.0001f + 1e-3f;
-    caps = 4.0f * (R2 - dO2) > 4.04f * ch2;
-  }
-  if (caps) return 0;
-  return box_line(d, P, V, inv_dth, bx, ilo, ihi) ? 1 : 2;
+  const float a1 = dO + k.rho;
+  if (dO - k.rho > 1.001f * k.Rf) { o.kind = -2; return o; }
+  if (!(a1 < 0.999f * k.Rf)) return o;
+  const float sF = sqrt_cull(R2 - dO2);
+  const float smin = sqrt_cull(R2 - a1 * a1);
+  const float a0 = fmaxf(0.f, dO - k.rho);
+  const float smax = sqrt_cull(R2 - a0 * a0);
+  const float ext = fmaxf(sF - smin, smax - sF);
+  const float ch2 = fmaf(ext, ext, k.rho * k.rho) * 1.0001f + 1e-3f;
+  if (!(4.0f * (R2 - dO2) > 4.04f * ch2)) return o;
+  o.wv = wv; o.sF = sF; o.ch2 = ch2; o.ch = sqrt_cull(ch2); o.kind = 0;
+  return o;
+}
+// z of the piercing point of side `side` (0: the larger line parameter), and whether its cap reaches detector rows at all
+__device__ __forceinline__ bool cap_is_low(const GridConst& k, const CapShared& sh, const V3& P, const V3& V, int side) {
+  const double s0 = side == 0 ? ((double)sh.sF - sh.wv) : (-(double)sh.sF - sh.wv);
+  return !((float)fma(s0, V.z, P.z) - sh.ch > k.portz);
+}
+// Can a bin lie in the row ranges (cap_rows) of BOTH caps of the line?  The construction keeps the piercing points more than 2.01
+// chords apart, so the caps themselves are disjoint -- but a row range carries slack, and on a coarse grid the two ranges of one
+// column can meet (tools/soak_cull.py found exactly that on 2- and 3-row grids).  Along the meridian of column j the angular
+// distance D to the cap's piercing point obeys cos D = rho cos(theta - tc), rho = sqrt(a^2 + b^2) <= 1; cap_rows hands out the rows
+// with |theta_i - tc| <= acos(cos w / rho) + s, s <= 2.5e-3 + 1e-4 (acos_cull) + 2e-5 (atan2_cull) + 1e-3 rows (<= 1.6e-3 rad on a
+// one-row grid) <= 4.3e-3, with cos w and rho good to 3e-6 (the 2e-6 taken off cos w, binary32 rounding): for those
+// cos D >= cos w - s sqrt(rho^2 - cos^2 w) - s^2/2 - 3e-6 >= cos w - s sin w - 1.3e-5 >= cos(w + 5e-3), i.e. every row handed out has
+// its centre within w + 5e-3 rad of the piercing point.  A common bin therefore needs the piercing points within 2 w + 1e-2 of each
+// other as seen from O; they are 2 asin(sF / R) apart.  Hence: no common bin if sF / R > sin(w + 5e-3), for which
+// sF / R > sin w + 5e-3 suffices while w + 5e-3 < pi/2.  Evaluated in binary32 with its own margin (8e-3, 1e-4 relative; cos w > 0.05).
+// A line that fails the test AND has its second cap among the detector rows takes the box windows for the whole line (bin_culled:
+// one pass over the tube around the line, every bin at most once) instead of its two caps: rare (none in any BASELINE
+// configuration: there sF / R >= 0.6 against sin w ~ 0.2), correct for any line.
+__device__ __forceinline__ bool caps_may_touch(const GridConst& k, const CapShared& sh) {
+  const float iR = rcp_cull(k.Rf);
+  const float cosw = fmaf(-0.5f * sh.ch2, iR * iR, 1.0f) - 2e-6f;   // (prep_cols' cos w)
+  const float sinw = sqrt_cull(fmaxf(0.f, fmaf(-cosw, cosw, 1.0f)));
+  return !(cosw > 0.05f && sh.sF * iR > fmaf(sinw, 1.0001f, 8e-3f));
+}
+// The cap of side `side` of a line with caps as the ROW producer wants it (prep_record's and bin_culled's formulas and margins):
+// own.{smax, smin, vxy, avz} carry {Fz, AF, jf, ch2} of the CapWin (the producer's per-owner data is one BoxLine either way),
+// [ilo, ihi] the rows the cap can reach (empty if it lies above every detector row).
+__device__ __forceinline__ void cap_rows_pre(const GridConst& k, const V3& P, const V3& V, const CapShared& sh, int side, BoxLine& own,
+                                             int& ilo, int& ihi) {
+  ilo = 0; ihi = -1;
+  const double s0 = side == 0 ? ((double)sh.sF - sh.wv) : (-(double)sh.sF - sh.wv);
+  const float Fz0 = (float)fma(s0, V.z, P.z);
+  if (Fz0 - sh.ch > k.portz) return;                                 // cap entirely above every detector row
+  const float Fx = (float)fma(s0, V.x, P.x), Fy = (float)fma(s0, V.y, P.y);
+  const float AF2 = fmaf(Fx, Fx, Fy * Fy);
+  const float AF = sqrt_cull(AF2);
+  float phiF = atan2_cull(Fy, Fx);
+  if (phiF < 0.f) phiF += 6.28318530718f;
+  const float omega = cap_angle(sh.ch, rcp_cull(k.Rf));
+  const float thF = atan2_cull(AF, k.portz - Fz0);
+  ilo = max((int)floorf((thF - omega) * k.inv_dth - 0.5f - 1e-3f), 0);
+  ihi = min((int)ceilf((thF + omega) * k.inv_dth - 0.5f + 1e-3f), k.n_theta - 1);
+  own.smax = Fz0; own.smin = AF; own.vxy = phiF * k.inv_dphi - 0.5f; own.avz = sh.ch2;
 }
 
-// producer: the rows of all GRAZING lines of a batch of 64 (general_pre = 1) packed over the lanes, as produce_packed packs the rows of
-// the fast-path lines: lane = (line, row); the line's box comes from its own lane through ds_bpermute.  produce_general took these lines
-// one at a time (lane = row: a third of the BRDF source's lines, ~900 instructions each, half of that kernel's time).
-// Same windows (box_window on the same box), each (line, row) once: same slots, other order.
+// producer of isx_bin_slots_kernel: the rows of the lines of a batch that take part in one pass, packed over the lanes -- lane =
+// (line, row); the owner of a slot is found without a search (every line marks its first slot of the 64 in wave-private LDS; nearest
+// mark at or below the lane: ballot + clz) and its per-line data (`own`: a cap, or the box of a grazing line) comes from the line's
+// own lane through ds_bpermute.  `boxes`: the rows get the (at most two) box windows of a grazing line, else the cap window.
+// One producer and ONE push site for every kind of line since round 4 (before: fast-path caps packed, grazing lines' boxes packed
+// in a second copy, the lines with two caps one at a time, lane = row, ~900 instructions per line: five inlined copies of the
+// consumer, 144 bytes of scratch per lane).  Same windows as before, each (line, row) once: the same slots in another order.
 template <class D>
-__device__ __forceinline__ void produce_boxes_packed(const D& d, uint32_t* __restrict__ hist, const double* __restrict__ rowt,
-                                                     const ColX* __restrict__ colx, const double* __restrict__ lines, const SlotQueues& sq,
-                                                     const BoxLine& gbx, int gilo, int nrow, int excl, int incl, int total,
-                                                     float inv_dphi, float portz, int first_line, int lane, LdsInt* mark) {
-#pragma unroll 1
-  for (int base = 0; base < total; base += 64) {
-    const int g = base + lane;
-    bool have = g < total;
-    volatile LdsInt* mk = mark;
-    mk[lane] = 0;
-    __builtin_amdgcn_wave_barrier();
-    if (nrow > 0 && excl < base + 64 && incl > base) mk[(excl > base ? excl : base) - base] = lane + 1;
-    __builtin_amdgcn_wave_barrier();
-    const int m = mk[lane];
-    const unsigned long long low = __ballot(m != 0) & (~0ull >> (63 - lane));
-    const int pos = 63 - __builtin_clzll(low | 1ull);
-    int owner = mk[pos] - 1;
-    if (!have || owner < 0) { owner = 0; have = false; }
-    const int o_excl = __shfl(excl, owner, 64), o_ilo = __shfl(gilo, owner, 64);
-    BoxLine b;
-    b.smax = __shfl(gbx.smax, owner, 64); b.smin = __shfl(gbx.smin, owner, 64); b.vxy = __shfl(gbx.vxy, owner, 64);
-    b.avz = __shfl(gbx.avz, owner, 64); b.ivz = __shfl(gbx.ivz, owner, 64); b.dn = __shfl(gbx.dn, owner, 64);
-    b.Hm = __shfl(gbx.Hm, owner, 64); b.Hz = __shfl(gbx.Hz, owner, 64); b.phin = __shfl(gbx.phin, owner, 64);
-    b.rs = __shfl(gbx.rs, owner, 64); b.sig = __shfl(gbx.sig, owner, 64);
-    const int i = have ? o_ilo + (g - o_excl) : 0;
-    int j0 = 0, c0 = 0, j1 = 0, c1 = 0;
-    if (have) box_window(b, (float)rowt[4 * i + 2] - portz, (float)rowt[4 * i + 3], d.n_phi, inv_dphi, j0, c0, j1, c1);
-    push_slots(d, hist, rowt, colx, lines, sq, first_line + owner, i, j0, c0, lane);
-    if (__ballot(c1 > 0) != 0ull) push_slots(d, hist, rowt, colx, lines, sq, first_line + owner, i, j1, c1, lane);
-  }
-}
-
-// producer: a line off the fast path (wave-uniform P, V; lane = row), cap windows around its two piercing points or box windows
-template <class DG, class D>
-__device__ inline void produce_general(const DG& dd, const D& dfast, uint32_t* __restrict__ hist, const double* __restrict__ rowt,
-                                       const ColX* __restrict__ colx, const double* __restrict__ lines, const SlotQueues& sq,
-                                       const V3 P, const V3 V, int line, int lane) {
-  struct { int n_theta, n_phi; double rho_d, R, portz; } d;
-  d.n_theta = dd.n_theta; d.n_phi = dd.n_phi; d.rho_d = dd.rho_d; d.R = dd.R; d.portz = dd.portz;
-  // (the construction of bin_culled<true>: same formulas, same margins)
-  const double wz = P.z - d.portz;
-  const double wv = fma(P.x, V.x, fma(P.y, V.y, wz * V.z));
-  const double hx = fma(-wv, V.x, P.x), hy = fma(-wv, V.y, P.y), hz = fma(-wv, V.z, wz);
-  const float dO2 = (float)fma(hx, hx, fma(hy, hy, hz * hz));
-  const float Rf = (float)d.R, rho = (float)d.rho_d;
-  const float R2 = Rf * Rf;
-  const float dO = sqrt_cull(dO2);
-  const float a1 = dO + rho;
-  CapWin w;
-  w.inv_dphi = (float)d.n_phi * 0.15915494309f;
-  w.Fz = 0.f; w.AF2 = 0.f; w.AF = 0.f; w.jf = 0.f; w.ch2 = 0.f;
-  const float inv_dth = (float)d.n_theta * 0.63661977237f;
-  bool caps = a1 < 0.999f * Rf;
-  float sF = 0.f, ch = 0.f, omega = 0.f;
-  if (caps) {
-    sF = sqrt_cull(R2 - dO2);
-    const float smin = sqrt_cull(R2 - a1 * a1);
-    const float a0 = fmaxf(0.f, dO - rho);
-    const float smax = sqrt_cull(R2 - a0 * a0);
-    const float ext = fmaxf(sF - smin, smax - sF);
-    w.ch2 = fmaf(ext, ext, rho * rho) * 1.0001f + 1e-3f;
-    caps = 4.0f * (R2 - dO2) > 4.04f * w.ch2;
-    ch = sqrt_cull(w.ch2);
-    omega = cap_angle(ch, rcp_cull(Rf));
-  }
-  // one loop nest for both constructions (one push site): caps -> two sides, one window per row; boxes -> one "side", up
-  // to two windows per row (the second ones in a second sweep over the same rows)
-  BoxLine bx;
-  int ilo = 0, ihi = -1;
-  if (!caps) {
-    if (!box_line(d, P, V, inv_dth, bx, ilo, ihi)) { ISX_DIAG_ADD(3, 1); return; }
-    ISX_DIAG_ADD(2, 1);
-  } else {
-    ISX_DIAG_ADD(1, 1);
-  }
-#pragma unroll 1
-  for (int side = 0; side < (caps ? 2 : 1); ++side) {
-    if (caps) {
-      const double s = side == 0 ? ((double)sF - wv) : (-(double)sF - wv);
-      const float Fx = (float)fma(s, V.x, P.x), Fy = (float)fma(s, V.y, P.y);
-      w.Fz = (float)fma(s, V.z, P.z);
-      if (w.Fz - ch > (float)d.portz) continue;  // cap entirely above every detector row
-      w.AF2 = fmaf(Fx, Fx, Fy * Fy);
-      w.AF = sqrt_cull(w.AF2);
-      float phiF = atan2_cull(Fy, Fx);
-      if (phiF < 0.f) phiF += 6.28318530718f;
-      w.jf = phiF * w.inv_dphi - 0.5f;
-      const float thF = atan2_cull(w.AF, (float)d.portz - w.Fz);
-      ilo = max((int)floorf((thF - omega) * inv_dth - 0.5f - 1e-3f), 0);
-      ihi = min((int)ceilf((thF + omega) * inv_dth - 0.5f + 1e-3f), d.n_theta - 1);
-    }
-#pragma unroll 1
-    for (int i0 = ilo; i0 <= ihi; i0 += 64) {
-      const int i = i0 + lane <= ihi ? i0 + lane : -1;
-      // (both windows of a row from ONE box_window: the second sweep used to evaluate it again -- BRDF binning 50.8 -> 48.9 ms.
-      //  Measured on top and dropped: the line's own lane deciding caps-or-box and building the box for the whole batch at once,
-      //  handed over by v_readlane: 48.8 ms -- 13 more live VGPRs, 152 bytes of scratch)
-      int j0 = 0, c0 = 0, j1 = 0, c1 = 0;
-      if (i >= 0) {
-        const float zi = (float)rowt[4 * i + 2], Ai = (float)rowt[4 * i + 3];
-        if (caps) cap_window(w, zi, Ai, d.n_phi, j0, c0);
-        else box_window(bx, zi - (float)d.portz, Ai, d.n_phi, w.inv_dphi, j0, c0, j1, c1);
-      }
-      push_slots(dfast, hist, rowt, colx, lines, sq, line, i >= 0 ? i : 0, j0, c0, lane);
-      if (__ballot(c1 > 0) != 0ull) push_slots(dfast, hist, rowt, colx, lines, sq, line, i >= 0 ? i : 0, j1, c1, lane);
-    }
-  }
-}
-
-// producer: the fast-path lines of a batch of 64, their rows packed over the lanes (the owner search of walk_lines_packed)
-template <class D>
-__device__ __forceinline__ void produce_packed(const D& d, uint32_t* __restrict__ hist, const double* __restrict__ rowt,
-                                               const ColX* __restrict__ colx, const double* __restrict__ lines, const SlotQueues& sq,
-                                               const RecPre& pre, int nrow, int excl, int incl, int total, float inv_dphi,
-                                               int first_line, int lane, LdsInt* mark) {
+__device__ __forceinline__ void produce_rows_packed(const D& d, uint32_t* __restrict__ hist, const double* __restrict__ rowt,
+                                                    const ColX* __restrict__ colx, const double* __restrict__ lines, const SlotQueues& sq,
+                                                    const BoxLine& own, int own_ilo, int nrow, int excl, int incl, int total, bool boxes,
+                                                    float inv_dphi, float portz, int first_line, int lane, LdsInt* mark) {
 #pragma unroll 1
   for (int base = 0; base < total; base += 64) {
     const int g = base + lane;
@@ -1229,15 +1157,30 @@ __device__ __forceinline__ void produce_packed(const D& d, uint32_t* __restrict_
     const int pos = 63 - __builtin_clzll(low | 1ull);                           // (slot `base` always carries one)
     int owner = mk[pos] - 1;
     if (!have || owner < 0) { owner = 0; have = false; }
-    const int o_excl = __shfl(excl, owner, 64), o_rows = __shfl(pre.rows, owner, 64);
-    const int i = have ? (o_rows & 0xffff) + (g - o_excl) : 0;
-    CapWin w;
-    w.inv_dphi = inv_dphi;
-    w.Fz = __shfl(pre.Fz, owner, 64); w.AF = __shfl(pre.AF, owner, 64); w.AF2 = w.AF * w.AF;
-    w.jf = __shfl(pre.jf, owner, 64); w.ch2 = __shfl(pre.ch2, owner, 64);
-    int jlo = 0, cnt = 0;
-    if (have) cap_window(w, (float)rowt[4 * i + 2], (float)rowt[4 * i + 3], d.n_phi, jlo, cnt);
-    push_slots(d, hist, rowt, colx, lines, sq, first_line + owner, i, jlo, cnt, lane);
+    const int o_excl = __shfl(excl, owner, 64), o_ilo = __shfl(own_ilo, owner, 64);
+    BoxLine b;
+    b.smax = __shfl(own.smax, owner, 64); b.smin = __shfl(own.smin, owner, 64); b.vxy = __shfl(own.vxy, owner, 64);
+    b.avz = __shfl(own.avz, owner, 64);
+    b.ivz = b.dn = b.Hm = b.Hz = b.phin = b.rs = b.sig = 0.f;
+    if (boxes) {
+      b.ivz = __shfl(own.ivz, owner, 64); b.dn = __shfl(own.dn, owner, 64); b.Hm = __shfl(own.Hm, owner, 64);
+      b.Hz = __shfl(own.Hz, owner, 64); b.phin = __shfl(own.phin, owner, 64); b.rs = __shfl(own.rs, owner, 64);
+      b.sig = __shfl(own.sig, owner, 64);
+    }
+    const int i = have ? o_ilo + (g - o_excl) : 0;
+    int j0 = 0, c0 = 0, j1 = 0, c1 = 0;
+    if (have) {
+      const float zi = (float)rowt[4 * i + 2], Ai = (float)rowt[4 * i + 3];
+      if (boxes) box_window(b, zi - portz, Ai, d.n_phi, inv_dphi, j0, c0, j1, c1);
+      else {
+        CapWin w;
+        w.inv_dphi = inv_dphi; w.Fz = b.smax; w.AF = b.smin; w.AF2 = b.smin * b.smin; w.jf = b.vxy; w.ch2 = b.avz;
+        cap_window(w, zi, Ai, d.n_phi, j0, c0);
+      }
+    }
+    const int nwin = (boxes && __ballot(c1 > 0) != 0ull) ? 2 : 1;   // (the second windows of the rows that have one: a second push)
+#pragma unroll 1
+    for (int w = 0; w < nwin; ++w) push_slots(d, hist, rowt, colx, lines, sq, first_line + owner, i, w == 0 ? j0 : j1, w == 0 ? c0 : c1, lane);
   }
 }
 
@@ -1274,37 +1217,18 @@ struct ColPre {     // per line and piercing point: its cap as the column produc
   int kind;                // 0 a cap with columns, -1 no caps: grazing line (bin_culled's box windows), -2 the line cannot hit
                            // anything, -3 this side's cap lies above every detector row
 };
-// side 0: the piercing point at the larger line parameter (the only one of a fast-path line), side 1: the other one.  The two caps
-// of a line are disjoint (the construction requires the piercing points more than 2.01 chords apart), so a line's slots of side 0
-// and side 1 never name the same bin.
-__device__ __forceinline__ ColPre prep_cols(const GridConst& k, int n_phi, const V3& P, const V3& V, int side) {
+// side 0: the piercing point at the larger line parameter (the only one of a fast-path line), side 1: the other one.
+__device__ __forceinline__ ColPre prep_cols(const GridConst& k, int n_phi, const V3& P, const V3& V, const CapShared& sh, int side) {
   ColPre o;
-  o.fx = o.fy = o.a = o.cosw = 0.f; o.jlo = 0; o.ncol = 0; o.kind = -1;
-  // (prep_record's construction and conditions: same formulas, same margins)
-  const double wz = P.z - (double)k.portz;
-  const double wv = fma(P.x, V.x, fma(P.y, V.y, wz * V.z));
-  const double hx = fma(-wv, V.x, P.x), hy = fma(-wv, V.y, P.y), hz = fma(-wv, V.z, wz);
-  const float dO2 = (float)fma(hx, hx, fma(hy, hy, hz * hz));
-  const float R2 = k.Rf * k.Rf;
-  const float dO = sqrt_cull(dO2);
-  const float a1 = dO + k.rho;
-  if (dO - k.rho > 1.001f * k.Rf) { o.kind = -2; return o; }
-  if (!(a1 < 0.999f * k.Rf)) return o;
-  const float sF = sqrt_cull(R2 - dO2);
-  const float smin = sqrt_cull(R2 - a1 * a1);
-  const float a0 = fmaxf(0.f, dO - k.rho);
-  const float smax = sqrt_cull(R2 - a0 * a0);
-  const float ext = fmaxf(sF - smin, smax - sF);
-  const float ch2 = fmaf(ext, ext, k.rho * k.rho) * 1.0001f + 1e-3f;
-  if (!(4.0f * (R2 - dO2) > 4.04f * ch2)) return o;
-  const float ch = sqrt_cull(ch2);
-  const double s0 = side == 0 ? ((double)sF - wv) : (-(double)sF - wv);
+  o.fx = o.fy = o.a = o.cosw = 0.f; o.jlo = 0; o.ncol = 0; o.kind = sh.kind;
+  if (sh.kind != 0) return o;
+  const double s0 = side == 0 ? ((double)sh.sF - sh.wv) : (-(double)sh.sF - sh.wv);
   const float Fz0 = (float)fma(s0, V.z, P.z);
-  if (Fz0 - ch > k.portz) { o.kind = -3; return o; }                 // cap entirely above every detector row
+  if (Fz0 - sh.ch > k.portz) { o.kind = -3; return o; }              // cap entirely above every detector row
   const float Fx = (float)fma(s0, V.x, P.x), Fy = (float)fma(s0, V.y, P.y);
   const float iR = rcp_cull(k.Rf);
   o.fx = Fx * iR; o.fy = Fy * iR; o.a = (k.portz - Fz0) * iR;
-  o.cosw = fmaf(-0.5f * ch2, iR * iR, 1.0f) - 2e-6f;                 // cos w = 1 - ch^2 / 2R^2 (a little smaller: a little wider)
+  o.cosw = fmaf(-0.5f * sh.ch2, iR * iR, 1.0f) - 2e-6f;              // cos w = 1 - ch^2 / 2R^2 (a little smaller: a little wider)
   o.kind = 0;
   // columns: sin theta_F |sin(phi - phi_F)| <= sin w
   const float sinF = sqrt_cull(fmaf(o.fx, o.fx, o.fy * o.fy));
@@ -1370,9 +1294,7 @@ __device__ __forceinline__ void consume_cols(const D& d, uint32_t* __restrict__ 
   if (len > 0) {
     V3 P, V;
     {
-      const double2* src = reinterpret_cast<const double2*>(src6);
-      const double2 a = src[0], b = src[1], c = src[2];
-      P.x = a.x; P.y = a.y; P.z = b.x; V.x = b.y; V.y = c.x; V.z = c.y;
+      load_line(src6, P, V);
     }
     const double wz = P.z - d.portz;
     const double t0 = -fma(P.x, V.x, fma(P.y, V.y, wz * V.z));
@@ -1469,9 +1391,7 @@ __device__ __forceinline__ void consume_cols(const D& d, uint32_t* __restrict__ 
 #if defined(ISX_DIAG) && !defined(ISX_DIAG_TIMING_ONLY)
     {   // tuning builds: a decision taken by tier 1 must be the reference's
       V3 P, V;
-      const double2* src = reinterpret_cast<const double2*>(src6);
-      const double2 a = src[0], b = src[1], c = src[2];
-      P.x = a.x; P.y = a.y; P.z = b.x; V.x = b.y; V.y = c.x; V.z = c.y;
+      load_line(src6, P, V);
       for (int t = 0; t < (two ? 2 : (one ? 1 : 0)); ++t) {
         const bool ref = check_intersection(d.table + 6 * (size_t)((ilo + kk + t) * d.n_phi + j), d.half_w2, P, V);
         if (ref != (t == 0 ? h0 : h1)) ISX_DIAG_ADD_LANES(14, 1);
@@ -1550,9 +1470,7 @@ __device__ __forceinline__ void consume_cols(const D& d, uint32_t* __restrict__ 
             const double cph = colx[jr].c, sph = colx[jr].s;
             V3 P, V;
             {
-              const double2* src = reinterpret_cast<const double2*>(src6 + (jr - j));
-              const double2 a = src[0], b = src[1], c = src[2];
-              P.x = a.x; P.y = a.y; P.z = b.x; V.x = b.y; V.y = c.x; V.z = c.y;
+              load_line(src6 + (jr - j), P, V);
             }
             const double pz = P.z - zz;
             const double dotd = fma(sd * V.y, cph, fma(-(sd * V.x), sph, -(cd * V.z)));
@@ -1578,9 +1496,7 @@ __device__ __forceinline__ void consume_cols(const D& d, uint32_t* __restrict__ 
 #if defined(ISX_DIAG) && !defined(ISX_DIAG_TIMING_ONLY)
       {   // tuning builds: a decision taken by tier 1 must be the reference's
         V3 P, V;
-        const double2* src = reinterpret_cast<const double2*>(src6);
-        const double2 a = src[0], b = src[1], c = src[2];
-        P.x = a.x; P.y = a.y; P.z = b.x; V.x = b.y; V.y = c.x; V.z = c.y;
+        load_line(src6, P, V);
         for (int t = 0; t < (two ? 2 : 1); ++t) {
           const bool ref = check_intersection(d.table + 6 * (size_t)((ilo + k + t) * d.n_phi + j), d.half_w2, P, V);
           if (ref != (t == 0 ? hit0 : hit1)) ISX_DIAG_ADD_LANES(14, 1);
@@ -1646,13 +1562,14 @@ __device__ __forceinline__ void push_cols(const D& d, uint32_t* __restrict__ his
   }
 }
 
-// producer: the columns of all fast-path lines of a batch of 64, packed over the lanes (owner search as in walk_lines_packed)
+// producer: the columns of the caps of a batch of 64 lines, packed over the lanes (owner search as in walk_lines_packed).
+// Called once per side of the lines: the two caps of a line that takes both passes never share a bin (caps_may_touch below).
 template <class D>
 __device__ __forceinline__ void produce_cols_packed(const D& d, uint32_t* __restrict__ hist, const double* __restrict__ rowt,
                                                     const ColX* __restrict__ colx, const RowX* __restrict__ rowx,
                                                     const double* __restrict__ lines, const SlotQueues& sq, const ColPre& pre,
                                                     int excl, int incl, int total, float inv_dth, int n_theta, int first_line,
-                                                    int lane, LdsInt* mark, const ColPre& pre0, bool second) {
+                                                    int lane, LdsInt* mark) {
 #pragma unroll 1
   for (int base = 0; base < total; base += 64) {
     const int g = base + lane;
@@ -1677,26 +1594,7 @@ __device__ __forceinline__ void produce_cols_packed(const D& d, uint32_t* __rest
     if (!have) j = 0;
     int ilo = 0, cnt = 0;
     if (have) cap_rows(fx, fy, a, cw, colx[j].c32, colx[j].s32, inv_dth, n_theta, ilo, cnt);
-    int ilo_b = 0, cnt_b = 0;
-    if (second) {
-      // the line's second cap: never a bin that its first cap already holds in this column (the two caps are disjoint as
-      // constructed, but each row range carries slack and is rounded to whole rows -- on a coarse grid they can meet), so the rows
-      // the first cap took for column j, recomputed exactly as they were pushed, are cut out; what is left is at most two pieces
-      const int jlo0 = __shfl(pre0.jlo, owner, 64), ncol0 = __shfl(pre0.kind == 0 ? pre0.ncol : 0, owner, 64);
-      const float fx0 = __shfl(pre0.fx, owner, 64), fy0 = __shfl(pre0.fy, owner, 64), a0 = __shfl(pre0.a, owner, 64), cw0 = __shfl(pre0.cosw, owner, 64);
-      int dj = j - jlo0;
-      if (dj < 0) dj += d.n_phi;
-      int i0 = 0, c0 = 0;
-      if (have && cnt > 0 && dj < ncol0) cap_rows(fx0, fy0, a0, cw0, colx[j].c32, colx[j].s32, inv_dth, n_theta, i0, c0);
-      if (c0 > 0) {
-        const int hi = ilo + cnt - 1, hi0 = i0 + c0 - 1;
-        const int a_hi = min(hi, i0 - 1), b_lo = max(ilo, hi0 + 1);
-        cnt = a_hi >= ilo ? a_hi - ilo + 1 : 0;
-        ilo_b = b_lo; cnt_b = hi >= b_lo ? hi - b_lo + 1 : 0;
-      }
-    }
     push_cols(d, hist, rowt, colx, rowx, lines, sq, first_line + owner, j, ilo, cnt, lane);
-    if (second && __ballot(cnt_b > 0) != 0ull) push_cols(d, hist, rowt, colx, rowx, lines, sq, first_line + owner, j, ilo_b, cnt_b, lane);
   }
 }
 
@@ -1855,6 +1753,14 @@ __device__ __forceinline__ bool segment_hits_tube(const V3& p, const V3& v, doub
   return t0 <= t1;
 }
 
+// the same with the disc entry read from the device's disc list (global memory, whatever pointer type reached this point)
+__device__ __forceinline__ bool segment_hits_tube_g(const V3& p, const V3& v, double tmax, const double* __restrict__ ca_global,
+                                                    double r, double h) {
+  double ca[6];
+  load6(ca_global, ca);
+  return segment_hits_tube(p, v, tmax, ca, r, h);
+}
+
 template <class DG>
 __device__ __forceinline__ void bin_discs(const DG& dd, uint32_t* __restrict__ hist, const V3& P0, const V3& P1,
                                               const V3& V, int lane) {
@@ -1865,7 +1771,7 @@ __device__ __forceinline__ void bin_discs(const DG& dd, uint32_t* __restrict__ h
   for (int b0 = 0; b0 < d.nbins; b0 += 64) {
     const int b = b0 + lane;
     bool hit = false;
-    if (b < d.nbins) hit = segment_hits_tube(P0, V, tmax, d.discs + 6 * (size_t)b, d.disc_r, d.disc_h);
+    if (b < d.nbins) hit = segment_hits_tube_g(P0, V, tmax, d.discs + 6 * (size_t)b, d.disc_r, d.disc_h);
     if (hit) atomicAdd(&hist[b], 1u);
   }
 }
@@ -2162,7 +2068,7 @@ __device__ __forceinline__ void persistent_body(const Geom& g_arg, const DetGrid
         b = (int)grp;
         V3 dl; dl.x = r.p.x - r.prev.x; dl.y = r.p.y - r.prev.y; dl.z = r.p.z - r.prev.z;
         const double tmax = dot3(dl, r.v);
-        hit = segment_hits_tube(r.prev, r.v, tmax, d.discs + 6 * (size_t)b, d.disc_r, d.disc_h);
+        hit = segment_hits_tube_g(r.prev, r.v, tmax, d.discs + 6 * (size_t)b, d.disc_r, d.disc_h);
       }
       if (hit) atomicAdd(&hist[b], 1u);
     } else if (SINK == SINK_DZ) {
@@ -2259,7 +2165,7 @@ __device__ __forceinline__ void persistent_body(const Geom& g_arg, const DetGrid
   unsigned long long flushed = 0;   // increments of this block = sum of its LDS bins
   for (int b = tid; b < nbins; b += nthr) {
     const uint32_t c = hist[b];
-    if (c) { atomicAdd(&wk.hist[b], (unsigned long long)c); flushed += c; }
+    if (c) { global_add_u64(&wk.hist[b], (unsigned long long)c); flushed += c; }
   }
   if (SINK != SINK_LOG && flushed) atomicAdd(&sstat[5], flushed);
   __syncthreads();
@@ -2340,13 +2246,16 @@ isx_trace_log_lean_kernel(const Geom g, const DetGrid d, const Work wk) { persis
 //            is no cycle), many consumers (compare-and-swap on the head);
 //   busy     rays that are in neither a tracer lane nor ended; a tracer wave with no ray left leaves when the launch's ray
 //            queue is dry and busy == 0, the assist wave when every tracer has left.
-// Every wait is bounded (kSpinLimit): a wave that gives up raises stats[7] and the host reports ISX_ERR_HIP-like failure
-// instead of hanging the device.
+// Every wait is bounded (kSpinLimit polls during which NO wave of the workgroup made progress -- AssistQueues::beat; a long
+// stretch without hand-overs, e.g. a tiny port opening with a large bounce limit or a down-clocked device, is not a failure):
+// a wave that gives up raises stats[7] and the host reports ISX_ERR_HIP instead of hanging the device.
 constexpr uint32_t kPendCap = 512, kResumeCap = 128;
 constexpr uint32_t kSpinLimit = 1u << 22;
 struct AssistQueues {   // LDS, one per workgroup
   uint32_t pend_res, pend_pub, pend_head, resume_pub, resume_head, busy, tracers_done, failed;
-  uint32_t drain, pad0, pad1, pad2;   // drain: a tracer wave has no ray left and none to get (the assist wave stops waiting for full batches)
+  uint32_t drain, beat, pad1, pad2;   // drain: a tracer wave has no ray left and none to get (the assist wave stops waiting for full batches)
+                                      // beat: bumped by every wave of the workgroup that makes progress (a tracer's loop trip, a batch of the
+                                      // assist wave): the bounded waits below count polls WITHOUT a beat, not idle time
 };
 enum : uint32_t { IDO_SCATTERED = 0x80000000u, IDO_TARGET = 0x40000000u };   // Ray::ido flags in a queue record (offsets < 2^30)
 
@@ -2397,7 +2306,8 @@ __device__ __forceinline__ void assist_body(const Geom& g_arg, const DetGrid& d_
   if ((tid >> 6) < n_tracers) {
     // =============================================================== tracer waves
     constexpr uint32_t kDry = 0xffffffffu;
-    uint32_t next = 0, end = 0, spins = 0;
+    uint32_t next = 0, end = 0, spins = 0, beat_seen = 0;
+    bool drained = false;
     Ray r;
     ray_start(g, r, 0);
     bool run = false, hand = false;    // hand: the lane's ray waits to be handed to the assist wave
@@ -2469,13 +2379,16 @@ __device__ __forceinline__ void assist_body(const Geom& g_arg, const DetGrid& d_
         if (__ballot(run || hand) == 0ull) {
           // no ray in this wave and none to be had from the launch; rays of this workgroup may still come back
           if (ld(&Q->busy) == 0u) break;
-          if (spins == 0u && lane == 0) __hip_atomic_store(&Q->drain, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+          if (!drained) { drained = true; if (lane == 0) __hip_atomic_store(&Q->drain, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+          { const uint32_t bt = ld(&Q->beat); if (bt != beat_seen) { beat_seen = bt; spins = 0u; } }   // somebody is still at work
           if (++spins > kSpinLimit) { if (lane == 0) add(&Q->failed, 1u); break; }
           ISX_TD_ADD(13, 1);
           __builtin_amdgcn_s_sleep(8);
           continue;
         }
       }
+      spins = 0u;
+      if (lane == 0) __hip_atomic_fetch_add(&Q->beat, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
       ISX_TD_MARK(0);
       ISX_TD_ADD(7, 1); ISX_TD_ADD(8, __popcll(__ballot(run))); ISX_TD_ADD(9, __popcll(__ballot(hand)));
       // ---- kStepsPerTrip bounces off the inner sphere per live lane (rule S1'); anything else is the assist wave's
@@ -2574,14 +2487,19 @@ __device__ __forceinline__ void assist_body(const Geom& g_arg, const DetGrid& d_
   } else {
     // =============================================================== the assist wave
     uint32_t reg_slot = 0, reg_left = 0, reg_id = 0xffffffffu;       // cursor in the open region of exit lines (SINK_REC)
-    uint32_t spins = 0, lazy = 0;
+    uint32_t spins = 0, lazy = 0, beat_seen = 0;
     // one wave serves eleven: it goes first whenever it has something to do (its SIMD's five tracers take every other slot)
     __builtin_amdgcn_s_setprio(3);
     for (;;) {
-      const uint32_t res = ld(&Q->pend_res), pub = ld(&Q->pend_pub), hd = ld(&Q->pend_head);
+      // pend_pub is a SUM of published counts, not an ordered cursor: it is read BEFORE pend_res, so that pub(t1) <= res(t1) <=
+      // res(t2) and pub == res proves that every reservation below res was published at t1.  (Read the other way round, a batch
+      // that reserves, writes and publishes between the two loads could make up for an earlier one that has reserved but not yet
+      // published, and this wave would read the earlier batch's unwritten slots.)
+      const uint32_t pub = ld(&Q->pend_pub), res = ld(&Q->pend_res), hd = ld(&Q->pend_head);
       const uint32_t n = pub == res ? res - hd : 0u;                 // everything below res is written once pub has caught up
       if (n == 0u) {
         if (res == hd && ld(&Q->tracers_done) == (uint32_t)n_tracers) break;
+        { const uint32_t bt = ld(&Q->beat); if (bt != beat_seen) { beat_seen = bt; spins = 0u; } }   // the tracers are at work
         if (++spins > kSpinLimit) { if (lane == 0) add(&Q->failed, 1u); break; }
         __builtin_amdgcn_s_sleep(4);
         continue;
@@ -2600,6 +2518,7 @@ __device__ __forceinline__ void assist_body(const Geom& g_arg, const DetGrid& d_
       }
       lazy = 0;
       spins = 0;
+      if (lane == 0) __hip_atomic_fetch_add(&Q->beat, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
       const uint32_t take = n < 64u ? n : 64u;
       const bool have = (uint32_t)lane < take;
       Ray r;
@@ -2701,7 +2620,7 @@ __device__ __forceinline__ void assist_body(const Geom& g_arg, const DetGrid& d_
           } else {
             b0 = (int)grp;
             V3 dl; dl.x = r.p.x - r.prev.x; dl.y = r.p.y - r.prev.y; dl.z = r.p.z - r.prev.z;
-            hit0 = segment_hits_tube(r.prev, r.v, dot3(dl, r.v), d_arg.discs + 6 * (size_t)b0, d_arg.disc_r, d_arg.disc_h);
+            hit0 = segment_hits_tube_g(r.prev, r.v, dot3(dl, r.v), d_arg.discs + 6 * (size_t)b0, d_arg.disc_r, d_arg.disc_h);
           }
         }
         if (hit0) atomicAdd(&wk.hist[b0], 1ull);
@@ -2741,6 +2660,7 @@ __device__ __forceinline__ void assist_body(const Geom& g_arg, const DetGrid& d_
         const uint32_t pubr = ld(&Q->resume_pub);
         uint32_t w = 0;
         while (pubr + cnt - ld(&Q->resume_head) > kResumeCap) {       // room?  (the tracers never wait for this wave)
+          { const uint32_t bt = ld(&Q->beat); if (bt != beat_seen) { beat_seen = bt; w = 0u; } }
           if (++w > kSpinLimit) { if (lane == 0) add(&Q->failed, 1u); break; }
           __builtin_amdgcn_s_sleep(2);
         }
@@ -2890,8 +2810,8 @@ isx_bin_discs_kernel(const DetGrid d_arg, const Work wk) {
       const bool have = b0 + (uint32_t)lane < n_lines;
       float px = 0.f, py = 0.f, pz = 0.f, vx = 0.f, vy = 0.f, vz = -1.f;
       if (have) {
-        const double2* src = reinterpret_cast<const double2*>(rec + 8ull * (b0 + (uint32_t)lane));
-        const double2 a = src[0], b = src[1], c = src[2], e = src[3];
+        const GlbD2* src = (const GlbD2*)(rec + 8ull * (b0 + (uint32_t)lane));
+        const isx_d2 a = src[0], b = src[1], c = src[2], e = src[3];
         LdsF64* sp = seg + 7 * lane;
         sp[0] = a.x; sp[1] = a.y; sp[2] = b.x; sp[3] = b.y; sp[4] = c.x; sp[5] = c.y; sp[6] = e.x;
         px = (float)a.x; py = (float)a.y; pz = (float)b.x; vx = (float)b.y; vy = (float)c.x; vz = (float)c.y;
@@ -2928,7 +2848,7 @@ isx_bin_discs_kernel(const DetGrid d_arg, const Work wk) {
   unsigned long long flushed = 0;
   for (int b = tid; b < nbins; b += nthr) {
     const uint32_t c = hist[b];
-    if (c) { atomicAdd(&wk.hist[b], (unsigned long long)c); flushed += c; }
+    if (c) { global_add_u64(&wk.hist[b], (unsigned long long)c); flushed += c; }
   }
   if (flushed) atomicAdd(&wk.stats[5], flushed);
 }
@@ -2998,9 +2918,7 @@ isx_bin_lines_kernel(const DetGrid d_arg, const Work wk) {
       RecPre pre;
       pre.Fz = pre.AF = pre.jf = pre.ch2 = 0.f; pre.rows = -1;
       if (have) {
-        const double2* src = reinterpret_cast<const double2*>(rec + 6ull * (b0 + (uint32_t)lane));
-        const double2 a = src[0], b = src[1], c = src[2];
-        lp.x = a.x; lp.y = a.y; lp.z = b.x; lv.x = b.y; lv.y = c.x; lv.z = c.y;
+        load_line(rec + 6ull * (b0 + (uint32_t)lane), lp, lv);
         if (bin_mode == 1) pre = prep_record(k, lp, lv);
       }
       struct { int n_phi; double half_w2, portz; const double* table; } dfast;
@@ -3045,10 +2963,10 @@ isx_bin_lines_kernel(const DetGrid d_arg, const Work wk) {
   __syncthreads();
   unsigned long long flushed = 0;
   unsigned long long* ghist = wk.hist;
-  asm volatile("" : "+s"(ghist));   // (same: no VGPR copy of this pointer held from the prologue)
+  asm volatile("" : "+s"(ghist));   // (no VGPR copy of this pointer held from the prologue; global_add_u64: global_atomic, not flat)
   for (int b = tid; b < nbins; b += nthr) {
     const uint32_t c = hist[b];
-    if (c) { atomicAdd(&ghist[b], (unsigned long long)c); flushed += c; }
+    if (c) { global_add_u64(&ghist[b], (unsigned long long)c); flushed += c; }
   }
   if (flushed) atomicAdd(&wk.stats[5], flushed);
 }
@@ -3118,36 +3036,55 @@ isx_bin_slots_kernel(const DetGrid d_arg, const Work wk) {
     for (uint32_t b0 = q_first; b0 < n_lines; b0 += 64u) {
       const bool have = b0 + (uint32_t)lane < n_lines;
       const int first_line = (int)(b0 - q_first);
-      GridConst k;
-      k.Rf = (float)d.R; k.rho = (float)d.rho_d; k.portz = (float)d.portz; k.n_theta = d.n_theta;
-      k.inv_dphi = (float)d.n_phi * 0.15915494309f;
-      k.inv_dth = (float)k.n_theta * 0.63661977237f;
-      V3 lp, lv;
-      lp.x = lp.y = lp.z = 0.0; lv.x = lv.y = 0.0; lv.z = -1.0;
-      RecPre pre;
-      pre.Fz = pre.AF = pre.jf = pre.ch2 = 0.f; pre.rows = -2;
-      if (have) {
-        const double2* src = reinterpret_cast<const double2*>(lines + 6 * (first_line + lane));
-        const double2 a = src[0], b = src[1], c = src[2];
-        lp.x = a.x; lp.y = a.y; lp.z = b.x; lv.x = b.y; lv.y = c.x; lv.z = c.y;
-        pre = prep_record(k, lp, lv);
-      }
-      { const int n_far = (int)__popcll(__ballot(have && pre.rows == -2)); (void)n_far; ISX_DIAG_ADD(3, n_far); }
-      ISX_BD_MARK(sq, 0);
-      // lines off the fast path.  What is decided about such a line before its rows -- caps or a box, the box, its row range --
-      // is evaluated by the line's own lane (general_pre); the grazing lines' rows are then packed over the lanes
-      // (produce_boxes_packed); the lines with general caps are taken one at a time, lane = row (produce_general)
-      BoxLine gbx;
-      gbx.smax = gbx.smin = gbx.vxy = gbx.avz = gbx.ivz = gbx.dn = gbx.Hm = gbx.Hz = gbx.phin = gbx.rs = gbx.sig = 0.f;
-      int gk = 2, gilo = 0, gihi = -1;
-      if (have && pre.rows == -1) {
-        struct { int n_theta; double rho_d, R, portz; } dg;
-        dg.n_theta = d.n_theta; dg.rho_d = d.rho_d; dg.R = d.R; dg.portz = d.portz;
-        gk = general_pre(dg, lp, lv, k.inv_dth, gbx, gilo, gihi);
-      }
-      { const int n_box = (int)__popcll(__ballot(gk == 1 && have && pre.rows == -1)); (void)n_box; ISX_DIAG_ADD(2, n_box); }
-      {
-        const int nrow = (have && pre.rows == -1 && gk == 1) ? gihi - gilo + 1 : 0;
+      // Three passes over the batch, one producer: the caps around the first piercing points (every line that has caps), the caps
+      // around the second piercing points (the few lines whose second cap reaches detector rows), the box windows of the grazing
+      // lines (no caps: a third of the BRDF source's lines).  Nothing but wave-uniform masks lives from one pass to the next: a
+      // pass reads its lines (again: L2) and the grid constants (LDS) where it needs them.
+      unsigned long long m_second = 0ull, m_box = 0ull;
+#pragma unroll 1
+      for (int pass = 0; pass < 3; ++pass) {
+        const unsigned long long pm = pass == 0 ? __ballot(have) : (pass == 1 ? m_second : m_box);
+        if (pm == 0ull) continue;
+        const bool part = ((pm >> lane) & 1ull) != 0ull;
+        BoxLine own;
+        own.smax = own.smin = own.vxy = own.avz = own.ivz = own.dn = own.Hm = own.Hz = own.phin = own.rs = own.sig = 0.f;
+        int ilo = 0, ihi = -1;
+        bool low2 = false, box = false, far = false;
+        GridConst k;   // (volatile LDS reads: derived again in every pass, never held across one)
+        k.Rf = (float)d.R; k.rho = (float)d.rho_d; k.portz = (float)d.portz; k.n_theta = d.n_theta;
+        k.inv_dphi = (float)d.n_phi * 0.15915494309f;
+        k.inv_dth = (float)k.n_theta * 0.63661977237f;
+        if (part) {
+          uint32_t li = (uint32_t)(first_line + lane);
+          asm volatile("" : "+v"(li));   // (the address is formed here, not hoisted out of the batch loop and spilled)
+          V3 lp, lv;
+          load_line(lines + 6 * li, lp, lv);
+          if (pass < 2) {
+            CapShared sh = prep_shared(k, lp, lv);
+            if (pass == 0) {
+              if (sh.kind == 0) {
+                low2 = cap_is_low(k, sh, lp, lv, 1);
+                if (low2 && caps_may_touch(k, sh)) { sh.kind = -1; low2 = false; }   // the whole line through the box windows
+              }
+              box = sh.kind == -1;
+              far = sh.kind == -2;
+            }
+            if (sh.kind == 0) cap_rows_pre(k, lp, lv, sh, pass, own, ilo, ihi);
+          } else {
+            struct { int n_theta; double rho_d, R, portz; } dg;
+            dg.n_theta = d.n_theta; dg.rho_d = d.rho_d; dg.R = d.R; dg.portz = d.portz;
+            if (!box_line(dg, lp, lv, k.inv_dth, own, ilo, ihi)) { ilo = 0; ihi = -1; far = true; }
+          }
+        }
+        if (pass == 0) {
+          m_second = __ballot(low2);
+          m_box = __ballot(box);
+          ISX_BD_MARK(sq, 0);
+          { const int n_fast = (int)__popcll(__ballot(part && !box && !far)); (void)n_fast; ISX_DIAG_ADD(0, n_fast); }
+        }
+        if (pass == 2) { const int n_box = (int)__popcll(__ballot(part && !far)); (void)n_box; ISX_DIAG_ADD(2, n_box); }
+        { const int n_far = (int)__popcll(__ballot(far)); (void)n_far; ISX_DIAG_ADD(3, n_far); }
+        const int nrow = (part && ihi >= ilo) ? ihi - ilo + 1 : 0;
         int incl = nrow;
 #pragma unroll
         for (int dlt = 1; dlt < 64; dlt <<= 1) {
@@ -3156,29 +3093,9 @@ isx_bin_slots_kernel(const DetGrid d_arg, const Work wk) {
         }
         const int total = __builtin_amdgcn_readlane(incl, 63);
         if (total > 0)
-          produce_boxes_packed(dfast, hist, rowt, colx, lines, sq, gbx, gilo, nrow, incl - nrow, incl, total, k.inv_dphi, k.portz, first_line,
-                               lane, mrk);
+          produce_rows_packed(dfast, hist, rowt, colx, lines, sq, own, ilo, nrow, incl - nrow, incl, total, pass == 2, k.inv_dphi, k.portz,
+                              first_line, lane, mrk);
       }
-      unsigned long long em = __ballot(have && pre.rows == -1 && gk == 0);
-      while (em) {
-        const int src = __builtin_ctzll(em);
-        em &= em - 1ull;
-        V3 P, V;
-        P.x = readlane_f64(lp.x, src); P.y = readlane_f64(lp.y, src); P.z = readlane_f64(lp.z, src);
-        V.x = readlane_f64(lv.x, src); V.y = readlane_f64(lv.y, src); V.z = readlane_f64(lv.z, src);
-        produce_general(d, dfast, hist, rowt, colx, lines, sq, P, V, first_line + src, lane);
-      }
-      // fast-path lines: their rows packed over the lanes
-      const int nrow = (have && pre.rows >= 0) ? ((pre.rows >> 16) - (pre.rows & 0xffff) + 1) : 0;
-      int incl = nrow;
-#pragma unroll
-      for (int dlt = 1; dlt < 64; dlt <<= 1) {
-        const int o = __shfl_up(incl, dlt, 64);
-        if (lane >= dlt) incl += o;
-      }
-      const int total = __builtin_amdgcn_readlane(incl, 63);
-      { const int n_fast = (int)__popcll(__ballot(nrow > 0)); (void)n_fast; ISX_DIAG_ADD(0, n_fast); }
-      produce_packed(dfast, hist, rowt, colx, lines, sq, pre, nrow, incl - nrow, incl, total, k.inv_dphi, first_line, lane, mrk);
     }
     drain_slots(dfast, hist, rowt, colx, lines, sq, 1, lane);   // the unit's leftovers, class by class
   }
@@ -3188,7 +3105,7 @@ isx_bin_slots_kernel(const DetGrid d_arg, const Work wk) {
   asm volatile("" : "+s"(ghist));
   for (int b = tid; b < nbins; b += nthr) {
     const uint32_t c = hist[b];
-    if (c) { atomicAdd(&ghist[b], (unsigned long long)c); flushed += c; }
+    if (c) { global_add_u64(&ghist[b], (unsigned long long)c); flushed += c; }
   }
   if (flushed) atomicAdd(&wk.stats[5], flushed);
 }
@@ -3272,46 +3189,55 @@ isx_bin_cols_kernel(const DetGrid d_arg, const Work wk) {
     for (uint32_t b0 = q_first; b0 < n_lines; b0 += 64u) {
       const bool have = b0 + (uint32_t)lane < n_lines;
       const int first_line = (int)(b0 - q_first);
-      GridConst k;
-      k.Rf = (float)d.R; k.rho = (float)d.rho_d; k.portz = (float)d.portz; k.n_theta = d.n_theta;
-      k.inv_dphi = (float)d.n_phi * 0.15915494309f;
-      k.inv_dth = (float)k.n_theta * 0.63661977237f;
-      V3 lp, lv;
-      lp.x = lp.y = lp.z = 0.0; lv.x = lv.y = 0.0; lv.z = -1.0;
-      ColPre pre;
-      pre.fx = pre.fy = pre.a = pre.cosw = 0.f; pre.jlo = 0; pre.ncol = 0; pre.kind = -2;
-      if (have) {
-        const double2* src = reinterpret_cast<const double2*>(lines + 6 * (first_line + lane));
-        const double2 a = src[0], b = src[1], c = src[2];
-        lp.x = a.x; lp.y = a.y; lp.z = b.x; lv.x = b.y; lv.y = c.x; lv.z = c.y;
-        pre = prep_cols(k, dcol.n_phi, lp, lv, 0);
-      }
-      ISX_BD_MARK(sq, 0);
-      { const int n_far = (int)__popcll(__ballot(have && pre.kind == -2)); (void)n_far; ISX_DIAG_ADD(3, n_far); }
-      // lines off the fast path: one at a time, lane = row (cap or box windows), as in isx_bin_lines_kernel
-      unsigned long long em = __ballot(have && pre.kind == -1);
-      while (em) {
-        const int src = __builtin_ctzll(em);
-        em &= em - 1ull;
-        V3 P, V;
-        P.x = readlane_f64(lp.x, src); P.y = readlane_f64(lp.y, src); P.z = readlane_f64(lp.z, src);
-        V.x = readlane_f64(lv.x, src); V.y = readlane_f64(lv.y, src); V.z = readlane_f64(lv.z, src);
-        bin_culled<true>(d, hist, rowt, colx, P, V, lane, spl);
-      }
-      // lines with caps: the columns of their caps packed over the lanes -- side 0 (every fast-path line has only this one),
-      // then side 1 for the few lines whose second piercing point lies low enough to reach detector rows
-      const ColPre pre_first = pre;
+      // Nothing but wave-uniform masks (scalar registers) lives from one pass of the batch to the next: until round 4 the line
+      // (12 VGPRs), the first cap (7) and the wave-uniform binary32 constants of the preparation (gfx950 has no scalar float
+      // unit: VGPRs as well) were kept across the whole inlined consumer for the benefit of the second pass -- the kernel sits
+      // at its 128-VGPR limit, so they went to scratch and back, 60 bytes per lane and batch: 0.8 GB of HBM writes per
+      // 5e7-ray launch next to 129.6 KB of algorithmic output.  A pass now reads its lines (again: L2) and the constants (LDS)
+      // where it needs them, and the second pass no longer looks at the first cap (caps_may_touch).
+      unsigned long long second_m = 0ull;
 #pragma unroll 1
       for (int side = 0; side < 2; ++side) {
-        if (side == 1) {
-          const bool again = have && pre.kind != -1 && pre.kind != -2;   // (a line with caps at all)
-          if (__ballot(again) == 0ull) break;
-          ColPre p1;
-          p1.fx = p1.fy = p1.a = p1.cosw = 0.f; p1.jlo = 0; p1.ncol = 0; p1.kind = -3;
-          if (again) p1 = prep_cols(k, dcol.n_phi, lp, lv, 1);
-          pre = p1;
+        if (side == 1 && second_m == 0ull) break;
+        // side 1: the few lines whose second piercing point lies low enough for its cap to reach detector rows (3 %)
+        const bool part = side == 0 ? have : (((second_m >> lane) & 1ull) != 0ull);
+        ColPre pre;
+        pre.fx = pre.fy = pre.a = pre.cosw = 0.f; pre.jlo = 0; pre.ncol = 0; pre.kind = -2;
+        V3 lp, lv;
+        lp.x = lp.y = lp.z = 0.0; lv.x = lv.y = 0.0; lv.z = -1.0;
+        bool low2 = false;
+        if (part) {
+          GridConst k;   // (volatile LDS reads: derived again here, never held across a pass)
+          k.Rf = (float)d.R; k.rho = (float)d.rho_d; k.portz = (float)d.portz; k.n_theta = d.n_theta;
+          k.inv_dphi = (float)d.n_phi * 0.15915494309f;
+          k.inv_dth = 0.f;
+          uint32_t li = (uint32_t)(first_line + lane);
+          asm volatile("" : "+v"(li));   // (the address is formed here, not hoisted out of the batch loop and spilled)
+          load_line(lines + 6 * li, lp, lv);
+          CapShared sh = prep_shared(k, lp, lv);
+          if (side == 0 && sh.kind == 0) {
+            low2 = cap_is_low(k, sh, lp, lv, 1);
+            if (low2 && caps_may_touch(k, sh)) { sh.kind = -1; low2 = false; }   // the whole line through the box windows
+          }
+          pre = prep_cols(k, dcol.n_phi, lp, lv, sh, side);
         }
-        const int ncol = (have && pre.kind == 0) ? pre.ncol : 0;
+        if (side == 0) {
+          ISX_BD_MARK(sq, 0);
+          { const int n_far = (int)__popcll(__ballot(have && pre.kind == -2)); (void)n_far; ISX_DIAG_ADD(3, n_far); }
+          // lines without caps (grazing lines; none in the headline): one at a time, lane = row, box windows
+          unsigned long long em = __ballot(have && pre.kind == -1);
+          while (em) {
+            const int src = __builtin_ctzll(em);
+            em &= em - 1ull;
+            V3 P, V;
+            P.x = readlane_f64(lp.x, src); P.y = readlane_f64(lp.y, src); P.z = readlane_f64(lp.z, src);
+            V.x = readlane_f64(lv.x, src); V.y = readlane_f64(lv.y, src); V.z = readlane_f64(lv.z, src);
+            bin_culled<false>(d, hist, rowt, colx, P, V, lane, spl);
+          }
+          second_m = __ballot(low2);
+          { const int n_fast = (int)__popcll(__ballot(have && pre.kind == 0 && pre.ncol > 0)); (void)n_fast; ISX_DIAG_ADD(0, n_fast); }
+        }
+        const int ncol = (part && pre.kind == 0) ? pre.ncol : 0;
         int incl = ncol;
 #pragma unroll
         for (int dlt = 1; dlt < 64; dlt <<= 1) {
@@ -3319,11 +3245,11 @@ isx_bin_cols_kernel(const DetGrid d_arg, const Work wk) {
           if (lane >= dlt) incl += o;
         }
         const int total = __builtin_amdgcn_readlane(incl, 63);
-        if (side == 0) { const int n_fast = (int)__popcll(__ballot(ncol > 0)); (void)n_fast; ISX_DIAG_ADD(0, n_fast); }
         ColPre pc = pre;
         pc.ncol = ncol;
-        produce_cols_packed(dcol, hist, rowt, colx, rowx, lines, sq, pc, incl - ncol, incl, total, k.inv_dth, k.n_theta, first_line, lane, mrk,
-                            pre_first, side == 1);
+        const int n_theta = d.n_theta;
+        produce_cols_packed(dcol, hist, rowt, colx, rowx, lines, sq, pc, incl - ncol, incl, total, (float)n_theta * 0.63661977237f, n_theta,
+                            first_line, lane, mrk);
       }
       if (first_line == 64) flush_deferred(dcol, hist, rowt, colx, lines, sq, lane);   // half-way through the unit (and at its end)
     }
@@ -3336,7 +3262,7 @@ isx_bin_cols_kernel(const DetGrid d_arg, const Work wk) {
   asm volatile("" : "+s"(ghist));
   for (int b = tid; b < nbins; b += nthr) {
     const uint32_t c = hist[b];
-    if (c) { atomicAdd(&ghist[b], (unsigned long long)c); flushed += c; }
+    if (c) { global_add_u64(&ghist[b], (unsigned long long)c); flushed += c; }
   }
   if (flushed) atomicAdd(&wk.stats[5], flushed);
 }

@@ -165,15 +165,36 @@ bool rccl_init(const Comm& c) {
   const std::string me = std::to_string(c.rank);
   (void)unlink((dir + "/ready." + me).c_str());   // nothing of this rank survives from an earlier launch with the same tag
   (void)unlink((dir + "/fail." + me).c_str());
+  (void)unlink((dir + "/ack." + me).c_str());
+  auto fresh = []() {
+    unsigned long long v = ((unsigned long long)std::chrono::steady_clock::now().time_since_epoch().count() << 20) ^
+                           (unsigned long long)getpid() ^ ((unsigned long long)std::time(nullptr) << 40);
+    return v ? v : 1ull;
+  };
+  // A killed launch with the same job tag (a fixed ISX_JOB_ID, a torchrun restart) leaves `launch`, `ready.*` and `id` behind, all
+  // with ITS nonce: a rank of the relaunch that starts before the new rank 0 must not adopt them (it would read the stale id
+  // and sit in ncclCommInitRank, which has no time-out).  Two measures: rank 0 removes what an earlier launch left before it
+  // publishes anything (the followers' `hello.*` included: a follower that is already waiting says hello again), and a follower
+  // trusts a `launch` file only once rank 0 has ECHOED the follower's own fresh token (`hello.<rank>` -> `ack.<rank>` =
+  // mix(nonce, token)): no file of an earlier launch can hold that value.
+  auto mix = [](unsigned long long nonce, unsigned long long token) {
+    return nonce ^ (token * 0x9E3779B97F4A7C15ull) ^ ((token << 17) | (token >> 47));
+  };
+  const unsigned long long token = fresh();
   unsigned long long nonce = 0;
+  std::vector<unsigned long long> acked((size_t)c.world, 0ull);
   if (c.rank == 0) {
-    nonce = ((unsigned long long)std::chrono::steady_clock::now().time_since_epoch().count() << 20) ^ (unsigned long long)getpid() ^
-            ((unsigned long long)std::time(nullptr) << 40);
-    if (nonce == 0) nonce = 1;
+    for (const char* name : {"launch", "id"}) (void)unlink((dir + "/" + name).c_str());
+    for (int r = 0; r < c.world; ++r)
+      for (const char* stem : {"ready.", "fail.", "ack.", "hello."}) (void)unlink((dir + "/" + stem + std::to_string(r)).c_str());
+    nonce = fresh();
     if (!publish_nonce(dir, "launch", nonce)) {
       std::cerr << "Error: isx_comm: cannot write into " << dir << std::endl;
       return false;
     }
+  } else if (!publish_nonce(dir, "hello." + me, token)) {
+    std::cerr << "Error: isx_comm: cannot write into " << dir << std::endl;
+    return false;
   }
   auto announce = [&](unsigned long long n) {
     const std::string name = (dev_ok ? "ready." : "fail.") + me;
@@ -184,11 +205,26 @@ bool rccl_init(const Comm& c) {
     std::cerr << "Error: isx_comm: cannot write into " << dir << std::endl;
     return false;
   }
-  bool all_ready = false, someone_failed = !dev_ok && c.rank == 0;
+  bool all_ready = false, someone_failed = false;
   for (int tries = 0; tries < wait_seconds() * 20 && !all_ready && !someone_failed; ++tries) {
-    if (c.rank != 0) {   // follow rank 0's nonce (the `launch` file of an earlier launch may still be there for a moment)
+    if (c.rank == 0) {   // echo the followers' tokens (a stale hello.<r> gets a stale ack: harmless, the live rank re-publishes)
+      int n_acked = 0;
+      for (int r = 1; r < c.world; ++r) {
+        unsigned long long t = 0;
+        if (read_nonce(dir + "/hello." + std::to_string(r), &t) && t != acked[(size_t)r] &&
+            publish_nonce(dir, "ack." + std::to_string(r), mix(nonce, t)))
+          acked[(size_t)r] = t;
+        if (acked[(size_t)r] != 0ull) n_acked++;
+      }
+      // a rank 0 that cannot bind its GPU has said so (fail.0); it stays long enough to echo the followers' tokens -- they can
+      // then verify the nonce of that file and stop at once instead of waiting out the rendezvous -- but no longer than 10 s
+      if (!dev_ok && (n_acked == c.world - 1 || tries >= 200)) { someone_failed = true; break; }
+    }
+    if (c.rank != 0) {   // follow rank 0's nonce -- once rank 0 of THIS launch has echoed this rank's token
+      // (rank 0 clears the directory when it starts, possibly after this rank said hello: say it again)
+      if (nonce == 0 && !has_nonce(dir + "/hello." + me, token)) (void)publish_nonce(dir, "hello." + me, token);
       unsigned long long seen = 0;
-      if (read_nonce(dir + "/launch", &seen) && seen != nonce) {
+      if (read_nonce(dir + "/launch", &seen) && seen != nonce && has_nonce(dir + "/ack." + me, mix(seen, token))) {
         nonce = seen;
         if (!announce(nonce)) {
           std::cerr << "Error: isx_comm: cannot write into " << dir << std::endl;
@@ -200,6 +236,7 @@ bool rccl_init(const Comm& c) {
     }
     int n_ready = 0;
     for (int r = 0; r < c.world; ++r) {
+      if (r == 0 && c.rank == 0 && !dev_ok) continue;   // (its own failure: handled above, once the followers can verify it)
       if (has_nonce(dir + "/fail." + std::to_string(r), nonce)) someone_failed = true;
       else if (has_nonce(dir + "/ready." + std::to_string(r), nonce)) n_ready++;
     }
@@ -207,6 +244,7 @@ bool rccl_init(const Comm& c) {
     if (!all_ready && !someone_failed) std::this_thread::sleep_for(std::chrono::milliseconds(50));
   }
   if (!all_ready) {
+    if (c.rank != 0) { (void)unlink((dir + "/hello." + me).c_str()); (void)unlink((dir + "/ack." + me).c_str()); }
     std::cerr << "Error: isx_comm: rank " << c.rank << ": " << (someone_failed ? "a rank could not bind its GPU" : "not every rank showed up")
               << " (rendezvous " << dir << "); not starting the job" << std::endl;
     return false;
@@ -250,6 +288,8 @@ bool rccl_init(const Comm& c) {
   }
   ISX_NCCL_OK(ncclCommInitRank(&R.comm, c.world, id, c.rank));   // returns once every rank has joined
   (void)unlink((dir + "/ready." + me).c_str());
+  (void)unlink((dir + "/hello." + me).c_str());
+  (void)unlink((dir + "/ack." + me).c_str());
   if (c.rank == 0) { (void)unlink((dir + "/id").c_str()); (void)unlink((dir + "/launch").c_str()); (void)rmdir(dir.c_str()); }   // rmdir succeeds once the last rank has cleaned up
   else (void)rmdir(dir.c_str());
   ISX_HIP_OK(hipStreamCreateWithFlags(&R.stream, hipStreamNonBlocking));

@@ -187,7 +187,7 @@ int isx_last_kernel_ms(double* single_ms, double* trace_ms, double* bin_ms);
  *   "bin_cols"     1 (default): (line, COLUMN) slots for the pencil source, (line, row) slots for the BRDF source; 0: row slots
  *                  everywhere; 2: column slots everywhere
  *   "bin_block", "bin_blocks_per_cu"  shape of round 2's binning kernel (0 workgroups per CU = what is resident)
- *   "ray_sub"      rays a wave takes off a launch's ray queue at a time (0 = default: 512, 256 for small launches)
+ *   "ray_sub"      rays a wave takes off a launch's ray queue at a time (0 = default: 128)
  *   "overlap", "overlap_trace_streams"  cut a flux-map call into k chunks, binning of chunk i on a second stream while chunk
  *                  i+1 is traced (measured slower on MI355X, default 0)
  *   "disc_pipeline"  1 (default): the shared-ray disc sweep as trace kernel + disc-binning kernel (discs clustered by eight on the

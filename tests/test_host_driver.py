@@ -246,6 +246,16 @@ def test_multirank_launch_stops_instead_of_hanging(cli, tmp_path):
     t0 = time.time()
     r = subprocess.run([cli, *args], cwd=tmp_path, env=env, capture_output=True, text=True, timeout=60)
     assert r.returncode != 0 and "not every rank showed up" in r.stderr and time.time() - t0 < 30, r.stderr
+    # ... nor does a lone FOLLOWER adopt the `launch` / `ready.*` leftovers of a killed launch with its tag (it would
+    # read that launch's id and block in ncclCommInitRank): it trusts a nonce only after rank 0 of THIS launch has echoed the
+    # follower's own fresh token (hello.<rank> -> ack.<rank>), which no leftover can contain.
+    for name in ("ready.0", "ready.1", "launch", "ack.1", "hello.1"):
+        with open(os.path.join(rd, name), "wb") as f:
+            f.write(b"ISXRDZV2" + struct.pack("<Q", 0x1234567))
+    env = dict(env, ISX_RANK="1")
+    t0 = time.time()
+    r = subprocess.run([cli, *args], cwd=tmp_path, env=env, capture_output=True, text=True, timeout=60)
+    assert r.returncode != 0 and "not every rank showed up" in r.stderr and time.time() - t0 < 30, r.stderr
     del jobdir
 
 

@@ -1,0 +1,88 @@
+#!/usr/bin/env python3
+"""Per-kernel ISA census of libisx (no GPU needed): VGPRs, scratch, and how every kernel reaches memory.
+
+usage: tools/isa_stats.py [--check] [--keep DIR] [extra -D flags for hipcc]
+
+Compiles csrc/isx_api.hip for gfx950 with --save-temps and counts, per kernel, flat_ / global_ / scratch_ / ds_
+instructions.  --check fails (exit 1) on the two traps DESIGN.md section 5 describes:
+  * a `flat_*` access in one of the binning kernels (a pointer whose address space hipcc could not infer: flat
+    operations complete out of order and force s_waitcnt vmcnt(0) lgkmcnt(0) together, so every line fetch also
+    drains the wave's LDS queue);
+  * any `flat_* ... sc0 sc1` (a volatile access through a generic pointer: system scope).
+and prints scratch use so that a spill inside a batch loop is seen at build time.
+"""
+import os
+import re
+import subprocess
+import sys
+import tempfile
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SRC = os.path.join(ROOT, "altair-raytracing_amd", "csrc", "isx_api.hip")
+FLAGS = ["-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "-ffp-contract=off", "-fno-fast-math", "-Wno-unused-function"]
+# kernels whose inner loops must not touch memory through generic pointers
+NO_FLAT = ("isx_bin_cols_kernel", "isx_bin_slots_kernel", "isx_bin_lines_kernel", "isx_bin_discs_kernel")
+
+
+def compile_isa(extra, keep=None):
+    d = keep or tempfile.mkdtemp(prefix="isx_isa_")
+    os.makedirs(d, exist_ok=True)
+    subprocess.check_call(["/opt/rocm/bin/hipcc", *FLAGS, *extra, "--save-temps", "-c", "-o", os.path.join(d, "isx_api.o"), SRC], cwd=d,
+                          stderr=subprocess.DEVNULL)
+    return os.path.join(d, "isx_api-hip-amdgcn-amd-amdhsa-gfx950.s")
+
+
+def kernels(path):
+    text = open(path).read()
+    for part in re.split(r"\n(?=\w+:\s*; @)", text):
+        m = re.match(r"(\w+):", part)
+        if m and m.group(1).startswith("isx_"):
+            yield m.group(1), part
+
+
+def census(body):
+    def n(pat):
+        return len(re.findall(pat, body, re.M))
+
+    def meta(key):
+        m = re.search(r"; %s: (\d+)" % key, body)
+        return int(m.group(1)) if m else -1
+
+    return {
+        "vgpr": meta("NumVgprs"), "sgpr": meta("NumSgprs"), "scratch": meta("ScratchSize"), "occ": meta("Occupancy"),
+        "flat_ld": n(r"^\s*flat_load"), "flat_st": n(r"^\s*flat_store"), "flat_at": n(r"^\s*flat_atomic"),
+        "flat_sys": n(r"^\s*flat_.*sc0 sc1"),
+        "glob_ld": n(r"^\s*global_load"), "glob_st": n(r"^\s*global_store"), "glob_at": n(r"^\s*global_atomic"),
+        "scr_ld": n(r"^\s*scratch_load"), "scr_st": n(r"^\s*scratch_store"),
+        "ds": n(r"^\s*ds_"), "lines": body.count("\n"),
+    }
+
+
+def main():
+    args = sys.argv[1:]
+    check = "--check" in args
+    keep = None
+    if "--keep" in args:
+        keep = args[args.index("--keep") + 1]
+        args = [a for i, a in enumerate(args) if a != "--keep" and (i == 0 or args[i - 1] != "--keep")]
+    extra = [a for a in args if a != "--check"]
+    path = compile_isa(extra, keep)
+    bad = []
+    print("%-36s %4s %4s %7s %3s | %7s %7s %7s %4s | %7s %7s %7s | %6s %6s | %5s" % (
+        "kernel", "vgpr", "sgpr", "scratch", "occ", "flat_ld", "flat_st", "flat_at", "sys", "glob_ld", "glob_st", "glob_at", "scr_ld", "scr_st", "ds"))
+    for name, body in kernels(path):
+        c = census(body)
+        print("%-36s %4d %4d %7d %3d | %7d %7d %7d %4d | %7d %7d %7d | %6d %6d | %5d" % (
+            name, c["vgpr"], c["sgpr"], c["scratch"], c["occ"], c["flat_ld"], c["flat_st"], c["flat_at"], c["flat_sys"],
+            c["glob_ld"], c["glob_st"], c["glob_at"], c["scr_ld"], c["scr_st"], c["ds"]))
+        if c["flat_sys"]:
+            bad.append("%s: %d system-scope flat accesses" % (name, c["flat_sys"]))
+        if name in NO_FLAT and (c["flat_ld"] + c["flat_st"] + c["flat_at"]):
+            bad.append("%s: %d flat_ accesses" % (name, c["flat_ld"] + c["flat_st"] + c["flat_at"]))
+    if check and bad:
+        print("\n".join("TRAP " + b for b in bad))
+        sys.exit(1)
+
+
+if __name__ == "__main__":
+    main()
