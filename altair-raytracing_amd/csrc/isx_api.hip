@@ -60,7 +60,7 @@ struct State {
   int assist_block = ISX_ASSIST_BLOCK;          // its workgroup size: (assist_block / 64 - 1) tracer waves + 1 assist wave
   int disc_pipeline = 1;                        // 1 (default): the shared-ray disc sweep as assist-wave trace kernel + isx_bin_discs_kernel; 0: fused SINK_DISC kernel
   int assist = 1;                               // 1: trace kernels with an assist wave per workgroup (assist_body)
-  int bin_cols = 1;                             // 1: isx_bin_cols_kernel ((line, column) slots) for the pencil source where bin_slots applies
+  int bin_cols = 1;                             // 1 (2: the same): isx_bin_cols_kernel ((line, column) slots) where bin_slots applies; 0: row slots
   int bin_slots = 1;                            // 1: isx_bin_slots_kernel (slot queues by window length) where the grid allows it
   // options
   int bin_mode = 1;
@@ -411,9 +411,9 @@ int enqueue(int sink, const isx_config* c, uint64_t n, uint64_t seed, uint64_t f
     // 32-bit slot records and the LDS; else the one without
     const bool slots = S.bin_slots && S.bin_mode == 1 && d.n_theta <= 256 && d.n_phi <= 255 &&
                        lds_tables + (size_t)(2 * d.n_phi) * sizeof(ColP) + (size_t)(kBlock / 64) * kSlotWaveWords * 4 <= S.lds_limit;
-    // ... and with COLUMN slots for the pencil source (most lines on the fast path; the BRDF model's grazing lines are served
-    // better by the row slots of isx_bin_slots_kernel)
-    const bool cols = slots && S.bin_cols && (!brdf || S.bin_cols == 2) &&
+    // ... and with COLUMN slots (default for every source since round 4: grazing lines are column slots as well -- prep_band;
+    // bin_cols = 0 keeps the row slots of isx_bin_slots_kernel)
+    const bool cols = slots && S.bin_cols &&
                       lds_tables + (size_t)(d.n_theta + 4) * sizeof(RowX) + (size_t)(kBlock / 64) * kColWaveWords * 4 <= S.lds_limit;
     typedef void (*BinFn)(const DetGrid, const Work);
     const BinFn bin_fn = cols ? isx_bin_cols_kernel : slots ? isx_bin_slots_kernel : isx_bin_lines_kernel;
@@ -1166,11 +1166,11 @@ int isx_exit_dz_hist(const isx_config* cfg, uint64_t n_rays, uint64_t seed, uint
 
 #ifdef ISX_DIAG
 // tuning builds only (not declared in isx.h): read and clear the binning diagnostics of isx_kernels.hpp
-int isx_diag_read(uint64_t* out32) {
-  if (!S.init || !out32) return ISX_ERR_BAD_ARG;
+int isx_diag_read(uint64_t* out48) {
+  if (!S.init || !out48) return ISX_ERR_BAD_ARG;
   HIPCHK(hipStreamSynchronize(S.stream));
-  HIPCHK(hipMemcpyFromSymbol(out32, HIP_SYMBOL(isx::g_diag), 32 * sizeof(unsigned long long)));
-  unsigned long long z[32] = {0};
+  HIPCHK(hipMemcpyFromSymbol(out48, HIP_SYMBOL(isx::g_diag), 48 * sizeof(unsigned long long)));
+  unsigned long long z[48] = {0};
   HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(isx::g_diag), z, sizeof(z)));
   return ISX_OK;
 }

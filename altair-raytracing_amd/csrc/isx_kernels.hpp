@@ -71,13 +71,14 @@ struct DetGrid {
 // re-scatter, [22] sink -- then [23] trips, [24] lanes running / [25] parked after the refill, [26] trips after the wave's range
 // ran out ("drain"), [27] lanes running in those, [28] rays ended, [29] flushes, [30] lanes flushed, [31] lanes refilled
 #ifdef ISX_DIAG
-__device__ unsigned long long g_diag[32];
+__device__ unsigned long long g_diag[48];   // [32..47]: the assist wave of assist_body (tools/diag_trace.py)
 #define ISX_DIAG_ADD(k, v) do { if (lane == 0) atomicAdd(&g_diag[k], (unsigned long long)(v)); } while (0)
 #define ISX_DIAG_ADD_LANES(k, v) atomicAdd(&g_diag[k], (unsigned long long)(v))
 #define ISX_TD_DECL unsigned long long td_[16] = {0}; unsigned long long tdc_ = clock64()
 #define ISX_TD_MARK(k) do { const unsigned long long c_ = clock64(); td_[k] += c_ - tdc_; tdc_ = c_; } while (0)
 #define ISX_TD_ADD(k, v) do { td_[k] += (unsigned long long)(v); } while (0)
 #define ISX_TD_FLUSH() do { if (lane == 0) for (int k_ = 0; k_ < 16; ++k_) atomicAdd(&g_diag[16 + k_], td_[k_]); } while (0)
+#define ISX_TD_FLUSH_AT(b_) do { if (lane == 0) for (int k_ = 0; k_ < 16; ++k_) atomicAdd(&g_diag[(b_) + k_], td_[k_]); } while (0)
 // binning kernel with slot queues: wave cycles since the previous mark go to region k (the timestamp lives in the two unused
 // counter words of the wave's SlotQueues): [16] batch preparation, [17] producers (owner search, windows), [18] push,
 // [19] pop + line fetch + coefficients, [20] column walk, [21] unit bookkeeping
@@ -94,6 +95,7 @@ __device__ unsigned long long g_diag[32];
 #define ISX_TD_MARK(k) do { } while (0)
 #define ISX_TD_ADD(k, v) do { } while (0)
 #define ISX_TD_FLUSH() do { } while (0)
+#define ISX_TD_FLUSH_AT(b_) do { } while (0)
 #endif
 
 enum : int { SINK_FLUX = 0, SINK_DZ = 1, SINK_DISC = 2, SINK_PERPOS = 3, SINK_LOG = 4, SINK_DISCPOS = 5, SINK_REC = 6 };
@@ -130,6 +132,9 @@ constexpr int kBlock = ISX_BLOCK;
 #endif
 #ifndef ISX_WALK4
 #define ISX_WALK4 1
+#endif
+#ifndef ISX_ATOM_BRANCH
+#define ISX_ATOM_BRANCH 0
 #endif
 #ifndef ISX_ASSIST_MIN
 #define ISX_ASSIST_MIN 48     // the assist wave waits for this many queued rays ... (measured: 16: 11.69 ms, 32: 11.50, 48: 11.34, 56: 11.44, 64: 11.48)
@@ -947,7 +952,7 @@ __device__ __forceinline__ void walk_lines_packed(const D& d, uint32_t* __restri
 constexpr int kClasses = 7, kQueueCap = 128;   // a class never holds more than 63 + 64 slots
 constexpr int kSlotWaveWords = kClasses * kQueueCap + 16 + 64;   // LDS words per wave: queues, counters, owner marks
 constexpr int kDeferCap = kDeferCapW;   // candidates a wave can put aside for tiers 2 and 3
-constexpr int kColWaveWords = kClasses * kQueueCap + 16 + 64 + 64 + 4 + kDeferCap;   // the same + the long-row list of bin_culled + the deferred list (count, 3 spare, entries)
+constexpr int kColWaveWords = kClasses * kQueueCap + 16 + 64 + 4 + kDeferCap;   // the same + the deferred list (count, 3 spare, entries)
 constexpr int kPiece = 16, kLongest = 24;
 struct SlotQueues {
   LdsWord* q;         // [kClasses][kQueueCap]
@@ -1262,6 +1267,9 @@ __device__ __forceinline__ void cap_rows(float fx, float fy, float a, float cosw
   if (!(rho2 > 1e-12f)) return;
   const float x = cosw * __builtin_amdgcn_rsqf(rho2);
   if (x > 1.0f) return;                                               // the column misses the cap
+  // (a cap wider than a quarter turn in the meridian's plane -- only the cap about h^ of a grazing line can be, prep_band: the caps
+  //  of prep_cols have cos w > 0.5 -- would need theta taken modulo 2 pi, and leaves out a short stretch at most: every row)
+  if (x < 0.0f) { ilo = 0; cnt = n_theta; return; }
   const float dl = acos_cull(fmaxf(x, -1.0f)) + 2.5e-3f;
   const float tc = atan2_cull(b, a);
   const float tlo = tc - dl, thi = tc + dl;
@@ -1270,6 +1278,95 @@ __device__ __forceinline__ void cap_rows(float fx, float fy, float a, float cosw
   const int lo = max((int)ceilf(tlo * inv_dth - 0.5f - 1e-3f), 0);
   const int hi = min((int)floorf(thi * inv_dth - 0.5f + 1e-3f), n_theta - 1);
   if (hi >= lo) { ilo = lo; cnt = hi - lo + 1; }
+}
+
+// ---- GRAZING lines as column slots (round 4; until then such a line was taken one at a time, lane = row: bin_culled's box
+// windows).  A line without caps passes S(O,R) at a distance h from O of about R (or its caps would merge: rho_d comparable to R).
+// Every detector centre c it can hit lies within rho of the line, X(s) = H + s V (H the foot of O, |V| = 1), hence -- e = the part of
+// c - H perpendicular to V, |e| <= rho -- inside two slabs:
+//   (c - H).h^ >= -rho  (h^ = H/h)        =>  c.h^ >= h - rho: the CAP of angular radius acos((h - rho)/R) about the direction h^
+//                                              (it bounds the LENGTH of the stretch of S(O,R) the tube crosses),
+//   |(c - H).u| <= rho,  u = V x h^        =>  |c.u| <= rho: the BAND of half-width asin(rho/R) about the great circle
+//                                              perpendicular to u (it bounds the stretch's WIDTH; H.u = 0),
+// a "rectangle" on the sphere around the tube's footprint (4/pi of its area, like the box windows' bounding boxes).  The cap is what
+// prep_cols / cap_rows already handle (F := R h^, cos w := (h - rho)/R); the band adds, per column, |N sin(theta - delta)| <= rho/R with
+// N e^(i delta) = (c_phi u_x + s_phi u_y) + i u_z, i.e. theta within asin(rho / (R N)) of delta + m pi: at most two stretches of
+// rows inside the cap's range.  Binary32 with explicit slack (rho: 0.1 % + 2e-3 cm as in box_line; unit vectors and R: 4e-6; angles
+// 2.6e-3 rad + the cull functions' 1e-4; rows 1e-3): never decides a result, a candidate outside the tube is a miss of the exact test.
+struct BandPre { float ux, uy, uz, kap; };   // u = V x h^, kappa = rho / R with its slack
+__device__ __forceinline__ ColPre prep_band(const GridConst& k, int n_phi, const V3& P, const V3& V, BandPre& bp) {
+  ColPre o;
+  o.fx = o.fy = o.a = o.cosw = 0.f; o.jlo = 0; o.ncol = 0; o.kind = -2;
+  bp.ux = bp.uy = bp.uz = 0.f; bp.kap = 2.f;
+  const double wz = P.z - (double)k.portz;
+  const double wv = fma(P.x, V.x, fma(P.y, V.y, wz * V.z));
+  const float Hx = (float)fma(-wv, V.x, P.x), Hy = (float)fma(-wv, V.y, P.y), Hz = (float)fma(-wv, V.z, wz);
+  const float Vx = (float)V.x, Vy = (float)V.y, Vz = (float)V.z;
+  const float h = sqrt_cull(fmaf(Hx, Hx, fmaf(Hy, Hy, Hz * Hz)));
+  if (h - k.rho > 1.001f * k.Rf) return o;                           // farther than R + rho_d from O: nothing can be hit (box_line's test)
+  const float rs = fmaf(k.rho, 1.001f, 2e-3f);
+  const float iR = rcp_cull(k.Rf);
+  float ex, ey, ez, cosw;
+  if (h > 1e-3f * k.Rf) {
+    const float ih = rcp_cull(h);
+    ex = Hx * ih; ey = Hy * ih; ez = Hz * ih;
+    cosw = fmaxf(-1.0f, (h - rs) * iR - 4e-6f);
+  } else {
+    // the line passes through O (to 0.1 % of R): any unit vector perpendicular to V serves as h^, and the cap is the whole sphere
+    const float ax = fabsf(Vx), ay = fabsf(Vy), az = fabsf(Vz);
+    float tx = 0.f, ty = 0.f, tz = 0.f;
+    if (ax <= ay && ax <= az) tx = 1.f; else if (ay <= az) ty = 1.f; else tz = 1.f;
+    const float tv = fmaf(tx, Vx, fmaf(ty, Vy, tz * Vz));
+    ex = fmaf(-tv, Vx, tx); ey = fmaf(-tv, Vy, ty); ez = fmaf(-tv, Vz, tz);
+    const float ie = __builtin_amdgcn_rsqf(fmaf(ex, ex, fmaf(ey, ey, ez * ez)));
+    ex *= ie; ey *= ie; ez *= ie;
+    cosw = -1.0f;
+  }
+  o.fx = ex; o.fy = ey; o.a = -ez; o.cosw = cosw; o.kind = 0;
+  bp.ux = fmaf(Vy, ez, -(Vz * ey)); bp.uy = fmaf(Vz, ex, -(Vx * ez)); bp.uz = fmaf(Vx, ey, -(Vy * ex));
+  bp.kap = fmaf(rs * iR, 1.0001f, 4e-6f);
+  // columns the cap can reach (prep_cols): all of them if it holds the pole or is wider than a hemisphere
+  const float sinF = sqrt_cull(fmaf(o.fx, o.fx, o.fy * o.fy));
+  const float sinw = sqrt_cull(fmaxf(0.f, fmaf(-cosw, cosw, 1.0f)));
+  if (!(cosw > 0.05f) || !(sinF > sinw * 1.01f + 1e-4f)) { o.jlo = 0; o.ncol = n_phi; return o; }
+  const float r = fminf(1.0f, sinw * rcp_cull(sinF) * 1.001f);
+  const float dphi = (1.57079637f - acos_cull(r)) + 3e-3f;
+  float phiF = atan2_cull(o.fy, o.fx);
+  if (phiF < 0.f) phiF += 6.28318530718f;
+  const float jc = phiF * k.inv_dphi - 0.5f, hw = dphi * k.inv_dphi + 0.02f;
+  const int lo = (int)ceilf(jc - hw), hi = (int)floorf(jc + hw);
+  int n = hi - lo + 1;
+  if (n >= n_phi) { o.jlo = 0; o.ncol = n_phi; return o; }
+  if (n < 0) n = 0;
+  int j0 = lo;
+  if (j0 < 0) j0 += n_phi;
+  if (j0 >= n_phi) j0 -= n_phi;
+  o.jlo = j0; o.ncol = n;
+  return o;
+}
+// the rows of column (c32, s32) inside the band, cut to [row_lo, row_hi] (what the cap allows): [ilo, ilo + cnt) and, if the
+// meridian enters the band twice, [ilo_b, ilo_b + cnt_b) -- disjoint (the stretches are pi apart, each shorter than 0.9 pi)
+__device__ __forceinline__ void band_rows(const BandPre& bp, float c32, float s32, float inv_dth, int row_lo, int row_hi, int& ilo, int& cnt,
+                                          int& ilo_b, int& cnt_b) {
+  ilo = cnt = ilo_b = cnt_b = 0;
+  if (row_hi < row_lo) return;
+  const float ga = fmaf(c32, bp.ux, s32 * bp.uy);
+  const float N2 = fmaf(ga, ga, bp.uz * bp.uz);
+  if (!(N2 > bp.kap * bp.kap * 1.03f + 1e-12f)) { ilo = row_lo; cnt = row_hi - row_lo + 1; return; }   // (nearly) the whole meridian lies in the band
+  const float x = bp.kap * __builtin_amdgcn_rsqf(N2);               // < 0.986
+  const float al = (1.57079637f - acos_cull(x)) + 2.6e-3f;          // asin(x) + slack: < 1.41, so the stretches are more than 0.3 rad apart
+  const float de = atan2_cull(bp.uz, ga);
+#pragma unroll
+  for (int m = -1; m <= 1; ++m) {
+    const float ce = fmaf((float)m, 3.14159274f, de);
+    const float tlo = ce - al, thi = ce + al;
+    if (thi < 0.f || tlo > 1.57079637f) continue;
+    const int lo = max((int)ceilf(tlo * inv_dth - 0.5f - 1e-3f), row_lo);
+    const int hi = min((int)floorf(thi * inv_dth - 0.5f + 1e-3f), row_hi);
+    if (hi < lo) continue;
+    if (cnt == 0) { ilo = lo; cnt = hi - lo + 1; }
+    else { ilo_b = lo; cnt_b = hi - lo + 1; }
+  }
 }
 
 // one pass: 64 column slots (record: line within the unit | column << 8 | first row << 16 | rows << 24), lane = slot
@@ -1416,6 +1513,35 @@ __device__ __forceinline__ void consume_cols(const D& d, uint32_t* __restrict__ 
       classify(ie + 2, k + 2, b0, b1);
 #endif
       ie += 4;
+#ifdef ISX_DIAG_MULT
+      // (north_star's "ballot/shuffle to coalesce same-bin writes", measured before it is built: of the lanes of a wave that add
+      //  to a bin in one ds_add_u32, how many name a bin that a LOWER lane of the same instruction names as well?
+      //  g_diag[8]: lanes that add 1, g_diag[9]: those of them that are not the first lane on their bin)
+      {
+        const bool hs[4] = {a0, a1, b0, b1};
+        for (int t = 0; t < 4; ++t) {
+          const uint32_t addr = (uint32_t)(uintptr_t)(bin + (uint32_t)t * row_bytes);
+          const unsigned long long hm = __ballot(hs[t]);
+          bool dup = false;
+          unsigned long long mm = hm;
+          while (mm) {
+            const int sl = __builtin_ctzll(mm);
+            mm &= mm - 1ull;
+            const uint32_t a2 = (uint32_t)__builtin_amdgcn_readlane((int)addr, sl);
+            if (hs[t] && sl < lane && a2 == addr) dup = true;
+          }
+          const int n_add = (int)__popcll(hm), n_dup = (int)__popcll(__ballot(dup));   // (ballots outside the macro's `if (lane == 0)`)
+          ISX_DIAG_ADD(8, n_add); ISX_DIAG_ADD(9, n_dup);
+        }
+      }
+#endif
+#if ISX_ATOM_BRANCH
+      // (variant: only the lanes that hit take part in the atomic -- fewer lanes in the LDS bank arbitration, four exec-mask branches)
+      if (a0) __hip_atomic_fetch_add(reinterpret_cast<LdsU32*>(bin), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      if (a1) __hip_atomic_fetch_add(reinterpret_cast<LdsU32*>(bin + row_bytes), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      if (b0) __hip_atomic_fetch_add(reinterpret_cast<LdsU32*>(bin + 2u * row_bytes), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      if (b1) __hip_atomic_fetch_add(reinterpret_cast<LdsU32*>(bin + 3u * row_bytes), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+#else
 #if ISX_ABL == 4
       if (a0 && a1 && b0 && b1 && band32 == 12345.f)
 #endif
@@ -1428,6 +1554,7 @@ __device__ __forceinline__ void consume_cols(const D& d, uint32_t* __restrict__ 
       __hip_atomic_fetch_add(reinterpret_cast<LdsU32*>(bin + 3u * row_bytes), b1 ? 1u : 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 #if ISX_ABL == 4
       }
+#endif
 #endif
       bin += 4u * row_bytes;
     }
@@ -1563,13 +1690,14 @@ __device__ __forceinline__ void push_cols(const D& d, uint32_t* __restrict__ his
 }
 
 // producer: the columns of the caps of a batch of 64 lines, packed over the lanes (owner search as in walk_lines_packed).
-// Called once per side of the lines: the two caps of a line that takes both passes never share a bin (caps_may_touch below).
+// Called once per pass of the batch: the two caps of a line that takes both cap passes never share a bin (caps_may_touch); `band`:
+// the lines of the pass are grazing lines (prep_band), the rows of a column are those of the cap AND the band.
 template <class D>
 __device__ __forceinline__ void produce_cols_packed(const D& d, uint32_t* __restrict__ hist, const double* __restrict__ rowt,
                                                     const ColX* __restrict__ colx, const RowX* __restrict__ rowx,
                                                     const double* __restrict__ lines, const SlotQueues& sq, const ColPre& pre,
                                                     int excl, int incl, int total, float inv_dth, int n_theta, int first_line,
-                                                    int lane, LdsInt* mark) {
+                                                    int lane, LdsInt* mark, const BandPre& bp, bool band) {
 #pragma unroll 1
   for (int base = 0; base < total; base += 64) {
     const int g = base + lane;
@@ -1592,9 +1720,19 @@ __device__ __forceinline__ void produce_cols_packed(const D& d, uint32_t* __rest
     int j = o_jlo + (g - o_excl);
     if (j >= d.n_phi) j -= d.n_phi;
     if (!have) j = 0;
-    int ilo = 0, cnt = 0;
-    if (have) cap_rows(fx, fy, a, cw, colx[j].c32, colx[j].s32, inv_dth, n_theta, ilo, cnt);
-    push_cols(d, hist, rowt, colx, rowx, lines, sq, first_line + owner, j, ilo, cnt, lane);
+    int ilo = 0, cnt = 0, ilo_b = 0, cnt_b = 0;
+    const float c32 = colx[j].c32, s32 = colx[j].s32;
+    if (have) cap_rows(fx, fy, a, cw, c32, s32, inv_dth, n_theta, ilo, cnt);
+    if (band) {
+      BandPre ob;
+      ob.ux = __shfl(bp.ux, owner, 64); ob.uy = __shfl(bp.uy, owner, 64); ob.uz = __shfl(bp.uz, owner, 64); ob.kap = __shfl(bp.kap, owner, 64);
+      const int r_lo = ilo, r_hi = ilo + cnt - 1;
+      band_rows(ob, c32, s32, inv_dth, r_lo, have ? r_hi : r_lo - 1, ilo, cnt, ilo_b, cnt_b);
+    }
+    const int npiece = (band && __ballot(cnt_b > 0) != 0ull) ? 2 : 1;
+#pragma unroll 1
+    for (int w = 0; w < npiece; ++w)
+      push_cols(d, hist, rowt, colx, rowx, lines, sq, first_line + owner, j, w == 0 ? ilo : ilo_b, w == 0 ? cnt : cnt_b, lane);
   }
 }
 
@@ -2401,9 +2539,11 @@ __device__ __forceinline__ void assist_body(const Geom& g_arg, const DetGrid& d_
         if (CH != 0 && r.tgt) return chord_arrive<true>(h, r, q);
         return next_hit_s1<false>(h, g, r.p, r.v, r.on, q);
       };
+      if (next == kDry) { ISX_TD_ADD(14, 1); ISX_TD_ADD(15, __popcll(__ballot(run))); }   // (-DISX_DIAG: trips after the launch's queue ran dry)
       {
         V3 q;
         bool arrived = false;
+        ISX_TD_ADD(4, __popcll(__ballot(run)));   // (-DISX_DIAG: lanes that attempt a bounce in this step)
         if (run) {
           const bool fresh = r.on == K_NONE && r.j == 0u && !r.scattered();
           if (fresh) {
@@ -2417,6 +2557,7 @@ __device__ __forceinline__ void assist_body(const Geom& g_arg, const DetGrid& d_
       static_steps<1, kStepsPerTrip>([&](auto rep) {
         V3 q;
         bool arrived = false;
+        ISX_TD_ADD(4, __popcll(__ballot(run)));
         if (run) {
           if (hot_search(q)) arrived = true;
           else { hand = true; run = false; }
@@ -2488,6 +2629,9 @@ __device__ __forceinline__ void assist_body(const Geom& g_arg, const DetGrid& d_
     // =============================================================== the assist wave
     uint32_t reg_slot = 0, reg_left = 0, reg_id = 0xffffffffu;       // cursor in the open region of exit lines (SINK_REC)
     uint32_t spins = 0, lazy = 0, beat_seen = 0;
+    // (-DISX_DIAG, g_diag[32..]: cycles [0] waiting for rays, [1] at work; [2] batches, [3] rays in them, [4] rays sent to the back
+    //  of the pending queue, [5] rays returned to the tracers, [6] rays that ended here)
+    ISX_TD_DECL;
     // one wave serves eleven: it goes first whenever it has something to do (its SIMD's five tracers take every other slot)
     __builtin_amdgcn_s_setprio(3);
     for (;;) {
@@ -2520,6 +2664,8 @@ __device__ __forceinline__ void assist_body(const Geom& g_arg, const DetGrid& d_
       spins = 0;
       if (lane == 0) __hip_atomic_fetch_add(&Q->beat, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
       const uint32_t take = n < 64u ? n : 64u;
+      ISX_TD_MARK(0);
+      ISX_TD_ADD(2, 1); ISX_TD_ADD(3, take);
       const bool have = (uint32_t)lane < take;
       Ray r;
       ray_start(g, r, 0);
@@ -2685,7 +2831,10 @@ __device__ __forceinline__ void assist_body(const Geom& g_arg, const DetGrid& d_
         if (lane == 0) add(&Q->resume_pub, cnt);
       }
       if (c_ended && lane == 0) __hip_atomic_fetch_sub(&Q->busy, c_ended, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+      ISX_TD_ADD(4, __popcll(__ballot(requeued))); ISX_TD_ADD(5, __popcll(bm)); ISX_TD_ADD(6, c_ended);
+      ISX_TD_MARK(1);
     }
+    ISX_TD_FLUSH_AT(32);
     if (lane == 0 && reg_id != 0xffffffffu) d_arg.rec_counts[reg_id] = kRegion - reg_left;
   }
 
@@ -3154,7 +3303,7 @@ isx_bin_cols_kernel(const DetGrid d_arg, const Work wk) {
     colx[b] = e;
   }
   if (tid == (nthr > 128 ? 128 : 0)) *d_lds = d_arg;
-  // per wave: the class queues, their 8 + 8 counters, 64 owner marks, 64 ints of long-row list for bin_culled
+  // per wave: the class queues, their 8 + 8 counters, 64 owner marks, the deferred list
   uint32_t* mine = wave_all + (size_t)(tid >> 6) * kColWaveWords;
   SlotQueues sq;
   sq.colp = nullptr;
@@ -3162,8 +3311,7 @@ isx_bin_cols_kernel(const DetGrid d_arg, const Work wk) {
   sq.tail = (LdsInt*)(mine + kClasses * kQueueCap);
   sq.head = sq.tail + 8;
   LdsInt* mrk = sq.head + 8;
-  LdsInt* spl = mrk + 64;
-  sq.defer = (LdsWord*)(spl + 64);
+  sq.defer = (LdsWord*)(mrk + 64);
   if (lane < 16) sq.tail[lane] = 0;
   sq.defer[2 * lane] = kDeferFree; sq.defer[2 * lane + 1] = kDeferFree;
   __syncthreads();
@@ -3189,23 +3337,26 @@ isx_bin_cols_kernel(const DetGrid d_arg, const Work wk) {
     for (uint32_t b0 = q_first; b0 < n_lines; b0 += 64u) {
       const bool have = b0 + (uint32_t)lane < n_lines;
       const int first_line = (int)(b0 - q_first);
-      // Nothing but wave-uniform masks (scalar registers) lives from one pass of the batch to the next: until round 4 the line
-      // (12 VGPRs), the first cap (7) and the wave-uniform binary32 constants of the preparation (gfx950 has no scalar float
-      // unit: VGPRs as well) were kept across the whole inlined consumer for the benefit of the second pass -- the kernel sits
-      // at its 128-VGPR limit, so they went to scratch and back, 60 bytes per lane and batch: 0.8 GB of HBM writes per
-      // 5e7-ray launch next to 129.6 KB of algorithmic output.  A pass now reads its lines (again: L2) and the constants (LDS)
-      // where it needs them, and the second pass no longer looks at the first cap (caps_may_touch).
-      unsigned long long second_m = 0ull;
+      // Three passes over the batch, one producer: the caps around the first piercing points (every line that has caps), the caps
+      // around the second piercing points (the few lines whose second cap reaches detector rows: 3 % of the headline's), cap AND
+      // band of the grazing lines (no caps; none in the headline, a third of the BRDF source's).
+      // Nothing but wave-uniform masks (scalar registers) lives from one pass to the next: until round 4 the line (12 VGPRs), the
+      // first cap (7) and the wave-uniform binary32 constants of the preparation (gfx950 has no scalar float unit: VGPRs as well)
+      // were kept across the whole inlined consumer for the benefit of the second pass -- the kernel sits at its 128-VGPR limit,
+      // so they went to scratch and back, 60 bytes per lane and batch: 0.8 GB of HBM writes per 5e7-ray launch next to 129.6 KB
+      // of algorithmic output.  A pass now reads its lines (again: L2) and the constants (LDS) where it needs them, and the
+      // second pass no longer looks at the first cap (caps_may_touch).
+      unsigned long long m_second = 0ull, m_band = 0ull;
 #pragma unroll 1
-      for (int side = 0; side < 2; ++side) {
-        if (side == 1 && second_m == 0ull) break;
-        // side 1: the few lines whose second piercing point lies low enough for its cap to reach detector rows (3 %)
-        const bool part = side == 0 ? have : (((second_m >> lane) & 1ull) != 0ull);
+      for (int pass = 0; pass < 3; ++pass) {
+        const unsigned long long pm = pass == 0 ? __ballot(have) : (pass == 1 ? m_second : m_band);
+        if (pm == 0ull) continue;
+        const bool part = ((pm >> lane) & 1ull) != 0ull;
         ColPre pre;
         pre.fx = pre.fy = pre.a = pre.cosw = 0.f; pre.jlo = 0; pre.ncol = 0; pre.kind = -2;
-        V3 lp, lv;
-        lp.x = lp.y = lp.z = 0.0; lv.x = lv.y = 0.0; lv.z = -1.0;
-        bool low2 = false;
+        BandPre bp;
+        bp.ux = bp.uy = bp.uz = 0.f; bp.kap = 2.f;
+        bool low2 = false, graze = false;
         if (part) {
           GridConst k;   // (volatile LDS reads: derived again here, never held across a pass)
           k.Rf = (float)d.R; k.rho = (float)d.rho_d; k.portz = (float)d.portz; k.n_theta = d.n_theta;
@@ -3213,30 +3364,28 @@ isx_bin_cols_kernel(const DetGrid d_arg, const Work wk) {
           k.inv_dth = 0.f;
           uint32_t li = (uint32_t)(first_line + lane);
           asm volatile("" : "+v"(li));   // (the address is formed here, not hoisted out of the batch loop and spilled)
+          V3 lp, lv;
           load_line(lines + 6 * li, lp, lv);
-          CapShared sh = prep_shared(k, lp, lv);
-          if (side == 0 && sh.kind == 0) {
-            low2 = cap_is_low(k, sh, lp, lv, 1);
-            if (low2 && caps_may_touch(k, sh)) { sh.kind = -1; low2 = false; }   // the whole line through the box windows
+          if (pass < 2) {
+            CapShared sh = prep_shared(k, lp, lv);
+            if (pass == 0 && sh.kind == 0) {
+              low2 = cap_is_low(k, sh, lp, lv, 1);
+              if (low2 && caps_may_touch(k, sh)) { sh.kind = -1; low2 = false; }   // the whole line as a grazing line
+            }
+            graze = sh.kind == -1;
+            pre = prep_cols(k, dcol.n_phi, lp, lv, sh, pass);
+          } else {
+            pre = prep_band(k, dcol.n_phi, lp, lv, bp);
           }
-          pre = prep_cols(k, dcol.n_phi, lp, lv, sh, side);
         }
-        if (side == 0) {
+        if (pass == 0) {
           ISX_BD_MARK(sq, 0);
-          { const int n_far = (int)__popcll(__ballot(have && pre.kind == -2)); (void)n_far; ISX_DIAG_ADD(3, n_far); }
-          // lines without caps (grazing lines; none in the headline): one at a time, lane = row, box windows
-          unsigned long long em = __ballot(have && pre.kind == -1);
-          while (em) {
-            const int src = __builtin_ctzll(em);
-            em &= em - 1ull;
-            V3 P, V;
-            P.x = readlane_f64(lp.x, src); P.y = readlane_f64(lp.y, src); P.z = readlane_f64(lp.z, src);
-            V.x = readlane_f64(lv.x, src); V.y = readlane_f64(lv.y, src); V.z = readlane_f64(lv.z, src);
-            bin_culled<false>(d, hist, rowt, colx, P, V, lane, spl);
-          }
-          second_m = __ballot(low2);
-          { const int n_fast = (int)__popcll(__ballot(have && pre.kind == 0 && pre.ncol > 0)); (void)n_fast; ISX_DIAG_ADD(0, n_fast); }
+          m_second = __ballot(low2);
+          m_band = __ballot(graze);
+          { const int n_fast = (int)__popcll(__ballot(part && pre.kind == 0 && pre.ncol > 0)); (void)n_fast; ISX_DIAG_ADD(0, n_fast); }
         }
+        if (pass == 2) { const int n_box = (int)__popcll(__ballot(part && pre.kind == 0)); (void)n_box; ISX_DIAG_ADD(2, n_box); }
+        { const int n_far = (int)__popcll(__ballot(part && pre.kind == -2)); (void)n_far; ISX_DIAG_ADD(3, n_far); }
         const int ncol = (part && pre.kind == 0) ? pre.ncol : 0;
         int incl = ncol;
 #pragma unroll
@@ -3245,11 +3394,12 @@ isx_bin_cols_kernel(const DetGrid d_arg, const Work wk) {
           if (lane >= dlt) incl += o;
         }
         const int total = __builtin_amdgcn_readlane(incl, 63);
+        if (total == 0) continue;
         ColPre pc = pre;
         pc.ncol = ncol;
         const int n_theta = d.n_theta;
         produce_cols_packed(dcol, hist, rowt, colx, rowx, lines, sq, pc, incl - ncol, incl, total, (float)n_theta * 0.63661977237f, n_theta,
-                            first_line, lane, mrk);
+                            first_line, lane, mrk, bp, pass == 2);
       }
       if (first_line == 64) flush_deferred(dcol, hist, rowt, colx, lines, sq, lane);   // half-way through the unit (and at its end)
     }

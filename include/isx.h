@@ -184,8 +184,8 @@ int isx_last_kernel_ms(double* single_ms, double* trace_ms, double* bin_ms);
  *                  0: round 2's kernels;
  *                  "assist_block" = their workgroup size (128..768, default 768 = 11 tracer waves + 1 assist wave)
  *   "bin_slots"    1 (default): binning kernels with slot queues by window length (grids up to 256 x 255); 0: round 2's
- *   "bin_cols"     1 (default): (line, COLUMN) slots for the pencil source, (line, row) slots for the BRDF source; 0: row slots
- *                  everywhere; 2: column slots everywhere
+ *   "bin_cols"     1 (default; 2 is accepted and means the same): (line, COLUMN) slots for every source -- caps of the lines that
+ *                  pass near the detector sphere's centre, cap-and-band windows for grazing lines; 0: (line, row) slots
  *   "bin_block", "bin_blocks_per_cu"  shape of round 2's binning kernel (0 workgroups per CU = what is resident)
  *   "ray_sub"      rays a wave takes off a launch's ray queue at a time (0 = default: 128)
  *   "overlap", "overlap_trace_streams"  cut a flux-map call into k chunks, binning of chunk i on a second stream while chunk

@@ -73,3 +73,36 @@ def test_box_windows_contain_every_hit():
         lp, d = bw.random_lines(c, 300, seed=n_theta)
         r = bw.check(c, lp, d)
         assert r["hits"] > 0 and r["missed"] == 0 and r["twice"] == 0, (n_theta, n_phi)
+
+
+def test_column_slots_contain_every_hit():
+    """The COLUMN-slot pre-selection of isx_bin_cols_kernel (caps of the lines that pass near O -- both of them for a line whose
+    second cap reaches detector rows, unless they could touch --, cap AND band for grazing lines; restated in float32 numpy in
+    tests/bandwin_np.py) against the exact test on all bins: no hit outside the rows its column was given, no bin handed out
+    twice for one line.  Exit lines of the headline, of a wide port and of the BRDF source from the oracle, random lines incl. the
+    degenerate families, coarse grids (where row ranges are widest), detectors from 2 % to 150 % of their sphere's radius."""
+    import bandwin_np as bw
+    import boxwin_np as bx
+    import oracle as orc
+    c, lp, d = bx.lines_for("brdf", 400)
+    r = bw.check(c, lp, d)
+    assert r["lines"] > 300 and r["missed"] == 0 and r["twice"] == 0
+    assert r["by_kind"]["band"]["lines"] > 80 and r["by_kind"]["band"]["candidates"] < 4.5 * r["by_kind"]["band"]["hits"]
+    for kind in ("headline", "wide"):
+        c, lp, d = bx.lines_for(kind, 400)
+        r = bw.check(c, lp, d)
+        assert r["lines"] > 100 and r["missed"] == 0 and r["twice"] == 0
+        assert r["candidates"] < 1.8 * r["hits"]
+    rng = np.random.default_rng(11)
+    for n_theta, n_phi, diam, dist in ((180, 90, 40.0, 100.0), (45, 20, 10.0, 100.0), (60, 120, 4.0, 150.0), (7, 3, 60.0, 80.0), (1, 1, 40.0, 100.0),
+                                       (2, 3, 30.0, 25.0), (3, 2, 12.0, 8.0), (5, 9, 150.0, 100.0), (17, 4, 90.0, 100.0), (90, 36, 6.0, 12.0)):
+        c = orc.default_config()
+        c.n_theta, c.n_phi, c.det_diameter, c.det_distance = n_theta, n_phi, diam, dist
+        lp, d = bx.random_lines(c, 200, seed=n_theta + n_phi)
+        # ... and lines aimed through the neighbourhood of O, where lines have two low caps
+        m = 150
+        tgt = np.array([0.0, 0.0, c.exit_port_z]) + rng.standard_normal((m, 3)) * dist * 0.4
+        V = rng.standard_normal((m, 3)); V /= np.linalg.norm(V, axis=1)[:, None]
+        lp = np.concatenate([lp, tgt - 120.0 * V]); d = np.concatenate([d, V])
+        r = bw.check(c, lp, d)
+        assert r["hits"] > 0 and r["missed"] == 0 and r["twice"] == 0, (n_theta, n_phi, diam, dist)

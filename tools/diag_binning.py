@@ -8,7 +8,7 @@ L = isx.load(); isx.init(0)
 if os.environ.get('ISX_PIPELINE'): isx.set_option('pipeline', int(os.environ['ISX_PIPELINE']))
 L.isx_diag_read.argtypes = [C.POINTER(C.c_uint64)]
 def diag():
-    a = (C.c_uint64 * 32)()
+    a = (C.c_uint64 * 48)()
     assert L.isx_diag_read(a) == 0
     return np.array(a[:32], dtype=np.uint64)
 def run(name, c, n):

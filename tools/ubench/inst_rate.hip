@@ -9,6 +9,9 @@ __global__ void k(double* out, unsigned long long* cyc, double seed) {
   double a0 = seed + threadIdx.x, a1 = a0 + 1, a2 = a0 + 2, a3 = a0 + 3, a4 = a0 + 4, a5 = a0 + 5, a6 = a0 + 6, a7 = a0 + 7;
   uint32_t u0 = threadIdx.x + 7, u1 = u0 * 3, u2 = u0 * 5, u3 = u0 * 7;
   float f0 = a0, f1 = a1, f2 = a2, f3 = a3;
+  typedef float f2v __attribute__((ext_vector_type(2)));
+  f2v p0 = {f0, f1}, p1 = {f1, f2}, p2 = {f2, f3}, p3 = {f3, f0};
+  const f2v pc = {1.0000001f, 0.9999999f}, pe = {0.5f, 0.25f};
   const double c = 1.0000001, e = 0.9999999;
   unsigned long long t0 = __builtin_amdgcn_s_memtime();
   for (int i = 0; i < N_IT; ++i) {
@@ -22,10 +25,13 @@ __global__ void k(double* out, unsigned long long* cyc, double seed) {
     if (OP == 6) { f0 = fmaf(f0, 1.0000001f, 0.5f); f1 = fmaf(f1, 1.0000001f, 0.5f); f2 = fmaf(f2, 1.0000001f, 0.5f); f3 = fmaf(f3, 1.0000001f, 0.5f); a0 = a0; }
     if (OP == 7) { a0 = __builtin_amdgcn_rcp(a0) + 2.0; a1 = __builtin_amdgcn_rcp(a1) + 2.0; a2 = __builtin_amdgcn_rcp(a2) + 2.0; a3 = __builtin_amdgcn_rcp(a3) + 2.0; }
     if (OP == 8) { u0 = u0 * 0xD2511F53u + 1; u1 = u1 * 0xCD9E8D57u + 1; u2 = u2 * 0xD2511F53u + 1; u3 = u3 * 0xCD9E8D57u + 1; }
+    if (OP == 10) { p0 = __builtin_elementwise_fma(p0, pc, pe); p1 = __builtin_elementwise_fma(p1, pc, pe); p2 = __builtin_elementwise_fma(p2, pc, pe); p3 = __builtin_elementwise_fma(p3, pc, pe); }
+    if (OP == 11) { p0 = p0 * pc; p1 = p1 * pc; p2 = p2 * pc; p3 = p3 * pc; }
+    if (OP == 12) { u0 = (f0 < f1) ? u1 : u0 + 1; u1 = (f1 < f2) ? u2 : u1 + 1; u2 = (f2 < f3) ? u3 : u2 + 1; u3 = (f3 < f0) ? u0 : u3 + 1; }
     if (OP == 9) { u0 = (u0 ^ u1) + 0x9E3779B9u; u1 = (u1 ^ u2) + 0x9E3779B9u; u2 = (u2 ^ u3) + 0x9E3779B9u; u3 = (u3 ^ u0) + 0x9E3779B9u; }
   }
   unsigned long long t1 = __builtin_amdgcn_s_memtime();
-  out[blockIdx.x * blockDim.x + threadIdx.x] = a0 + a1 + a2 + a3 + a4 + a5 + a6 + a7 + u0 + u1 + u2 + u3 + f0 + f1 + f2 + f3;
+  out[blockIdx.x * blockDim.x + threadIdx.x] = a0 + a1 + a2 + a3 + a4 + a5 + a6 + a7 + u0 + u1 + u2 + u3 + f0 + f1 + f2 + f3 + p0.x + p0.y + p1.x + p1.y + p2.x + p2.y + p3.x + p3.y;
   if (threadIdx.x == 0) cyc[blockIdx.x] = t1 - t0;
 }
 template <int OP> void run(const char* name, int per_iter, int waves_per_simd) {
@@ -54,6 +60,7 @@ int main() {
     run<0>("v_fma_f64", 8, w); run<1>("v_mul_f64", 8, w); run<2>("v_add_f64", 8, w);
     run<3>("u64=u32*u32 (+xor)", 4, w); run<8>("u32 mul+add", 4, w); run<9>("u32 xor+add", 4, w);
     run<4>("sqrt f64 (IEEE) + add", 4, w); run<5>("div f64 (IEEE) + add", 4, w); run<7>("v_rcp_f64 + add", 4, w); run<6>("v_fma_f32", 4, w);
+    run<10>("v_pk_fma_f32", 4, w); run<11>("v_pk_mul_f32", 4, w); run<12>("v_cmp_f32+cndmask+add (3)", 4, w);
   }
   return 0;
 }
