@@ -484,7 +484,7 @@ __device__ __forceinline__ void walk_columns(const D& d, uint32_t* __restrict__ 
 // four forms and g of BOTH candidates are packed binary32 operations -- the same expressions in the same order as walk_columns,
 // hence the same error bound and band -- 12 v_pk instructions for two candidates where one at a time took 4 + 5 each.  The second
 // candidate of the last step of an odd window is masked.  Tiers 2 and 3 as in walk_columns, for whichever of the two needs them.
-constexpr int kDeferCapW = 124;   // (the deferred list of a wave: 128 words, two entries per lane)
+constexpr int kDeferCapW = 252;   // (the deferred list of a wave: 256 words -- count, three spare, 252 entries)
 // Tiers 2 and 3 of the decision for candidate (row ir, column jr) of the line at src6 (walk_columns: binary64 about the original point
 // with its 2.1e-9 band, then the reference's own test from the detector table).
 template <class D>
@@ -965,33 +965,37 @@ __device__ __forceinline__ int slot_class(int cnt) {   // cnt in 1..kLongest
   return cnt <= 4 ? 0 : (cnt <= 12 ? (cnt - 3) >> 1 : (cnt <= 16 ? 5 : 6));
 }
 
-// The candidates a wave has put aside for tiers 2 and 3 (consume_cols): every lane owns two entries of the wave's deferred list
-// (0xffffffff = free), fills them as its walks meet candidates that tier 1 cannot decide -- a plain LDS write, nothing to wait
-// for -- and here, twice per unit, the wave decides them: lane = candidate, one line fetch and one exact decision per lane with
-// the whole wave at it, instead of one lane of a diverged wave waiting for its line to come back from L2 while the other 63
-// stand still (the ablation without tiers 2 and 3 runs 1.16 of 6.9 ms shorter, for 8e-4 of the candidates).
+// The candidates a wave has put aside for tiers 2 and 3 (consume_cols).  A walk that meets a candidate tier 1 cannot decide appends
+// it to the wave's deferred list -- one LDS atomic for the position, one write; the candidate counts as a miss in the walk -- and
+// here the wave decides what has collected, lane = candidate, 64 at a time: one line fetch and one exact decision per lane with
+// the whole wave at it, instead of one lane of a diverged wave waiting for its line to come back from L2 while the other 63 stand
+// still (the ablation without tiers 2 and 3 runs 1.16 of 6.9 ms shorter on the headline, for 8e-4 of its candidates; the grazing
+// lines of the BRDF source send 6e-3 of theirs this way -- their forms are seven times worse conditioned -- which is why the list is
+// a DENSE append list, flushed whenever 64 have collected, since round 4: with two entries per lane, flushed twice per unit, four in
+// five of that source's undecided candidates found their lane's entries taken and were decided on the spot).
 // Entry: line within the unit | column << 8 | row << 16.  A hit goes to the bin; the walk added 0 for the candidate.
-constexpr uint32_t kDeferFree = 0xffffffffu;
+constexpr uint32_t kDeferFlushAt = 64;
 template <class D>
 __device__ __forceinline__ void flush_deferred(const D& d, uint32_t* __restrict__ hist, const double* __restrict__ rowt,
                                                const ColX* __restrict__ colx, const double* __restrict__ lines, const SlotQueues& sq,
                                                int lane) {
   volatile LdsWord* df = sq.defer;
   typedef __attribute__((address_space(3))) uint32_t LdsU32;
+  const uint32_t held = df[0];                                        // (same address in every lane: wave-uniform; it keeps counting past the capacity)
+  const uint32_t n = held < (uint32_t)kDeferCap ? held : (uint32_t)kDeferCap;
 #pragma unroll 1
-  for (int k = 0; k < 2; ++k) {
-    const uint32_t e = df[2 * lane + k];
-    const bool have = e != kDeferFree;
-    if (__ballot(have) == 0ull) continue;
+  for (uint32_t base = 0; base < n; base += 64u) {
+    const bool have = base + (uint32_t)lane < n;
+    const uint32_t e = have ? df[4u + base + (uint32_t)lane] : 0u;
     const int line = (int)(e & 255u), jr = (int)((e >> 8) & 255u), ir = (int)((e >> 16) & 255u);
     bool hit = false;
-    if (have) {
-      hit = decide_exact(d, rowt, colx, lines + 6 * line, ir, jr);
-      df[2 * lane + k] = kDeferFree;
-    }
+    if (have) hit = decide_exact(d, rowt, colx, lines + 6 * line, ir, jr);
     if (hit) __hip_atomic_fetch_add(reinterpret_cast<LdsU32*>((__attribute__((address_space(3))) void*)hist) + (ir * d.n_phi + jr), 1u,
                                     __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
   }
+  __builtin_amdgcn_wave_barrier();
+  if (lane == 0) df[0] = 0u;
+  __builtin_amdgcn_wave_barrier();
 }
 
 // one pass: 64 slots (fewer when a unit's leftovers are flushed), lane = slot
@@ -1434,11 +1438,6 @@ __device__ __forceinline__ void consume_cols(const D& d, uint32_t* __restrict__ 
   // (the row table as two arrays -- {S_i, S_i+1, C_i, C_i+1} at 16 bytes per row, {T_i, T_i+1} at 8 -- instead of one 32-byte
   //  entry: a 16-byte read then spreads over sixteen bank groups instead of eight, and the ablation that reads one entry for
   //  all lanes says that bank conflicts of these reads cost 1.1 of the kernel's 7.0 ms)
-  uint32_t dcnt;   // this lane's entries of the deferred list that are taken
-  {
-    const uint32_t e0 = ((volatile LdsWord*)sq.defer)[2 * lane], e1 = ((volatile LdsWord*)sq.defer)[2 * lane + 1];
-    dcnt = (e0 != kDeferFree ? 1u : 0u) + (e1 != kDeferFree ? 1u : 0u);   // (filled in order: entry 1 is never taken alone)
-  }
   const float4* rowA = reinterpret_cast<const float4*>(rowx);
   const float2* rowB = reinterpret_cast<const float2*>(rowA + (d.n_theta + 4));
   auto classify = [&](int ie, int kk, bool& h0, bool& h1) {
@@ -1453,10 +1452,10 @@ __device__ __forceinline__ void consume_cols(const D& d, uint32_t* __restrict__ 
     const isx_f2 g = __builtin_elementwise_fma(dot, __builtin_elementwise_fma(dot, ddw, num * mdv), num * num);
     bool hit0 = g.x < 0.f, hit1 = g.y < 0.f;
     if (one && !(fminf(fabsf(g.x), fabsf(g.y)) > band32)) {
-      // What tier 1 cannot decide waits in the lane's two entries of the wave's deferred list (flush_deferred) and counts as a
-      // miss here; if both are taken -- a slot whose band is infinite sends every candidate this way -- it is decided on the
-      // spot.  (One list per wave with positions from an LDS atomic: 6.42 ms, the lane waits for the atomic's return; with
-      // positions from a wave-uniform count, ballot + mbcnt: 6.77 -- two more compares and ballots in EVERY step.)
+      // What tier 1 cannot decide is appended to the wave's deferred list (flush_deferred) and counts as a miss here; if the list
+      // is full -- a slot whose band is infinite sends every candidate this way -- it is decided on the spot.  (Positions from a
+      // wave-uniform count, ballot + mbcnt, instead of the LDS atomic: 6.77 against 6.42 ms -- two more compares and ballots in
+      // EVERY step.)
 #pragma unroll 1
       for (int t = 0; t < 2; ++t) {
         const float gt = t == 0 ? g.x : g.y;
@@ -1467,14 +1466,14 @@ __device__ __forceinline__ void consume_cols(const D& d, uint32_t* __restrict__ 
         int ir = ilo + kk + t;
         asm volatile("" : "+v"(ir));
         bool hit = false;
+        typedef __attribute__((address_space(3))) uint32_t LdsCnt;
 #if defined(ISX_DIAG) && !defined(ISX_DIAG_TIMING_ONLY)
-        const bool room = false;   // (the tuning build re-decides every candidate right here: nothing is put aside)
+        const uint32_t pos = (uint32_t)kDeferCap;   // (the tuning build re-decides every candidate right here: nothing is put aside)
 #else
-        const bool room = dcnt < 2u;
+        const uint32_t pos = __hip_atomic_fetch_add(reinterpret_cast<LdsCnt*>(sq.defer), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 #endif
-        if (room) {
-          ((volatile LdsWord*)sq.defer)[2 * lane + (int)dcnt] = (uint32_t)line | ((uint32_t)j << 8) | ((uint32_t)ir << 16);
-          dcnt += 1u;
+        if (pos < (uint32_t)kDeferCap) {
+          ((volatile LdsWord*)sq.defer)[4u + pos] = (uint32_t)line | ((uint32_t)j << 8) | ((uint32_t)ir << 16);
         } else {
           int jr = j;
           asm volatile("" : "+v"(jr));
@@ -3313,7 +3312,7 @@ isx_bin_cols_kernel(const DetGrid d_arg, const Work wk) {
   LdsInt* mrk = sq.head + 8;
   sq.defer = (LdsWord*)(mrk + 64);
   if (lane < 16) sq.tail[lane] = 0;
-  sq.defer[2 * lane] = kDeferFree; sq.defer[2 * lane + 1] = kDeferFree;
+  if (lane == 0) sq.defer[0] = 0u;
   __syncthreads();
   typedef __attribute__((address_space(3))) DetGrid LdsDetGrid;
   const volatile LdsDetGrid& d = *(const volatile LdsDetGrid*)d_lds;
@@ -3401,7 +3400,8 @@ isx_bin_cols_kernel(const DetGrid d_arg, const Work wk) {
         produce_cols_packed(dcol, hist, rowt, colx, rowx, lines, sq, pc, incl - ncol, incl, total, (float)n_theta * 0.63661977237f, n_theta,
                             first_line, lane, mrk, bp, pass == 2);
       }
-      if (first_line == 64) flush_deferred(dcol, hist, rowt, colx, lines, sq, lane);   // half-way through the unit (and at its end)
+      // what the walks of this batch put aside for tiers 2 and 3: decided as soon as a wave-full has collected (and at the unit's end)
+      if (((volatile LdsWord*)sq.defer)[0] >= kDeferFlushAt) flush_deferred(dcol, hist, rowt, colx, lines, sq, lane);
     }
     drain_cols(dcol, hist, rowt, colx, rowx, lines, sq, 1, lane);   // the unit's leftovers, class by class
     flush_deferred(dcol, hist, rowt, colx, lines, sq, lane);        // ... and what its walks put aside for tiers 2 and 3
