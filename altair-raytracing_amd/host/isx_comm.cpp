@@ -8,6 +8,7 @@
 #include <sys/stat.h>
 #include <unistd.h>
 
+#include <algorithm>
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -298,21 +299,35 @@ bool rccl_init(const Comm& c) {
   return true;
 }
 
-// RCCL transport: one staging buffer on the device, three in-place all-reduces on one stream, one synchronisation
+// RCCL transport: ONE in-place ncclAllReduce(ncclSum, ncclUint64) per call on one stream, one synchronisation ("a
+// single all-reduce of the histogram").  Everything that is not a sum travels as per-rank slots of the SUM buffer (see
+// reduce_collective): a slot is written by one rank and zero on all others, so its sum is that rank's value.
 struct RcclTransport : Transport {
-  bool exchange(unsigned long long* buf, size_t n_sum, size_t n_max, size_t n_min) override {
-    const size_t total = n_sum + n_max + n_min;
+  bool reserve(size_t total) {
     if (total > R.cap) {
       if (R.d_buf) ISX_HIP_OK(hipFree(R.d_buf));
       R.d_buf = nullptr; R.cap = 0;
       ISX_HIP_OK(hipMalloc(&R.d_buf, total * sizeof(unsigned long long)));
       R.cap = total;
     }
-    ISX_HIP_OK(hipMemcpyAsync(R.d_buf, buf, total * sizeof(unsigned long long), hipMemcpyHostToDevice, R.stream));
-    if (n_sum) ISX_NCCL_OK(ncclAllReduce(R.d_buf, R.d_buf, n_sum, ncclUint64, ncclSum, R.comm, R.stream));
-    if (n_max) ISX_NCCL_OK(ncclAllReduce(R.d_buf + n_sum, R.d_buf + n_sum, n_max, ncclUint64, ncclMax, R.comm, R.stream));
-    if (n_min) ISX_NCCL_OK(ncclAllReduce(R.d_buf + n_sum + n_max, R.d_buf + n_sum + n_max, n_min, ncclInt64, ncclMin, R.comm, R.stream));
-    ISX_HIP_OK(hipMemcpyAsync(buf, R.d_buf, total * sizeof(unsigned long long), hipMemcpyDeviceToHost, R.stream));
+    return true;
+  }
+  bool exchange_sum(unsigned long long* buf, size_t n) override {
+    if (!reserve(n)) return false;
+    ISX_HIP_OK(hipMemcpyAsync(R.d_buf, buf, n * sizeof(unsigned long long), hipMemcpyHostToDevice, R.stream));
+    ISX_NCCL_OK(ncclAllReduce(R.d_buf, R.d_buf, n, ncclUint64, ncclSum, R.comm, R.stream));
+    ISX_HIP_OK(hipMemcpyAsync(buf, R.d_buf, n * sizeof(unsigned long long), hipMemcpyDeviceToHost, R.stream));
+    ISX_HIP_OK(hipStreamSynchronize(R.stream));
+    return true;
+  }
+  // the first n_dev words are already in R.d_buf (the histogram, written there by the kernels: no D2H -> H2D round trip of the
+  // 130 KB before the collective); the tail comes from the host.  The whole reduced buffer goes back to `buf`.
+  bool exchange_sum_device_head(unsigned long long* buf, size_t n_dev, size_t n) {
+    if (n > R.cap) return false;   // (device_hist() reserved it)
+    if (n > n_dev)
+      ISX_HIP_OK(hipMemcpyAsync(R.d_buf + n_dev, buf + n_dev, (n - n_dev) * sizeof(unsigned long long), hipMemcpyHostToDevice, R.stream));
+    ISX_NCCL_OK(ncclAllReduce(R.d_buf, R.d_buf, n, ncclUint64, ncclSum, R.comm, R.stream));
+    ISX_HIP_OK(hipMemcpyAsync(buf, R.d_buf, n * sizeof(unsigned long long), hipMemcpyDeviceToHost, R.stream));
     ISX_HIP_OK(hipStreamSynchronize(R.stream));
     return true;
   }
@@ -320,37 +335,56 @@ struct RcclTransport : Transport {
 
 Transport* g_transport_override = nullptr;
 
+// words of the SUM buffer behind the histogram: census (7 per statistics block), kernel time (one slot per rank and block),
+// status (one slot per rank)
+size_t tail_words(size_t ns, int world) { return 7 * ns + ns * (size_t)world + (size_t)world; }
+
+void pack_tail(unsigned long long* tail, int rank, int world, int local_rc, const isx_stats* st, size_t ns) {
+  std::memset(tail, 0, tail_words(ns, world) * sizeof(unsigned long long));
+  if (local_rc == ISX_OK) {
+    for (size_t k = 0; k < ns; ++k) {
+      unsigned long long* c = tail + 7 * k;
+      c[0] = st[k].launched; c[1] = st[k].exited; c[2] = st[k].counted_below_z; c[3] = st[k].absorbed;
+      c[4] = st[k].suspended; c[5] = st[k].bin_increments; c[6] = st[k].wall_hits;
+      tail[7 * ns + k * (size_t)world + (size_t)rank] = (unsigned long long)(st[k].t_kernel_ms * 1e3 + 0.5);
+    }
+  }
+  // status: ISX_OK = 0, errors are negative -> the slot carries -rc; the job-wide status is the worst (most negative) one
+  tail[7 * ns + ns * (size_t)world + (size_t)rank] = (unsigned long long)(-(long long)local_rc);
+}
+
+int unpack_tail(const unsigned long long* tail, int world, isx_stats* st, size_t ns) {
+  unsigned long long worst = 0;
+  for (int r = 0; r < world; ++r) worst = std::max(worst, tail[7 * ns + ns * (size_t)world + (size_t)r]);
+  if (worst != 0) return -(int)worst;
+  for (size_t k = 0; k < ns; ++k) {
+    const unsigned long long* c = tail + 7 * k;
+    st[k].launched = c[0]; st[k].exited = c[1]; st[k].counted_below_z = c[2]; st[k].absorbed = c[3];
+    st[k].suspended = c[4]; st[k].bin_increments = c[5]; st[k].wall_hits = c[6];
+    unsigned long long t = 0;
+    for (int r = 0; r < world; ++r) t = std::max(t, tail[7 * ns + k * (size_t)world + (size_t)r]);
+    st[k].t_kernel_ms = (double)t * 1e-3;
+  }
+  return ISX_OK;
+}
+
 }  // namespace
 
 // ------------------------------------------------------------------------------------------------ the collective
-// Every rank calls this exactly once per trace call, WHATEVER its local status: the status travels with the data
-// (MIN over ranks: ISX_OK = 0, errors are negative), so either every rank gets the reduced result or every rank gets
-// the same error -- no rank is left waiting in a collective the others never enter.
-int reduce_collective(Transport& t, int local_rc, uint64_t* hits, size_t count, isx_stats* st, int n_stats) {
+// Every rank calls this exactly once per trace call, WHATEVER its local status: the status travels with the data, so either
+// every rank gets the reduced result or every rank gets the same error -- no rank is left waiting in a collective the others
+// never enter.  ONE sum: buffer = [hits | census words | kernel time: one slot per rank | status: one slot per rank]; a rank
+// that failed contributes zeros and its error code.
+int reduce_collective(Transport& t, int rank, int world, int local_rc, uint64_t* hits, size_t count, isx_stats* st, int n_stats) {
   const size_t ns = st ? (size_t)n_stats : 0;
-  const size_t n_sum = count + 7 * ns, n_max = ns, n_min = 1;
-  std::vector<unsigned long long> h(n_sum + n_max + n_min, 0ull);
-  if (local_rc == ISX_OK) {
-    std::memcpy(h.data(), hits, count * sizeof(uint64_t));
-    for (size_t k = 0; k < ns; ++k) {
-      unsigned long long* c = h.data() + count + 7 * k;
-      c[0] = st[k].launched; c[1] = st[k].exited; c[2] = st[k].counted_below_z; c[3] = st[k].absorbed;
-      c[4] = st[k].suspended; c[5] = st[k].bin_increments; c[6] = st[k].wall_hits;
-      h[n_sum + k] = (unsigned long long)(st[k].t_kernel_ms * 1e3 + 0.5);
-    }
-  }
-  long long status = (long long)local_rc;
-  std::memcpy(&h[n_sum + n_max], &status, sizeof(status));
-  if (!t.exchange(h.data(), n_sum, n_max, n_min)) return local_rc != ISX_OK ? local_rc : ISX_ERR_HIP;
-  std::memcpy(&status, &h[n_sum + n_max], sizeof(status));
-  if (status != ISX_OK) return (int)status;
+  if (world < 1 || rank < 0 || rank >= world) return ISX_ERR_BAD_ARG;
+  std::vector<unsigned long long> h(count + tail_words(ns, world), 0ull);
+  if (local_rc == ISX_OK) std::memcpy(h.data(), hits, count * sizeof(uint64_t));
+  pack_tail(h.data() + count, rank, world, local_rc, st, ns);
+  if (!t.exchange_sum(h.data(), h.size())) return local_rc != ISX_OK ? local_rc : ISX_ERR_HIP;
+  const int rc = unpack_tail(h.data() + count, world, st, ns);
+  if (rc != ISX_OK) return rc;
   std::memcpy(hits, h.data(), count * sizeof(uint64_t));
-  for (size_t k = 0; k < ns; ++k) {
-    const unsigned long long* c = h.data() + count + 7 * k;
-    st[k].launched = c[0]; st[k].exited = c[1]; st[k].counted_below_z = c[2]; st[k].absorbed = c[3];
-    st[k].suspended = c[4]; st[k].bin_increments = c[5]; st[k].wall_hits = c[6];
-    st[k].t_kernel_ms = (double)h[n_sum + k] * 1e-3;
-  }
   return ISX_OK;
 }
 
@@ -382,9 +416,35 @@ void Comm::set_transport_for_tests(Transport* t) { g_transport_override = t; }
 
 int Comm::reduce(int local_rc, uint64_t* hits, size_t count, isx_stats* st, int n_stats) {
   if (!active()) return local_rc;
-  if (g_transport_override) return reduce_collective(*g_transport_override, local_rc, hits, count, st, n_stats);
+  if (g_transport_override) return reduce_collective(*g_transport_override, rank, world, local_rc, hits, count, st, n_stats);
   if (!rccl_init(*this)) return local_rc != ISX_OK ? local_rc : ISX_ERR_HIP;
-  return reduce_collective(g_rccl, local_rc, hits, count, st, n_stats);
+  return reduce_collective(g_rccl, rank, world, local_rc, hits, count, st, n_stats);
+}
+
+// The histogram of a sharded flux-map call can stay on the device until the collective: device_hist() hands out (and zeroes) the
+// head of the collective's own buffer, the kernels accumulate into it (isx_fluxmap_device), reduce_device_hist() appends census,
+// time and status and runs the ONE all-reduce in place.  nullptr: no RCCL on this rank (a transport double is installed, or the
+// communicator could not be built) -- the caller takes the host path, whose collective then reports the failure.
+unsigned long long* Comm::device_hist(size_t count, int n_stats) {
+  if (!active() || g_transport_override) return nullptr;
+  if (!rccl_init(*this)) return nullptr;
+  if (!g_rccl.reserve(count + tail_words((size_t)n_stats, world))) return nullptr;
+  if (hipMemsetAsync(R.d_buf, 0, count * sizeof(unsigned long long), R.stream) != hipSuccess) return nullptr;
+  if (hipStreamSynchronize(R.stream) != hipSuccess) return nullptr;   // (the kernels run on libisx's own stream)
+  return R.d_buf;
+}
+
+int Comm::reduce_device_hist(int local_rc, uint64_t* hits, size_t count, isx_stats* st, int n_stats) {
+  const size_t ns = st ? (size_t)n_stats : 0;
+  std::vector<unsigned long long> h(count + tail_words(ns, world), 0ull);
+  pack_tail(h.data() + count, rank, world, local_rc, st, ns);
+  if (local_rc != ISX_OK && hipMemsetAsync(R.d_buf, 0, count * sizeof(unsigned long long), R.stream) != hipSuccess)
+    return local_rc;   // (a failed rank contributes zeros)
+  if (!g_rccl.exchange_sum_device_head(h.data(), count, h.size())) return local_rc != ISX_OK ? local_rc : ISX_ERR_HIP;
+  const int rc = unpack_tail(h.data() + count, world, st, ns);
+  if (rc != ISX_OK) return rc;
+  std::memcpy(hits, h.data(), count * sizeof(uint64_t));
+  return ISX_OK;
 }
 
 bool Comm::agree(bool local_ok) {
@@ -427,8 +487,18 @@ int fluxmap_all(const isx_config* cfg, uint64_t n_rays, uint64_t seed, uint64_t 
   uint64_t f, cnt;
   c.shard(n_rays, f, cnt);
   isx_stats local{};
-  int rc = isx_fluxmap(cfg, cnt, seed, first_ray + f, hits, &local);
-  rc = c.reduce(rc, hits, grid_bins(cfg), &local);
+  int rc;
+  if (unsigned long long* d_hist = grid_bins(cfg) ? c.device_hist(grid_bins(cfg), 1) : nullptr) {
+    // the histogram stays on the device: kernels -> the collective's buffer -> ONE all-reduce -> host
+    rc = isx_take_stats(nullptr);                                     // (census of anything enqueued earlier must not leak into this call)
+    if (rc == ISX_OK) rc = isx_fluxmap_device(cfg, cnt, seed, first_ray + f, (uint64_t*)d_hist);
+    const int rc2 = isx_take_stats(&local);                           // synchronises libisx's stream
+    if (rc == ISX_OK) rc = rc2;
+    rc = c.reduce_device_hist(rc, hits, grid_bins(cfg), &local, 1);
+  } else {
+    rc = isx_fluxmap(cfg, cnt, seed, first_ray + f, hits, &local);
+    rc = c.reduce(rc, hits, grid_bins(cfg), &local);
+  }
   if (rc == ISX_OK && st) *st = local;
   return rc;
 }

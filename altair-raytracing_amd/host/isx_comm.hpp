@@ -13,7 +13,7 @@
 // magic word and the job tag and is verified on read; before anybody enters ncclCommInitRank every rank reports whether
 // it could bind its GPU (ready.<rank> / fail.<rank>), so one broken rank stops the job instead of hanging it.
 //
-// Failure semantics: every *_all() call ends in ONE collective that also carries the local status (MIN over ranks), so
+// Failure semantics: every *_all() call ends in ONE collective (one ncclAllReduce) that also carries the local status, so
 // either every rank returns the reduced result or every rank returns the same error; Comm::agree() is the same for
 // conditions checked on one rank only (the output file of the writer rank).
 #pragma once
@@ -24,15 +24,16 @@
 
 namespace isxhost {
 
-// What the collective needs from the wire: in place, buf = [n_sum words summed | n_max words max'ed (both uint64) |
-// n_min words min'ed as int64].  RCCL in production; tests install an in-process double (tests/comm_stub_test.cpp).
+// What the collective needs from the wire: ONE in-place sum of n uint64 words over all ranks.  RCCL in production
+// (ncclAllReduce, ncclSum); tests install an in-process double (tests/native/comm_stub_test.cpp).
 struct Transport {
-  virtual bool exchange(unsigned long long* buf, size_t n_sum, size_t n_max, size_t n_min) = 0;
+  virtual bool exchange_sum(unsigned long long* buf, size_t n) = 0;
   virtual ~Transport() {}
 };
-// The collective itself (transport-independent): sums hits[count] and the census words of st[n_stats], takes the MAX of
-// the kernel times and the MIN of the status.  Returns the job-wide status; outputs are written only if it is ISX_OK.
-int reduce_collective(Transport& t, int local_rc, uint64_t* hits, size_t count, isx_stats* st, int n_stats);
+// The collective itself (transport-independent), ONE sum per call: hits[count] and the census words of st[n_stats] are summed;
+// the kernel times and the status travel as per-rank slots of the same buffer (written by one rank, zero on the others), from
+// which every rank takes the MAX time and the worst status.  Returns the job-wide status; outputs are written only if it is ISX_OK.
+int reduce_collective(Transport& t, int rank, int world, int local_rc, uint64_t* hits, size_t count, isx_stats* st, int n_stats);
 
 struct Comm {
   int rank = 0, world = 1, local_rank = 0;
@@ -44,6 +45,10 @@ struct Comm {
   // called by EVERY rank with its local status: in-place SUM of hits[count] and of the census in *st over all ranks
   // (t_kernel_ms: MAX); returns the job-wide status (the worst local one)
   int reduce(int local_rc, uint64_t* hits, size_t count, isx_stats* st, int n_stats = 1);
+  // the same with the histogram still on the device (RCCL only): device_hist() = zeroed device buffer of `count` words for the
+  // kernels to accumulate into (nullptr: take the host path), reduce_device_hist() = the collective on it, result in hits[count]
+  unsigned long long* device_hist(size_t count, int n_stats);
+  int reduce_device_hist(int local_rc, uint64_t* hits, size_t count, isx_stats* st, int n_stats);
   // true on every rank iff local_ok on every rank (collective)
   bool agree(bool local_ok);
   void finalize();

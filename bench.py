@@ -11,8 +11,9 @@ contiguous slice of the global ray-index stream of that step, so results do not 
 bins them into the 180x90 detector histogram on its GPU, and the histograms are summed with
 ONE all-reduce over RCCL (torch.distributed backend "nccl").  Weak scaling: per-GPU work is
 fixed -- 5e7 rays per GPU per step for EVERY N, so the N = 1 point of a scaling curve is the
-single-GPU bench.  At N = 8 a second timed loop runs BASELINE configs[4] (1e9 rays per step over
-the node) and is reported under "configs4".  Prints one JSON line on rank 0.
+single-GPU bench.  At N = 8 two more timed loops run BASELINE configs[4] (1e9 rays per step over
+the node: "configs4") and configs[3] (integratingSphereDetectorSweep.C's 362 disc positions share
+1e7 rays per GPU and step, ray-sharded: "configs3"); extra keys only.  Prints one JSON line on rank 0.
 """
 import argparse
 import json
@@ -248,6 +249,56 @@ def main():
                     "value": n4 * world * a.steps / dt4 / 1e6, "unit": "Mrays/s", "ms_per_step": dt4 / a.steps * 1e3,
                     "kernel_ms_min_max_over_ranks": over_ranks(rec4["kernel_ms"]),
                     "allreduce_ms_min_max_over_ranks": over_ranks(rec4["allreduce_ms"])}
+    # BASELINE configs[3] (integratingSphereDetectorSweep.C:31-105, ray-sharded): the 181 x 2 disc positions of the macro share the
+    # rays -- every rank traces its slice of the step's rays against ALL discs, ONE all-reduce of the 362 counts.  At N = 8
+    # (ISX_BENCH_CONFIGS3=1: at any N, rehearsal); extra keys only.
+    configs3 = None
+    if (world == 8 and a.rays <= 0) or os.environ.get("ISX_BENCH_CONFIGS3") == "1":
+        import math
+        discs = []
+        for th in np.arange(-45.0, 45.0 + 1e-9, 0.5):   # rootMacros::detectorDiskPlacement (integratingSphereDetectorSweep.C:145-172)
+            for ph in (0.0, 180.0):
+                t_, p_ = math.radians(th), math.radians(ph)
+                x, y, z = 200 * math.sin(t_) * math.cos(p_), 200 * math.sin(t_) * math.sin(p_), -200 * math.cos(t_)
+                rot = -math.atan2(math.sqrt(x * x + y * y), -100 - z)
+                discs.append([x, y, z, math.sin(rot), 0.0, math.cos(rot)])
+        discs = np.array(discs)
+        c3 = isx.default_config()
+        c3.r_out = 105.0; c3.reflectance = 1.0; c3.roughness_rad = 0.0; c3.max_points = 10000; c3.box_half = 200.0
+        c3.src[2] = -80.0
+        n3 = int(os.environ.get("ISX_BENCH_CONFIGS3_RAYS", "10000000"))
+        disc_dev = torch.zeros(len(discs), dtype=torch.int64, device=dev)
+        k3, ar3 = [], []
+
+        def step3(s):
+            first, _ = isx.step_slice(s, rank, world, n3)
+            h, st3 = isx.disc_sweep(c3, discs, 5.0, 0.1, n3, 7, first)
+            k3.append(st3.t_kernel_ms)
+            disc_dev.copy_(torch.from_numpy(h.reshape(-1).astype(np.int64)))
+            if use_dist:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                dist.all_reduce(disc_dev, op=dist.ReduceOp.SUM)
+                e1.record()
+                torch.cuda.synchronize()
+                ar3.append(e0.elapsed_time(e1))
+
+        step3(0)
+        k3.clear(); ar3.clear()
+        barrier()
+        t0 = time.perf_counter()
+        for s in range(1, 1 + a.steps):
+            step3(s)
+        barrier()
+        t3 = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=dev)
+        if use_dist:
+            dist.all_reduce(t3, op=dist.ReduceOp.MAX)
+        dt3 = float(t3.item())
+        configs3 = {"workload": "BASELINE configs[3]: integratingSphereDetectorSweep.C, 362 disc positions (r 5 cm, 200 cm from the origin) share "
+                                f"{n3} rays per GPU and step, shell 100.1-105 cm, rho 1; one all-reduce of the 362 counts",
+                    "rays_per_gpu_per_step": n3, "n_discs": int(len(discs)), "value": n3 * world * a.steps / dt3 / 1e6, "unit": "Mrays/s",
+                    "ms_per_step": dt3 / a.steps * 1e3, "kernel_ms_min_max_over_ranks": over_ranks(k3),
+                    "allreduce_ms_min_max_over_ranks": over_ranks(ar3), "disc_hits_last_step": int(disc_dev.sum().item())}
     if rank == 0:
         rays_total = n * world * a.steps
         value = rays_total / dt / 1e6
@@ -286,24 +337,28 @@ def main():
 
         def issue_block(kernel, live_ms, pk):
             """VALU-issue roofline of one kernel: executed SQ_INSTS_VALU per ray (its PMC pass) x rays / its LIVE time.
-            `peak` / `frac` price the executed mix by class (f64 4 cycles, 32-bit 2, v_mad_u64_u32 7, f64 rcp/rsq 16, a packed
-            f32 instruction 2: tools/summarize_profile.py) against 1024 SIMDs x 2.4 GHz -- `peak` is the wave-instruction rate this
-            mix could issue at best, `frac` = achieved / peak (= `frac_mix`); `frac_4cycle` / `peak_4cycle` charge every instruction 4
-            cycles (the convention of rounds 1-2: a mixed stream can exceed it, so a saturated kernel reads > 1); `valu_busy` is
-            the counter that says whether the VALU had idle cycles at all."""
+            `peak` / `frac` price the executed mix by class (`cycle_prices`, each with its source in `cycle_price_sources`: the
+            guide's cycle constants or tools/ubench/inst_rate.hip measured on MI355X; a PACKED f32 instruction costs what an f64 one
+            does) against 1024 SIMDs x 2.4 GHz -- `peak` is the wave-instruction rate this mix could issue at best, `frac` = achieved /
+            peak (= `frac_mix`); `frac_4cycle` / `peak_4cycle` charge every instruction 4 cycles (the convention of rounds 1-2: a
+            mixed stream can exceed it); `valu_idle` says whether the VALU had idle cycles at all (`valu_busy_counter_ratio` is
+            4 x SQ_ACTIVE_INST_VALU / SIMD-cycles: overlapping issue is counted more than once, so it exceeds 1 on a saturated
+            kernel -- a counter ratio, not a fraction)."""
             blk = {"bound": "valu_issue", "kernel": kernel, "kernel_ms": live_ms, "peak": peak_issue, "unit": "G wave-instr/s",
                    "achieved": None, "frac": None, "traffic": (pk or {}).get("hbm_bytes_per_launch")}
             if pk and pk.get("valu_wave_insts_per_ray") and live_ms > 0:
                 ach = pk["valu_wave_insts_per_ray"] * n / (live_ms * 1e-3) / 1e9
                 blk.update(achieved=ach, frac=ach / peak_issue, valu_wave_insts_per_ray=pk["valu_wave_insts_per_ray"],
-                           valu_busy=pk.get("valu_busy"), valu_lane_utilization=pk.get("valu_lane_utilization"),
+                           valu_idle=pk.get("valu_idle"), valu_busy_counter_ratio=pk.get("valu_busy_counter_ratio"),
+                           valu_lane_utilization=pk.get("valu_lane_utilization"),
                            profiled_kernel_ms=pk.get("kernel_ms"), profiled_clock_ghz=pk.get("clock_ghz"))
                 mix = pk.get("issue_mix")
                 if mix:
                     # the roofline proper: what THIS instruction mix can issue per second (peak), against what it did (achieved)
                     fm = mix["cycles_per_ray"] * n / (cus * 4 * VALU_CLOCK_GHZ * 1e9 * live_ms * 1e-3)
                     blk.update(peak_mix_cycles_per_ray=mix["cycles_per_ray"], frac_mix=fm, frac_4cycle=ach / peak_issue,
-                               peak_4cycle=peak_issue, peak=ach / fm, frac=fm)
+                               peak_4cycle=peak_issue, peak=ach / fm, frac=fm, cycle_prices=mix.get("cycles"),
+                               cycle_price_sources=mix.get("price_sources"))
             return blk
 
         kern = pj.get("kernels", {})
@@ -313,6 +368,8 @@ def main():
             b_trace = issue_block(k_trace, t_trace, kern.get(k_trace))
             b_bin = issue_block(k_bin, t_bin, kern.get(k_bin))
             b_trace["algorithmic_hbm_bytes"], b_bin["algorithmic_hbm_bytes"] = alg_bytes_trace, alg_bytes_bin
+            for b in (b_trace, b_bin):   # HBM bytes the counters saw per launch / the bytes the algorithm needs (1 = no wasted traffic)
+                b["traffic_ratio"] = (b["traffic"] / b["algorithmic_hbm_bytes"]) if b.get("traffic") else None
             dominant, other = (b_bin, b_trace) if t_bin >= t_trace else (b_trace, b_bin)
         else:
             dominant, other = issue_block("isx_trace_bin_kernel", t_single or k_ms, pj if not kern else None), None
@@ -340,15 +397,25 @@ def main():
             # convention.  `roofline` is the dominant (longer) kernel of the launch, `roofline_other_kernel` the second one.
             "roofline": dominant,
             "roofline_other_kernel": other,
+            # the whole step against the issue roofline: (sum over the step's kernels of their mix-priced issue cycles at 2.4 GHz) /
+            # ms_per_step -- what the step would take if both kernels issued without a gap, over what it takes with launches,
+            # zeroing, synchronisation and the all-reduce
+            "roofline_step": (None if not (pipeline and dominant.get("peak_mix_cycles_per_ray") and other and other.get("peak_mix_cycles_per_ray")) else {
+                "bound": "valu_issue", "unit": "ms per step",
+                "peak": (dominant["peak_mix_cycles_per_ray"] + other["peak_mix_cycles_per_ray"]) * n / (cus * 4 * VALU_CLOCK_GHZ * 1e9) * 1e3,
+                "achieved": dt / a.steps * 1e3,
+                "frac": (dominant["peak_mix_cycles_per_ray"] + other["peak_mix_cycles_per_ray"]) * n / (cus * 4 * VALU_CLOCK_GHZ * 1e9) / (dt / a.steps)}),
             "pipeline": ({"kernels": [k_trace, k_bin], "trace_ms": t_trace, "bin_ms": t_bin,
                           "exit_lines_per_launch": lines} if pipeline else None),
             # per-rank means of the timed steps, [min, max] over the ranks: kernel time, its two halves, the one all-reduce
             "per_rank_ms_min_max": per_rank,
             "configs4": configs4,
+            "configs3": configs3,
             # the HBM figure the north star asks for: algorithmic bytes (exit lines written once and read once, 48 B each, plus
             # one 129.6 KB histogram) / kernel time against 8 TB/s
             "roofline_hbm": {"bound": "hbm", "achieved": hbm_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                              "frac": hbm_gbs / HBM_PEAK_GBS, "traffic": traffic, "algorithmic_bytes_per_launch": alg_bytes,
+                             "traffic_ratio": (traffic / alg_bytes) if traffic else None,
                              "note": "HBM is not the binding resource of this path (SURVEY.md 8d): ~2 GB of exit lines per 5e7 "
                                      "rays cross HBM once in each direction; no traffic is faked to raise the fraction"},
             # reference-algorithm flop (brute-force convention of SURVEY.md 8d) -- NOT a utilisation: the kernel culls

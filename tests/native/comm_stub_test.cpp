@@ -1,5 +1,5 @@
 // CPU test of the host driver's collective (altair-raytracing_amd/host/isx_comm.*): N "ranks" = N threads joined by an
-// in-process Transport double.  Checks (a) SUM/MAX/MIN semantics of reduce_collective, (b) the ADVICE r01 case: ONE rank
+// in-process Transport double.  Checks (a) the semantics of reduce_collective (sums, MAX of the times, worst status) through ONE sum, (b) the ADVICE r01 case: ONE rank
 // fails before the collective -> every rank still enters it, nobody blocks, every rank returns the same error.
 // Built and run by tests/test_host_driver.py::test_collective_status_with_a_failing_rank (no GPU needed).
 #include <condition_variable>
@@ -17,32 +17,25 @@ struct Hub {
   int world;
   std::mutex m;
   std::condition_variable cv;
-  int arrived = 0, generation = 0;
+  int arrived = 0, generation = 0, exchanges = 0;
   std::vector<unsigned long long> acc;
-  size_t n_sum = 0, n_max = 0, n_min = 0;
 };
 
+// ONE sum per collective: the double counts the exchanges, so the test can assert "a single all-reduce per call"
 struct Loopback : Transport {
   Hub& h;
   explicit Loopback(Hub& hub) : h(hub) {}
-  bool exchange(unsigned long long* buf, size_t n_sum, size_t n_max, size_t n_min) override {
+  bool exchange_sum(unsigned long long* buf, size_t n) override {
     std::unique_lock<std::mutex> lk(h.m);
-    const size_t total = n_sum + n_max + n_min;
-    if (h.arrived == 0) { h.acc.assign(buf, buf + total); h.n_sum = n_sum; h.n_max = n_max; h.n_min = n_min; }
+    if (h.arrived == 0) { h.acc.assign(buf, buf + n); h.exchanges++; }
     else {
-      if (n_sum != h.n_sum || n_max != h.n_max || n_min != h.n_min) return false;   // ranks disagree on the layout
-      for (size_t k = 0; k < n_sum; ++k) h.acc[k] += buf[k];
-      for (size_t k = n_sum; k < n_sum + n_max; ++k) if (buf[k] > h.acc[k]) h.acc[k] = buf[k];
-      for (size_t k = n_sum + n_max; k < total; ++k) {
-        long long a, b;
-        std::memcpy(&a, &h.acc[k], 8); std::memcpy(&b, &buf[k], 8);
-        if (b < a) std::memcpy(&h.acc[k], &b, 8);
-      }
+      if (n != h.acc.size()) return false;   // ranks disagree on the layout
+      for (size_t k = 0; k < n; ++k) h.acc[k] += buf[k];
     }
     const int gen = h.generation;
     if (++h.arrived == h.world) { h.arrived = 0; h.generation++; h.cv.notify_all(); }
     else h.cv.wait(lk, [&] { return h.generation != gen; });
-    std::memcpy(buf, h.acc.data(), total * sizeof(unsigned long long));
+    std::memcpy(buf, h.acc.data(), n * sizeof(unsigned long long));
     return true;
   }
 };
@@ -59,11 +52,12 @@ static int run_case(int world, int failing_rank, int fail_code) {
     st[(size_t)r].launched = 10 + (uint64_t)r; st[(size_t)r].wall_hits = 1000; st[(size_t)r].t_kernel_ms = 1.5 * (r + 1);
     th.emplace_back([&, r] {
       Loopback t(hub);
-      rc[(size_t)r] = reduce_collective(t, r == failing_rank ? fail_code : ISX_OK, hits[(size_t)r].data(), 5, &st[(size_t)r], 1);
+      rc[(size_t)r] = reduce_collective(t, r, world, r == failing_rank ? fail_code : ISX_OK, hits[(size_t)r].data(), 5, &st[(size_t)r], 1);
     });
   }
   for (auto& t : th) t.join();   // a rank left waiting in the collective would hang here (the test runs under a time-out)
   int bad = 0;
+  if (hub.exchanges != 1) { std::printf("%d exchanges for one collective (SURVEY.md 8e: ONE all-reduce)\n", hub.exchanges); bad++; }
   for (int r = 0; r < world; ++r) {
     if (failing_rank >= 0) {
       if (rc[(size_t)r] != fail_code) { std::printf("rank %d: rc %d, expected %d\n", r, rc[(size_t)r], fail_code); bad++; }
@@ -91,6 +85,7 @@ int main() {
   bad += run_case(2, 1, ISX_ERR_BAD_CONFIG);
   bad += run_case(2, 0, ISX_ERR_HIP);
   bad += run_case(8, 5, ISX_ERR_TOO_LARGE);
+  bad += run_case(3, 2, ISX_ERR_NO_DEVICE);
   std::printf(bad ? "FAILED %d\n" : "OK\n", bad);
   return bad ? 1 : 0;
 }

@@ -412,7 +412,7 @@ def test_bench_two_ranks_share_the_gpu_over_gloo(isx):
     import subprocess
     import sys
     rays, steps, warmup = 1_500_000, 2, 1
-    env = dict(os.environ, ISX_BENCH_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env = dict(os.environ, ISX_BENCH_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0", ISX_BENCH_CONFIGS3="1", ISX_BENCH_CONFIGS3_RAYS="300000")
     for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "ISX_FORCE_DIST"):
         env.pop(k, None)
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
@@ -443,6 +443,28 @@ def test_bench_two_ranks_share_the_gpu_over_gloo(isx):
         lo, hi = pr[key]
         assert 0 < lo <= hi, (key, pr)
     assert pr["kernel_ms"][1] < out["ms_per_step"] and out["configs4"] is None
+    # the configs[3] leg (the driver's N = 8 launch runs it by default; here ISX_BENCH_CONFIGS3=1 rehearses it with two ranks):
+    # 362 disc positions share the rays of a step, ray-sharded, ONE all-reduce of the counts -- the last step's summed counts
+    # must be those of its two slices swept in this process
+    c3 = out["configs3"]
+    assert c3 is not None and c3["n_discs"] == 362 and c3["rays_per_gpu_per_step"] == 300000 and c3["value"] > 0
+    import math
+    discs = []
+    for th in np.arange(-45.0, 45.0 + 1e-9, 0.5):
+        for ph in (0.0, 180.0):
+            t_, p_ = math.radians(th), math.radians(ph)
+            x, y, z = 200 * math.sin(t_) * math.cos(p_), 200 * math.sin(t_) * math.sin(p_), -200 * math.cos(t_)
+            rot = -math.atan2(math.sqrt(x * x + y * y), -100 - z)
+            discs.append([x, y, z, math.sin(rot), 0.0, math.cos(rot)])
+    cfg3 = isx.default_config()
+    cfg3.r_out = 105.0; cfg3.reflectance = 1.0; cfg3.roughness_rad = 0.0; cfg3.max_points = 10000; cfg3.box_half = 200.0
+    cfg3.src[2] = -80.0
+    want = 0
+    for rank in range(2):
+        first, count = isx.step_slice(steps, rank, 2, 300000)   # (the leg's last timed step has index `steps`: one warm-up step before it)
+        h3, _ = isx.disc_sweep(cfg3, np.array(discs), 5.0, 0.1, count, 7, first)
+        want += int(h3.sum())
+    assert c3["disc_hits_last_step"] == want and want > 0
 
 
 def test_random_configurations_equal_the_oracle(isx, orc):

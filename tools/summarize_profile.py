@@ -78,11 +78,15 @@ if kt:
     rows = [r for r in csv.DictReader(open(kt)) if is_kernel(r["Kernel_Name"])]
     durs = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6 for r in rows]
     mx = max(durs)
-    big = [d for d in durs if d > 0.5 * mx]
+    order = sorted(range(len(rows)), key=lambda i: int(rows[i]["Start_Timestamp"]))
+    big_all = [durs[i] for i in order if durs[i] > 0.5 * mx]
+    # the first full-size launch of the process is the warm-up step (cold instruction cache, page faults of the workspace:
+    # 13.0 against 11.2 ms for the trace kernel): it is listed, not averaged
+    big = big_all[1:] if len(big_all) > 1 else big_all
     r = rows[durs.index(mx)]
     lines += [f"## kernel trace (`rocprofv3 --kernel-trace --stats -- {a.command}`)", "",
-              f"* full-size launches ({RAYS:.3g} rays): {len(big)}, average {sum(big)/len(big):.3f} ms, min {min(big):.3f}, max {max(big):.3f}"
-              f" -> {RAYS / (sum(big)/len(big)) / 1e3:.1f} Mrays/s",
+              f"* full-size launches ({RAYS:.3g} rays): {len(big_all)}, the first (warm-up) {big_all[0]:.3f} ms; the other {len(big)}: average "
+              f"{sum(big)/len(big):.3f} ms, min {min(big):.3f}, max {max(big):.3f} -> {RAYS / (sum(big)/len(big)) / 1e3:.1f} Mrays/s",
               f"* grid {r['Grid_Size_X']} threads = {int(r['Grid_Size_X'])//int(r['Workgroup_Size_X'])} workgroups x {r['Workgroup_Size_X']}, "
               f"VGPR_Count {r['VGPR_Count']}, SGPR_Count {r['SGPR_Count']}, scratch {r['Scratch_Size']}, "
               f"LDS_Block_Size {r['LDS_Block_Size']} (dynamic LDS is not shown by the trace)", ""]
@@ -140,8 +144,13 @@ if pmc:
     if "SQ_ACTIVE_INST_VALU" in pmc and "GRBM_GUI_ACTIVE" in pmc:
         simd_cycles = 1024 * pmc["GRBM_GUI_ACTIVE"] / 8
         busy = 4 * pmc["SQ_ACTIVE_INST_VALU"] / simd_cycles
-        summ["valu_busy"] = busy
-        lines.append(f"* VALU busy = 4*SQ_ACTIVE_INST_VALU / (1024 SIMD x cycles) = {busy:.3f}")
+        # (4 x SQ_ACTIVE_INST_VALU counts every SIMD-cycle in which a VALU instruction of ANY wave is in flight; instructions of
+        #  different waves overlap in the pipeline, so the ratio exceeds 1 on a saturated kernel: it says "no idle VALU cycle by this
+        #  counter", it is not a utilisation)
+        summ["valu_busy_counter_ratio"] = busy
+        summ["valu_idle"] = "none by this counter (ratio >= 1)" if busy >= 1.0 else f"{1.0 - busy:.3f} of the SIMD cycles"
+        lines.append(f"* 4*SQ_ACTIVE_INST_VALU / (1024 SIMD x cycles) = {busy:.3f}" +
+                     (" (>= 1: no idle VALU cycle by this counter; overlapping issue is counted more than once, not a fraction)" if busy >= 1.0 else " = VALU busy"))
     if "SQ_THREAD_CYCLES_VALU" in pmc and "SQ_ACTIVE_INST_VALU" in pmc:
         util = pmc["SQ_THREAD_CYCLES_VALU"] / (64 * pmc["SQ_ACTIVE_INST_VALU"])
         summ["valu_lane_utilization"] = util
@@ -170,20 +179,35 @@ if pmc:
         lines.append(f"* f32: add {f32[0]/RAYS:.1f}, mul {f32[1]/RAYS:.1f}, fma {f32[2]/RAYS:.1f}, trans {f32[3]/RAYS:.2f}")
         lines.append(f"* int32 {pmc.get('SQ_INSTS_VALU_INT32',0)/RAYS:.1f}, int64 {pmc.get('SQ_INSTS_VALU_INT64',0)/RAYS:.1f}, "
                      f"cvt {pmc.get('SQ_INSTS_VALU_CVT',0)/RAYS:.1f}, LDS atomics {pmc.get('SQ_INSTS_LDS_ATOMIC',0)/RAYS:.2f}")
-        # Mix-aware issue bound: the 614.4 G/s "peak" charges every wave64 VALU instruction 4 cycles; on gfx950
-        # a 32-bit VALU instruction issues in 2 (MI355X_MICROARCH.md, cycle constants: v_fma_f32 2 cyc with several waves per
-        # SIMD), an f64 one in 4, and tools/ubench/inst_rate.hip measured v_mad_u64_u32 at ~7 and v_rcp_f64 / v_rsq_f64 at ~16.
-        # issue cycles per ray = sum over classes; whatever the class counters do not cover (moves, compares, selects, bit
-        # operations, lane permutes) is priced as 32-bit.
+        # Mix-aware issue bound: issue cycles per ray = sum over instruction classes of (count x cycles per wave64 instruction).
+        # Prices (cycles per wave-instruction per SIMD with 4 waves per SIMD), with where each comes from:
+        #   f64 add / mul / fma     4.6   tools/ubench/inst_rate.hip on MI355X (4.36-4.69; MI355X_MICROARCH.md's 16 lanes/clk gives 4)
+        #   f64 rcp / rsq          16     inst_rate.hip (v_rcp_f64 + one add: 20.5)
+        #   v_mad_u64_u32           7     inst_rate.hip (multiply + xor: 9.05)
+        #   f32 add / mul / fma     4.6 in the binning kernels, whose f32 arithmetic is PACKED (v_pk_fma_f32 4.75, v_pk_mul_f32 4.48:
+        #                           inst_rate.hip, round 4 -- a packed instruction does two lanes' worth of work per lane at the f64
+        #                           rate; rounds 2-3 priced it like a scalar one, at 2, which halved these kernels' fraction);
+        #                           2.35 elsewhere (scalar v_fma_f32: inst_rate.hip 2.35; the guide's cycle constants say 2)
+        #   f32 transcendental      4     MI355X_MICROARCH.md (cycle constants: 8 for one wave alone, 4 shared)
+        #   conversions             4     MI355X_MICROARCH.md (v_cvt_pk 4-5)
+        #   everything else         2     32-bit integer / compare / select / move / permute: MI355X_MICROARCH.md (v_add/v_fma_f32 2 cycles with
+        #                                 several waves per SIMD); inst_rate.hip: 1.7 (compare + select + add) to 2.3
         f32n = f32[0] + f32[1] + f32[2]
         i64, cvt, i32 = pmc.get("SQ_INSTS_VALU_INT64", 0.0), pmc.get("SQ_INSTS_VALU_CVT", 0.0), pmc.get("SQ_INSTS_VALU_INT32", 0.0)
         other = max(0.0, pmc["SQ_INSTS_VALU"] - (wave_insts + f32n + f32[3] + i64 + cvt + i32))
-        mix_cycles = 4.0 * (add + mul + fma) + 16.0 * trans + 2.0 * f32n + 4.0 * f32[3] + 7.0 * i64 + 4.0 * cvt + 2.0 * (i32 + other)
+        packed = KERNEL.startswith("isx_bin_")
+        price = {"f64": 4.6, "f64_trans": 16.0, "f32_arith": 4.6 if packed else 2.35, "f32_trans": 4.0, "int64_mad": 7.0, "cvt": 4.0, "other_32bit": 2.0}
+        mix_cycles = (price["f64"] * (add + mul + fma) + price["f64_trans"] * trans + price["f32_arith"] * f32n + price["f32_trans"] * f32[3] +
+                      price["int64_mad"] * i64 + price["cvt"] * cvt + price["other_32bit"] * (i32 + other))
         summ["issue_mix"] = {"cycles_per_ray": mix_cycles / RAYS, "uniform_4_cycles_per_ray": 4.0 * pmc["SQ_INSTS_VALU"] / RAYS,
-                             "unclassified_valu_per_ray": other / RAYS,
-                             "cycles": {"f64": 4, "f64_trans": 16, "f32_int32_other": 2, "f32_trans": 4, "int64_mad": 7, "cvt": 4}}
-        lines.append(f"* mix-aware issue cycles per ray = {mix_cycles/RAYS:.1f} (f64 4, f64 rcp/rsq 16, v_mad_u64_u32 7, cvt 4, f32 trans 4, every "
-                     f"other VALU instruction 2; {other/RAYS:.1f} unclassified per ray) against {4.0*pmc['SQ_INSTS_VALU']/RAYS:.1f} with 4 cycles for all")
+                             "unclassified_valu_per_ray": other / RAYS, "cycles": price, "f32_arithmetic_is_packed": packed,
+                             "price_sources": {"f64": "tools/ubench/inst_rate.hip (4.36-4.69)", "f64_trans": "inst_rate.hip", "int64_mad": "inst_rate.hip",
+                                               "f32_arith": "inst_rate.hip (v_pk_fma_f32 4.75 / v_pk_mul_f32 4.48 packed, v_fma_f32 2.35 scalar)",
+                                               "f32_trans": "MI355X_MICROARCH.md cycle constants", "cvt": "MI355X_MICROARCH.md cycle constants",
+                                               "other_32bit": "MI355X_MICROARCH.md cycle constants (2); inst_rate.hip 1.7-2.3"}}
+        lines.append(f"* mix-aware issue cycles per ray = {mix_cycles/RAYS:.1f} (f64 {price['f64']}, f64 rcp/rsq 16, v_mad_u64_u32 7, f32 arithmetic "
+                     f"{price['f32_arith']}{' (packed)' if packed else ''}, cvt 4, f32 trans 4, every other VALU instruction 2; {other/RAYS:.1f} "
+                     f"unclassified per ray) against {4.0*pmc['SQ_INSTS_VALU']/RAYS:.1f} with 4 cycles for all")
         if big:
             t = sum(big) / len(big) * 1e-3
             for label, clk in (("2.4 GHz", 2.4e9), ("the measured clock", summ.get("clock_ghz", 2.4) * 1e9)):
