@@ -2379,22 +2379,59 @@ isx_trace_log_lean_kernel(const Geom g, const DetGrid d, const Work wk) { persis
 //   pending  kPendCap slots, many producers (the tracers: slots reserved by compare-and-swap, so the ring never overflows; a
 //            wave that finds no room keeps its rays and tries again a trip later), one consumer (the assist wave, which only
 //            takes what is published: res == pub);
-//   resume   kResumeCap slots, one producer (the assist wave, which waits for room -- the tracers never wait for it, so there
-//            is no cycle), many consumers (compare-and-swap on the head);
+//   resume   kResumeCap slots, many consumers (the tracers: compare-and-swap on the head) and, since round 4, several
+//            producers (slots reserved by compare-and-swap, taken only once everything reserved is published: pub == res, as
+//            on the pending ring): the assist wave, which waits for room -- the tracers never wait for it, so there is no
+//            cycle -- and the tracer waves that give their last rays away at the end of a launch (below);
 //   busy     rays that are in neither a tracer lane nor ended; a tracer wave with no ray left leaves when the launch's ray
 //            queue is dry and busy == 0, the assist wave when every tracer has left.
+// The end of a launch (round 4).  Once the launch's ray queue is dry a wave only loses rays: after ~20 loop trips it runs a
+// dozen lanes of 64 and keeps doing so for another ~40 trips, until its longest ray has ended -- 3 % of all trips of a 5e7-ray
+// launch of the headline, 8 % at 2e7 rays, 12 % of the shared-ray disc sweep (reflectance 1: 144 bounces per ray), all of them
+// at a fifth of the lanes.  So a wave that is down to kDonateMax rays after the queue ran dry hands them to the resume ring --
+// the records the assist wave writes there, with the two Philox words an odd interaction count needs taken from the lane's own
+// block -- and leaves; the waves that stay fill their dead lanes with them.  `alive` keeps the last wave from leaving that
+// way, and a wave that leaves because it sees no work (busy == 0) takes itself out of `alive` FIRST and looks again: a donor
+// announces its rays in `busy` before it takes itself out, so one of the two always sees the other.
+// Scheduling only: a ray's history is a function of (seed, index).
 // Every wait is bounded (kSpinLimit polls during which NO wave of the workgroup made progress -- AssistQueues::beat; a long
 // stretch without hand-overs, e.g. a tiny port opening with a large bounce limit or a down-clocked device, is not a failure):
 // a wave that gives up raises stats[7] and the host reports ISX_ERR_HIP instead of hanging the device.
 constexpr uint32_t kPendCap = 512, kResumeCap = 128;
+#ifndef ISX_DONATE_MAX
+#define ISX_DONATE_MAX 32     // a tracer wave with at most this many rays left after the launch's queue ran dry gives them away (0: never;
+                              // measured, trace kernel of 5e7 headline rays / of the 1e7-ray disc sweep: 0: 11.35 / 7.13 ms, 16: 11.27 / 6.79,
+                              // 24: 11.29 / 6.76, 32: 11.23 / 6.71, 48: 11.31 / 6.85)
+#endif
+constexpr uint32_t kDonateMax = ISX_DONATE_MAX;
 constexpr uint32_t kSpinLimit = 1u << 22;
 struct AssistQueues {   // LDS, one per workgroup
   uint32_t pend_res, pend_pub, pend_head, resume_pub, resume_head, busy, tracers_done, failed;
-  uint32_t drain, beat, pad1, pad2;   // drain: a tracer wave has no ray left and none to get (the assist wave stops waiting for full batches)
+  uint32_t drain, beat, resume_res, alive;   // drain: a tracer wave has no ray left and none to get (the assist wave stops waiting for full batches)
+                                      // resume_res: slots of the resume ring reserved (it has several producers since round 4)
+                                      // alive: tracer waves that have neither left nor given their last rays away (set to n_tracers)
                                       // beat: bumped by every wave of the workgroup that makes progress (a tracer's loop trip, a batch of the
                                       // assist wave): the bounded waits below count polls WITHOUT a beat, not idle time
 };
 enum : uint32_t { IDO_SCATTERED = 0x80000000u, IDO_TARGET = 0x40000000u };   // Ray::ido flags in a queue record (offsets < 2^30)
+
+// A ray as a 64-byte record of the LDS queues: point, direction, {index | flags, interaction count, two more words} -- the
+// surface it sits on and a spare for the pending ring, words 2-3 of its Philox block for the resume ring.
+__device__ __forceinline__ void ray_pack(uint4* dst, const Ray& r, uint32_t wa, uint32_t wb) {
+  const unsigned long long px = (unsigned long long)__double_as_longlong(r.p.x), py = (unsigned long long)__double_as_longlong(r.p.y),
+                           pz = (unsigned long long)__double_as_longlong(r.p.z), vx = (unsigned long long)__double_as_longlong(r.v.x),
+                           vy = (unsigned long long)__double_as_longlong(r.v.y), vz = (unsigned long long)__double_as_longlong(r.v.z);
+  dst[0] = make_uint4((uint32_t)px, (uint32_t)(px >> 32), (uint32_t)py, (uint32_t)(py >> 32));
+  dst[1] = make_uint4((uint32_t)pz, (uint32_t)(pz >> 32), (uint32_t)vx, (uint32_t)(vx >> 32));
+  dst[2] = make_uint4((uint32_t)vy, (uint32_t)(vy >> 32), (uint32_t)vz, (uint32_t)(vz >> 32));
+  dst[3] = make_uint4(r.ido | (r.tgt ? IDO_TARGET : 0u), r.j, wa, wb);
+}
+__device__ __forceinline__ void ray_unpack(const uint4& a, const uint4& b, const uint4& c, const uint4& e, Ray& r) {
+  r.p.x = __longlong_as_double(((long long)a.y << 32) | a.x); r.p.y = __longlong_as_double(((long long)a.w << 32) | a.z);
+  r.p.z = __longlong_as_double(((long long)b.y << 32) | b.x); r.v.x = __longlong_as_double(((long long)b.w << 32) | b.z);
+  r.v.y = __longlong_as_double(((long long)c.y << 32) | c.x); r.v.z = __longlong_as_double(((long long)c.w << 32) | c.z);
+  r.ido = e.x & ~IDO_TARGET; r.tgt = (e.x & IDO_TARGET) != 0u; r.j = e.y;
+}
 
 // DISC (the shared-ray physical-disc sweep, integratingSphereDetectorSweep.C:134-172 / SINK_DISC): the assist wave writes, for
 // EVERY ray that leaves for the world box, its forward exit segment -- start point, direction, length (8 doubles per slot) --
@@ -2427,7 +2464,7 @@ __device__ __forceinline__ void assist_body(const Geom& g_arg, const DetGrid& d_
     g_lds->q0[0] = q0.x; g_lds->q0[1] = q0.y; g_lds->q0[2] = q0.z;
     g_lds->q0_ok = ok ? 1 : 0;
   }
-  if (tid == 0) { *d_lds = d_arg; AssistQueues z = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}; *Q = z; }
+  if (tid == 0) { *d_lds = d_arg; AssistQueues z = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, (uint32_t)n_tracers}; *Q = z; }
   __syncthreads();
   typedef __attribute__((address_space(3))) Geom LdsGeom;
   const volatile LdsGeom& g = *(const volatile LdsGeom*)g_lds;
@@ -2460,7 +2497,9 @@ __device__ __forceinline__ void assist_body(const Geom& g_arg, const DetGrid& d_
         // them, and the assist wave overwrites a slot only after the head has passed it, so what was read is what was won
         const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(dead >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)dead, 0u));
         for (;;) {
-          const uint32_t hd = ld(&Q->resume_head), avail = ld(&Q->resume_pub) - hd;
+          // (pub before res: pub(t1) <= res(t1) <= res(t2), so pub == res proves every slot below res is written)
+          const uint32_t pubq = ld(&Q->resume_pub), resq = ld(&Q->resume_res), hd = ld(&Q->resume_head);
+          const uint32_t avail = pubq == resq ? resq - hd : 0u;
           if (avail == 0u) break;
           const uint32_t want = (uint32_t)__popcll(dead);
           const uint32_t take = want < avail ? want : avail;
@@ -2480,10 +2519,8 @@ __device__ __forceinline__ void assist_body(const Geom& g_arg, const DetGrid& d_
           won = (uint32_t)__builtin_amdgcn_readfirstlane((int)won);
           if (!won) continue;
           if (mine) {
-            r.p.x = __longlong_as_double(((long long)a.y << 32) | a.x); r.p.y = __longlong_as_double(((long long)a.w << 32) | a.z);
-            r.p.z = __longlong_as_double(((long long)b.y << 32) | b.x); r.v.x = __longlong_as_double(((long long)b.w << 32) | b.z);
-            r.v.y = __longlong_as_double(((long long)c.y << 32) | c.x); r.v.z = __longlong_as_double(((long long)c.w << 32) | c.z);
-            r.ido = e.x & ~IDO_TARGET; r.tgt = (e.x & IDO_TARGET) != 0u; r.j = e.y; r.on = K_INNER;
+            ray_unpack(a, b, c, e, r);
+            r.on = K_INNER;
             r.cw[0] = 0u; r.cw[1] = 0u; r.cw[2] = e.z; r.cw[3] = e.w;
             run = true;
           }
@@ -2515,7 +2552,17 @@ __device__ __forceinline__ void assist_body(const Geom& g_arg, const DetGrid& d_
         }
         if (__ballot(run || hand) == 0ull) {
           // no ray in this wave and none to be had from the launch; rays of this workgroup may still come back
-          if (ld(&Q->busy) == 0u) break;
+          if (ld(&Q->busy) == 0u) {
+            // out of `alive` first, then look again: a wave that gives its rays away has announced them in `busy` before it
+            // took itself out, so either it found this wave still counted, or this wave finds its rays
+            uint32_t gone = 0;
+            if (lane == 0) {
+              __hip_atomic_fetch_sub(&Q->alive, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_WORKGROUP);
+              if (ld(&Q->busy) == 0u) gone = 1u;
+              else add(&Q->alive, 1u);
+            }
+            if (__builtin_amdgcn_readfirstlane((int)gone)) break;
+          }
           if (!drained) { drained = true; if (lane == 0) __hip_atomic_store(&Q->drain, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
           { const uint32_t bt = ld(&Q->beat); if (bt != beat_seen) { beat_seen = bt; spins = 0u; } }   // somebody is still at work
           if (++spins > kSpinLimit) { if (lane == 0) add(&Q->failed, 1u); break; }
@@ -2604,14 +2651,7 @@ __device__ __forceinline__ void assist_body(const Geom& g_arg, const DetGrid& d_
         if (ok) {
           if (hand) {
             const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(hm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)hm, 0u));
-            uint4* dst = pend_q + 4 * ((base + rank) & (kPendCap - 1));
-            const unsigned long long px = (unsigned long long)__double_as_longlong(r.p.x), py = (unsigned long long)__double_as_longlong(r.p.y),
-                                     pz = (unsigned long long)__double_as_longlong(r.p.z), vx = (unsigned long long)__double_as_longlong(r.v.x),
-                                     vy = (unsigned long long)__double_as_longlong(r.v.y), vz = (unsigned long long)__double_as_longlong(r.v.z);
-            dst[0] = make_uint4((uint32_t)px, (uint32_t)(px >> 32), (uint32_t)py, (uint32_t)(py >> 32));
-            dst[1] = make_uint4((uint32_t)pz, (uint32_t)(pz >> 32), (uint32_t)vx, (uint32_t)(vx >> 32));
-            dst[2] = make_uint4((uint32_t)vy, (uint32_t)(vy >> 32), (uint32_t)vz, (uint32_t)(vz >> 32));
-            dst[3] = make_uint4(r.ido | (r.tgt ? IDO_TARGET : 0u), r.j, (uint32_t)r.on, 0u);
+            ray_pack(pend_q + 4 * ((base + rank) & (kPendCap - 1)), r, (uint32_t)r.on, 0u);
             hand = false;
           }
           __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
@@ -2621,6 +2661,53 @@ __device__ __forceinline__ void assist_body(const Geom& g_arg, const DetGrid& d_
         }
       }
       ISX_TD_MARK(3);
+      // ---- the end of the launch: a wave that is down to a few rays gives them to the waves that stay, and leaves
+      if (kDonateMax != 0u && next == kDry) {
+        const unsigned long long live = __ballot(run);
+        const uint32_t cnt = (uint32_t)__popcll(live);
+        if (cnt != 0u && cnt <= kDonateMax && __ballot(hand) == 0ull) {
+          uint32_t ok = 0, base = 0;
+          if (lane == 0) {
+            add(&Q->busy, cnt);                                          // announced before this wave takes itself out
+            for (;;) {
+              const uint32_t al = ld(&Q->alive);
+              if (al < 2u) break;                                        // the last wave keeps its rays
+              uint32_t expect = al;
+              if (__hip_atomic_compare_exchange_strong(&Q->alive, &expect, al - 1u, __ATOMIC_ACQ_REL, __ATOMIC_RELAXED,
+                                                       __HIP_MEMORY_SCOPE_WORKGROUP)) { ok = 1u; break; }
+            }
+            if (ok) {
+              for (;;) {
+                const uint32_t rs = ld(&Q->resume_res), h2 = ld(&Q->resume_head);
+                if (rs + cnt - h2 > kResumeCap) { ok = 0u; break; }      // no room: another trip with these rays
+                uint32_t expect = rs;
+                if (__hip_atomic_compare_exchange_strong(&Q->resume_res, &expect, rs + cnt, __ATOMIC_ACQ_REL, __ATOMIC_RELAXED,
+                                                         __HIP_MEMORY_SCOPE_WORKGROUP)) { base = rs; break; }
+              }
+              if (!ok) add(&Q->alive, 1u);
+            }
+            if (!ok) __hip_atomic_fetch_sub(&Q->busy, cnt, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+          }
+          ok = (uint32_t)__builtin_amdgcn_readfirstlane((int)ok);
+          base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+          if (ok) {
+            if (run) {
+              const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(live >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)live, 0u));
+              // (the record the assist wave writes for a ray that returns: at the top of a trip a lane with an odd interaction
+              //  count holds words 2-3 of its block j/2 in cw[2..3] -- bounce_words)
+              ray_pack(resume_q + 4 * ((base + rank) & (kResumeCap - 1)), r, r.cw[2], r.cw[3]);
+              run = false;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            if (lane == 0) {
+              add(&Q->resume_pub, cnt);
+              __hip_atomic_store(&Q->drain, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);   // (no more waiting for full batches)
+            }
+            ISX_TD_ADD(5, cnt); ISX_TD_ADD(6, 1);
+            break;
+          }
+        }
+      }
     }
     ISX_TD_FLUSH();
     if (lane == 0) add(&Q->tracers_done, 1u);
@@ -2671,10 +2758,8 @@ __device__ __forceinline__ void assist_body(const Geom& g_arg, const DetGrid& d_
       if (have) {
         const uint4* src = pend_q + 4 * ((hd + (uint32_t)lane) & (kPendCap - 1));
         const uint4 a = src[0], b = src[1], c = src[2], e = src[3];
-        r.p.x = __longlong_as_double(((long long)a.y << 32) | a.x); r.p.y = __longlong_as_double(((long long)a.w << 32) | a.z);
-        r.p.z = __longlong_as_double(((long long)b.y << 32) | b.x); r.v.x = __longlong_as_double(((long long)b.w << 32) | b.z);
-        r.v.y = __longlong_as_double(((long long)c.y << 32) | c.x); r.v.z = __longlong_as_double(((long long)c.w << 32) | c.z);
-        r.ido = e.x & ~IDO_TARGET; r.tgt = (e.x & IDO_TARGET) != 0u; r.j = e.y; r.on = (int)e.z;
+        ray_unpack(a, b, c, e, r);
+        r.on = (int)e.z;
       }
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");          // (the slots are free once they have been read)
       if (lane == 0) add(&Q->pend_head, take);
@@ -2716,14 +2801,7 @@ __device__ __forceinline__ void assist_body(const Geom& g_arg, const DetGrid& d_
         if (!ok) continue;
         if (go) {
           const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(gm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)gm, 0u));
-          uint4* dst = pend_q + 4 * ((base + rank) & (kPendCap - 1));
-          const unsigned long long px = (unsigned long long)__double_as_longlong(r.p.x), py = (unsigned long long)__double_as_longlong(r.p.y),
-                                   pz = (unsigned long long)__double_as_longlong(r.p.z), vx = (unsigned long long)__double_as_longlong(r.v.x),
-                                   vy = (unsigned long long)__double_as_longlong(r.v.y), vz = (unsigned long long)__double_as_longlong(r.v.z);
-          dst[0] = make_uint4((uint32_t)px, (uint32_t)(px >> 32), (uint32_t)py, (uint32_t)(py >> 32));
-          dst[1] = make_uint4((uint32_t)pz, (uint32_t)(pz >> 32), (uint32_t)vx, (uint32_t)(vx >> 32));
-          dst[2] = make_uint4((uint32_t)vy, (uint32_t)(vy >> 32), (uint32_t)vz, (uint32_t)(vz >> 32));
-          dst[3] = make_uint4(r.ido | (r.tgt ? IDO_TARGET : 0u), r.j, (uint32_t)r.on, 0u);
+          ray_pack(pend_q + 4 * ((base + rank) & (kPendCap - 1)), r, (uint32_t)r.on, 0u);
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         if (lane == 0) add(&Q->pend_pub, cnt);
@@ -2802,13 +2880,24 @@ __device__ __forceinline__ void assist_body(const Geom& g_arg, const DetGrid& d_
       const unsigned long long bm = __ballot(back);
       if (bm) {
         const uint32_t cnt = (uint32_t)__popcll(bm);
-        const uint32_t pubr = ld(&Q->resume_pub);
-        uint32_t w = 0;
-        while (pubr + cnt - ld(&Q->resume_head) > kResumeCap) {       // room?  (the tracers never wait for this wave)
-          { const uint32_t bt = ld(&Q->beat); if (bt != beat_seen) { beat_seen = bt; w = 0u; } }
-          if (++w > kSpinLimit) { if (lane == 0) add(&Q->failed, 1u); break; }
-          __builtin_amdgcn_s_sleep(2);
+        // room?  (the tracers never wait for this wave; slots are reserved by compare-and-swap: waves that give their last rays
+        // away write to this ring as well)
+        uint32_t pubr = 0, w = 0;
+        if (lane == 0) {
+          for (;;) {
+            const uint32_t rs = ld(&Q->resume_res);
+            if (rs + cnt - ld(&Q->resume_head) <= kResumeCap) {
+              uint32_t expect = rs;
+              if (__hip_atomic_compare_exchange_strong(&Q->resume_res, &expect, rs + cnt, __ATOMIC_ACQ_REL, __ATOMIC_RELAXED,
+                                                       __HIP_MEMORY_SCOPE_WORKGROUP)) { pubr = rs; break; }
+              continue;
+            }
+            { const uint32_t bt = ld(&Q->beat); if (bt != beat_seen) { beat_seen = bt; w = 0u; } }
+            if (++w > kSpinLimit) { add(&Q->failed, 1u); pubr = rs; break; }   // (gives up: the launch is reported as failed)
+            __builtin_amdgcn_s_sleep(2);
+          }
         }
+        pubr = (uint32_t)__builtin_amdgcn_readfirstlane((int)pubr);
         if (back) {
           const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(bm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bm, 0u));
           uint32_t cw2 = 0u, cw3 = 0u;
@@ -2817,14 +2906,7 @@ __device__ __forceinline__ void assist_body(const Geom& g_arg, const DetGrid& d_
             draw_block(seed, first + (uint64_t)r.offset(), r.j >> 1, r.stream(), wv);
             cw2 = wv[2]; cw3 = wv[3];
           }
-          uint4* dst = resume_q + 4 * ((pubr + rank) & (kResumeCap - 1));
-          const unsigned long long px = (unsigned long long)__double_as_longlong(r.p.x), py = (unsigned long long)__double_as_longlong(r.p.y),
-                                   pz = (unsigned long long)__double_as_longlong(r.p.z), vx = (unsigned long long)__double_as_longlong(r.v.x),
-                                   vy = (unsigned long long)__double_as_longlong(r.v.y), vz = (unsigned long long)__double_as_longlong(r.v.z);
-          dst[0] = make_uint4((uint32_t)px, (uint32_t)(px >> 32), (uint32_t)py, (uint32_t)(py >> 32));
-          dst[1] = make_uint4((uint32_t)pz, (uint32_t)(pz >> 32), (uint32_t)vx, (uint32_t)(vx >> 32));
-          dst[2] = make_uint4((uint32_t)vy, (uint32_t)(vy >> 32), (uint32_t)vz, (uint32_t)(vz >> 32));
-          dst[3] = make_uint4(r.ido | (r.tgt ? IDO_TARGET : 0u), r.j, cw2, cw3);
+          ray_pack(resume_q + 4 * ((pubr + rank) & (kResumeCap - 1)), r, cw2, cw3);
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         if (lane == 0) add(&Q->resume_pub, cnt);

@@ -138,3 +138,35 @@ def test_long_idle_assist_wave_is_not_a_failure(isx, orc):
     assert np.array_equal(gh, oh)
     _same(gst, ost)
     assert gst.wall_hits > 20_000 * n
+
+
+def test_the_last_rays_of_a_launch_change_hands_without_changing_results(isx, orc):
+    """Round 4: once a launch's ray queue is dry, a tracer wave that is down to a few rays hands them to the waves of its workgroup
+    that stay (resume ring, now with several producers) and leaves.  Launches in which that end game is most of the launch --
+    few rays per wave, long-lived rays (reflectance 1: ~144 bounces, the longest of a launch thousands), every workgroup shape,
+    one workgroup or many -- must give the oracle's map and census, bit for bit; so must the sinks that share the trace kernels."""
+    def cfg(mod, rho, chord=0):
+        c = mod.default_config()
+        c.reflectance = rho; c.max_points = 10000; c.trace_mode = chord
+        return c
+    try:
+        for rho, n in ((1.0, 30_000), (0.99, 90_000)):
+            for chord in (0, 1):
+                oh, ost = orc.fluxmap(cfg(orc, rho, chord), n, SEED, 17)
+                for block, grid in ((768, 0), (768, 1), (128, 2), (256, 5), (448, 0)):
+                    isx.set_option("assist_block", block); isx.set_option("grid_blocks", grid)
+                    gh, gst = isx.fluxmap(cfg(isx, rho, chord), n, SEED, 17)
+                    assert np.array_equal(gh, oh), (rho, chord, block, grid)
+                    _same(gst, ost)
+        _reset(isx)
+        c, o = _brdf(isx), _brdf(orc)
+        gh, gst = isx.fluxmap(c, 40_000, SEED, 3)
+        oh, ost = orc.fluxmap(o, 40_000, SEED, 3)
+        assert np.array_equal(gh, oh)
+        _same(gst, ost)
+        gp, gpst = isx.fluxmap_per_position(cfg(isx, 1.0), 3, SEED)
+        op, opst = orc.fluxmap_per_position(cfg(orc, 1.0), 3, SEED)
+        assert np.array_equal(gp, op)
+        _same(gpst, opst)
+    finally:
+        _reset(isx)

@@ -32,7 +32,7 @@ def run_assist(name, fn, n_rays, steps=6):
            "drain_trip_share (queue dry)": d[14] / trips, "lanes_running_in_drain_trips": d[15] / max(d[14], 1),
            "lanes_running_outside_drain": (d[8] - d[15]) / max(trips - d[14], 1),
            "hand_overs_refused_per_trip": d[10] / trips, "rays_taken_back_per_trip": d[11] / trips, "rays_ended_in_tracers_per_trip": d[12] / trips,
-           "end_of_launch_wait_polls": d[13],
+           "end_of_launch_wait_polls": d[13], "waves_that_gave_their_last_rays_away": d[6], "rays_given_away_per_such_wave": d[5] / max(d[6], 1),
            "assist_wave": {"share_of_all_wave_cycles": assist_cyc / (assist_cyc + tracer_cyc), "at_work_share_of_its_cycles": a[1] / max(assist_cyc, 1),
                            "batches_per_ray": a[2] / n_rays, "rays_per_batch (of 64 lanes)": a[3] / max(a[2], 1),
                            "hand_overs_per_ray": a[3] / n_rays, "sent_to_the_back_of_the_queue_per_ray": a[4] / n_rays,
