@@ -707,7 +707,7 @@ int collect_stats(isx_stats* out) {
   S.ev_used = 0;
   unsigned long long h[8];
   HIPCHK(hipMemcpy(h, S.d_stats, sizeof(h), hipMemcpyDeviceToHost));
-  HIPCHK(hipMemset(S.d_stats, 0, sizeof(h)));
+  HIPCHK(hipMemsetAsync(S.d_stats, 0, sizeof(h), S.stream));   // (ahead of whatever this stream launches next: no second blocking call)
   // stats[7]: a wave of an assist-wave trace kernel gave up a bounded wait (its results are incomplete): never seen, never silent
   if (h[7] != 0) { S.last_hip = (int)hipErrorLaunchFailure; return ISX_ERR_HIP; }
   if (out) {

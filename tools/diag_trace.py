@@ -15,8 +15,10 @@ REGIONS = ["refill", "step0_search", "generic_flush", "step0_interact", "steps_1
 def run_assist(name, fn, n_rays, steps=6):
     """the trace kernels with an assist wave (assist_body): where the lanes of the launch go.
     lane-cycles of the kernel = (tracer + assist) wave cycles x 64; useful = a lane with a live ray inside a bounce step."""
-    isx.set_option("bin_mode", 2)
-    diag(); st = fn(); d = diag()
+    if name != "discs":
+        isx.set_option("bin_mode", 2)
+        diag()
+    st = fn(); d = diag()
     isx.set_option("bin_mode", 1)
     cyc = d[:4]; trips = d[7]; a = d[16:]
     live_steps = d[4]                      # lanes that attempted a bounce, summed over the steps of all trips
@@ -66,6 +68,22 @@ for which in (sys.argv[1:] or ["flux"]):
     c = isx.default_config()
     if which == "brdf":
         c.source_model = isx.SOURCE_BRDF; c.roughness_rad = 0.5; c.reflectance = 1.0; c.max_points = 10000; c.box_half = 200.0
+    if which == "discs":   # BASELINE configs[3]: 362 disc positions share 1e7 rays (shell 100.1-105, reflectance 1)
+        import math
+        discs = []
+        for th in np.arange(-45.0, 45.0 + 1e-9, 0.5):
+            for ph in (0.0, 180.0):
+                t_, p_ = math.radians(th), math.radians(ph)
+                x, y, z = 200 * math.sin(t_) * math.cos(p_), 200 * math.sin(t_) * math.sin(p_), -200 * math.cos(t_)
+                rot = -math.atan2(math.sqrt(x * x + y * y), -100 - z)
+                discs.append([x, y, z, math.sin(rot), 0.0, math.cos(rot)])
+        c.r_out = 105.0; c.reflectance = 1.0; c.roughness_rad = 0.0; c.max_points = 10000; c.box_half = 200.0; c.src[2] = -80.0
+        n = 10_000_000
+        diag()
+        st = isx.disc_sweep(c, np.array(discs), 5.0, 0.1, n, 7)[1]
+        class _S: pass
+        run_assist(which, lambda: st, n, int(os.environ.get("ISX_STEPS", "6")))
+        continue
     if which == "perpos":
         run(which, lambda: isx.fluxmap_per_position(c, 2000, 5)[1], 2000 * 16200)
     else:
