@@ -90,15 +90,18 @@ __device__ __forceinline__ V3 axpy(double t, const V3& v, const V3& p) {
 }
 
 // ---------------------------------------------------------------- Philox4x32-10
+__device__ __forceinline__ uint32_t xor3(uint32_t a, uint32_t b, uint32_t c) { return (uint32_t)__builtin_amdgcn_bitop3_b32(a, b, c, 0x96); }
 __device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0,
                                               uint32_t k1, uint32_t w[4]) {
 #pragma unroll
   for (int r = 0; r < 10; ++r) {
     const uint64_t p0 = (uint64_t)0xD2511F53u * c0;
     const uint64_t p1 = (uint64_t)0xCD9E8D57u * c2;
-    const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0;
+    // (the two three-way XORs of a round as ONE v_bitop3_b32 each -- truth table 0x96 = a ^ b ^ c; hipcc leaves them as two v_xor_b32
+    //  when the key is a scalar: 40 -> 20 instructions per block, 13 % -> 7 % of the trace kernel's VALU stream)
+    const uint32_t n0 = xor3((uint32_t)(p1 >> 32), c1, k0);
     const uint32_t n1 = (uint32_t)p1;
-    const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
+    const uint32_t n2 = xor3((uint32_t)(p0 >> 32), c3, k1);
     const uint32_t n3 = (uint32_t)p0;
     c0 = n0; c1 = n1; c2 = n2; c3 = n3;
     k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
@@ -491,7 +494,9 @@ __device__ __forceinline__ V3 surface_normal(const Hot& h, const G& g, int kind,
 // point T is sampled directly: no direction, no orthonormal basis, no intersection.  Same Philox words as the
 // explicit bounce (a -> z, b -> absorb + azimuth).  Returns false if absorbed.
 // z of a uniform point of the unit sphere from a Philox word: 1 - 2 (w + 1/2) 2^-32 (every operation exact)
-__device__ __forceinline__ double sphere_z(uint32_t w) { return fma(-2.0, ((double)w + 0.5) * 0x1.0p-32, 1.0); }
+// (as ONE fused operation on the converted word: 1 - 2^-32 - w 2^-31 = (2^32 - 1 - 2w) / 2^32 has at most 33 significant bits, so
+//  it is the same real number, exactly represented, as fma(-2, (w + 0.5) 2^-32, 1) -- the oracle's expression -- two instructions less)
+__device__ __forceinline__ double sphere_z(uint32_t w) { return fma((double)w, sconst(-0x1.0p-31), sconst(1.0 - 0x1.0p-32)); }
 __device__ __forceinline__ bool interact_chord(const Hot& h, V3& T, uint32_t wa, uint32_t wb) {
   if (!((unsigned long long)wb < h.rho_thr)) return false;   // u01(wb) < rho, decided on the integer
   const double zz = sphere_z(wa);

@@ -1772,13 +1772,15 @@ __device__ __forceinline__ void ray_start(const G& g, Ray& r, uint32_t ido) {
 // Second half of a step, once the boundary (kind, q) is known: advance, interact.
 // CH: 0 explicit bounces only, 1 chord identity for every eligible bounce (compile time), 2 decided by h.chord.
 // Returns 0 while running, else the end status of the CURRENT trace.
-template <bool KEEP_PREV, bool LEAN, int CH, int PH = PH_DIRECT, class G>
+// SET_ON = false (the tracer waves of assist_body, which only ever arrive on the inner sphere and tell a fresh ray by its
+// interaction count): Ray::on is not maintained -- one move and one compare less per bounce.
+template <bool KEEP_PREV, bool LEAN, int CH, int PH = PH_DIRECT, bool SET_ON = true, class G>
 __device__ __forceinline__ int ray_arrive(const Hot& h, const G& g, Ray& r, uint64_t seed, uint64_t id_base, int kind, const V3& q) {
   const uint64_t rid = id_base + (uint64_t)r.offset();
   if (KEEP_PREV) r.prev = r.p;
   r.p = q;
   if (kind == K_BOX) { r.on = K_BOX; return ST_EXITED; }
-  r.on = kind;
+  if (SET_ON) r.on = kind;
   bool alive;
   uint32_t wa, wb;
   bounce_words<PH>(seed, rid, r.j, r.stream(), r.cw, wa, wb);
@@ -2576,14 +2578,16 @@ __device__ __forceinline__ void assist_body(const Geom& g_arg, const DetGrid& d_
       ISX_TD_MARK(0);
       ISX_TD_ADD(7, 1); ISX_TD_ADD(8, __popcll(__ballot(run))); ISX_TD_ADD(9, __popcll(__ballot(hand)));
       // ---- kStepsPerTrip bounces off the inner sphere per live lane (rule S1'); anything else is the assist wave's
-      int pend = 0;
+      // (the end of a ray as two flags -- lane masks in scalar registers -- instead of a status word per lane; a tracer lane's ray
+      //  sits on the inner sphere unless it is fresh, so Ray::on is neither read nor written in the steps)
+      bool ended = false, susp = false;
       auto arrive = [&](const V3& q, auto ph) {
-        const int st = ray_arrive<false, LEAN, CH, decltype(ph)::value>(h, g, r, seed, first, K_INNER, q);
-        if (st != 0) { run = false; pend = st; }
+        const int st = ray_arrive<false, LEAN, CH, decltype(ph)::value, false>(h, g, r, seed, first, K_INNER, q);
+        if (st != 0) { run = false; ended = true; susp = st == ST_SUSPENDED; }
       };
       auto hot_search = [&](V3& q) -> bool {
         if (CH != 0 && r.tgt) return chord_arrive<true>(h, r, q);
-        return next_hit_s1<false>(h, g, r.p, r.v, r.on, q);
+        return next_hit_s1<false>(h, g, r.p, r.v, K_INNER, q);
       };
       if (next == kDry) { ISX_TD_ADD(14, 1); ISX_TD_ADD(15, __popcll(__ballot(run))); }   // (-DISX_DIAG: trips after the launch's queue ran dry)
       {
@@ -2591,7 +2595,7 @@ __device__ __forceinline__ void assist_body(const Geom& g_arg, const DetGrid& d_
         bool arrived = false;
         ISX_TD_ADD(4, __popcll(__ballot(run)));   // (-DISX_DIAG: lanes that attempt a bounce in this step)
         if (run) {
-          const bool fresh = r.on == K_NONE && r.j == 0u && !r.scattered();
+          const bool fresh = r.j == 0u && !r.scattered();   // (a ray that returns from the assist wave has interactions behind it)
           if (fresh) {
             if (g.q0_ok) { q.x = g.q0[0]; q.y = g.q0[1]; q.z = g.q0[2]; arrived = true; }
             else { hand = true; run = false; }
@@ -2612,14 +2616,14 @@ __device__ __forceinline__ void assist_body(const Geom& g_arg, const DetGrid& d_
       });
       ISX_TD_MARK(1);
       // ---- rays that ended on the inner sphere (absorbed, suspended): census, or the BRDF re-scatter of a primary
-      if (RESC && pend != 0 && h.source_model == 1 && !r.scattered()) {
+      if (RESC && ended && h.source_model == 1 && !r.scattered()) {
         n_wall += r.j;
+        r.on = K_INNER;                  // (a primary ends on the inner sphere here: the re-scattered ray starts there and runs on)
         ray_rescatter(g, r, seed, first);
-        if (r.on == K_INNER) run = true; else hand = true;   // (a primary ends on the inner sphere here, so: run)
-        pend = 0;
+        run = true;
+        ended = false; susp = false;
       }
       {
-        const bool ended = pend != 0;
         if (ended) {
           n_wall += r.j;
           if (n_wall > 0x7fffffffu) { atomicAdd(&sstat[6], (unsigned long long)n_wall); n_wall = 0; }
@@ -2627,7 +2631,7 @@ __device__ __forceinline__ void assist_body(const Geom& g_arg, const DetGrid& d_
         const unsigned long long me = __ballot(ended);
         if (me) {
           n_ended += (uint32_t)__popcll(me);
-          n_susp += (uint32_t)__popcll(__ballot(pend == ST_SUSPENDED));
+          n_susp += (uint32_t)__popcll(__ballot(susp));
           ISX_TD_ADD(12, __popcll(me));
         }
       }
@@ -2651,7 +2655,8 @@ __device__ __forceinline__ void assist_body(const Geom& g_arg, const DetGrid& d_
         if (ok) {
           if (hand) {
             const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(hm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)hm, 0u));
-            ray_pack(pend_q + 4 * ((base + rank) & (kPendCap - 1)), r, (uint32_t)r.on, 0u);
+            // (the surface the ray sits on: none for a fresh ray -- Geom::q0_ok = 0 --, else the inner sphere)
+            ray_pack(pend_q + 4 * ((base + rank) & (kPendCap - 1)), r, (r.j == 0u && !r.scattered()) ? (uint32_t)K_NONE : (uint32_t)K_INNER, 0u);
             hand = false;
           }
           __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
