@@ -137,13 +137,15 @@ constexpr int kBlock = ISX_BLOCK;
 #define ISX_ATOM_BRANCH 0
 #endif
 #ifndef ISX_ASSIST_MIN
-#define ISX_ASSIST_MIN 48     // the assist wave waits for this many queued rays ... (measured: 16: 11.69 ms, 32: 11.50, 48: 11.34, 56: 11.44, 64: 11.48)
+#define ISX_ASSIST_MIN 64     // the assist wave waits for this many queued rays ... (round 3, trace kernel of 5e7 rays: 16: 11.69 ms, 32: 11.50, 48: 11.34,
+                              // 56: 11.44, 64: 11.48; round 4, after the bounce got 10 % shorter: 40: 10.40, 48: 10.36, 64: 10.32)
 #endif
 #ifndef ISX_ASSIST_LAZY
 #define ISX_ASSIST_LAZY 128   // ... for at most this many polls (1024: 12.5 ms)
 #endif
 #ifndef ISX_STEPS
-#define ISX_STEPS 6
+#define ISX_STEPS 8           // (round 1: 4 / 6 / 8: -3 % / best / -1 %; round 4, with the per-trip bookkeeping of the queues and a shorter
+                              //  bounce: 4: 10.74 ms, 6: 10.36, 8: 10.18, 10: 10.20 -- and every other configuration 1-4 % faster at 8)
 #endif
 constexpr int kStepsPerTrip = ISX_STEPS;   // bounces attempted per trip of the persistent loop
 #if ISX_WAVES_PER_EU > 0

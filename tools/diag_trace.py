@@ -12,7 +12,7 @@ def diag():
     assert L.isx_diag_read(a) == 0
     return np.array(a[16:], dtype=np.float64)   # [0..15] the tracer waves' (persistent_body's) slots, [16..31] the assist wave's
 REGIONS = ["refill", "step0_search", "generic_flush", "step0_interact", "steps_1..N-1", "census_rescatter", "sink"]
-def run_assist(name, fn, n_rays, steps=6):
+def run_assist(name, fn, n_rays, steps=8):
     """the trace kernels with an assist wave (assist_body): where the lanes of the launch go.
     lane-cycles of the kernel = (tracer + assist) wave cycles x 64; useful = a lane with a live ray inside a bounce step."""
     if name != "discs":
@@ -82,7 +82,7 @@ for which in (sys.argv[1:] or ["flux"]):
         diag()
         st = isx.disc_sweep(c, np.array(discs), 5.0, 0.1, n, 7)[1]
         class _S: pass
-        run_assist(which, lambda: st, n, int(os.environ.get("ISX_STEPS", "6")))
+        run_assist(which, lambda: st, n, int(os.environ.get("ISX_STEPS", "8")))
         continue
     if which == "perpos":
         run(which, lambda: isx.fluxmap_per_position(c, 2000, 5)[1], 2000 * 16200)
@@ -92,4 +92,4 @@ for which in (sys.argv[1:] or ["flux"]):
             isx.set_option("assist", 0)
             run(which, lambda: isx.fluxmap(c, n, 5)[1], n)
         isx.set_option("assist", 1)
-        run_assist(which, lambda: isx.fluxmap(c, n, 5)[1], n, int(os.environ.get("ISX_STEPS", "6")))
+        run_assist(which, lambda: isx.fluxmap(c, n, 5)[1], n, int(os.environ.get("ISX_STEPS", "8")))
