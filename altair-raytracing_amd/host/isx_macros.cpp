@@ -114,22 +114,18 @@ static bool file_exists(const std::string& p) {
   return true;
 }
 
+// never overwrite (fluxAtObserverOptimize.C:336-387: the name the macros export; the behaviour is the contract): the first of
+// <path>, <stem>_1<ext>, <stem>_2<ext>, ... that does not exist, the extension being whatever follows the last '.' of the file part
 std::string getUniqueFilename(const std::string& basePath) {
   if (!file_exists(basePath)) return basePath;
-  std::string directory, filename;
-  const size_t lastSlash = basePath.find_last_of("/\\");
-  if (lastSlash != std::string::npos) {
-    directory = basePath.substr(0, lastSlash + 1);
-    filename = basePath.substr(lastSlash + 1);
-  } else {
-    filename = basePath;
-  }
-  const size_t lastDot = filename.find_last_of('.');
-  const std::string stem = lastDot != std::string::npos ? filename.substr(0, lastDot) : filename;
-  const std::string ext = lastDot != std::string::npos ? filename.substr(lastDot) : "";
-  for (int counter = 1;; ++counter) {
-    const std::string cand = directory + stem + "_" + std::to_string(counter) + ext;
-    if (!file_exists(cand)) return cand;
+  const size_t cut = basePath.find_last_of("/\\");
+  const size_t name_at = cut == std::string::npos ? 0 : cut + 1;     // where the file part starts
+  const size_t dot = basePath.find_last_of('.');
+  const size_t ext_at = (dot != std::string::npos && dot >= name_at) ? dot : basePath.size();
+  const std::string head = basePath.substr(0, ext_at), tail = basePath.substr(ext_at);
+  for (int k = 1;; ++k) {
+    const std::string candidate = head + "_" + std::to_string(k) + tail;
+    if (!file_exists(candidate)) return candidate;
   }
 }
 

@@ -173,7 +173,6 @@ def test_two_row_walk_never_counts_a_bin_twice(isx, geo):
         _reset(isx)
 
 
-@pytest.mark.gpu
 def test_per_position_sinks_with_and_without_the_assist_wave(isx, orc):
     """The per-position map (fluxAtObserverOptimize.C:542-579, also twofold) and the per-position disc sweep
     (integratingSphereDetectorSweep.C:54-77) run with an assist wave per workgroup by default: the one exact test per exiting
