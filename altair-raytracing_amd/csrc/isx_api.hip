@@ -510,7 +510,6 @@ int enqueue(int sink, const isx_config* c, uint64_t n, uint64_t seed, uint64_t f
   // disc-binning kernel (lane = segment, the discs one after the other)
   // (a disc list whose histogram + cluster table + per-wave lists exceed the workgroup's LDS -- above ~16 000 discs on gfx950 --
   //  takes the fused SINK_DISC kernel below, which needs the histogram only)
-  constexpr int kDiscBinBlock = 512;
   const size_t lds_disc_bin = (((size_t)d.nbins * 4 + 15) & ~(size_t)15) + (size_t)g_disc_clusters.n_clusters * 16 +
                               (d.nbins <= kDiscsInLds ? (size_t)d.nbins * 48 + (size_t)((d.nbins + 1) & ~1) * 4 : 0) +
                               (size_t)(kDiscBinBlock / 64) * (64 * 7 + kPairCap / 2) * sizeof(double);

@@ -1069,15 +1069,27 @@ __device__ __forceinline__ void push_slots(const D& d, uint32_t* __restrict__ hi
   }
 }
 
-// What the two caps of a line share (prep_record's construction and conditions: same formulas, same margins).
+// What the two caps of a line share.  Every detector centre c the line can hit lies within rho of it (the disc of radius rho about c
+// holds a point of the line), i.e. on the stretch of S(O,R) inside the tube of radius rho about the line.  With H the foot of O on the
+// line, h = |H|, eta = h/R, kappa = rho/R and c^ = a h^ + b V + e u (u = V x h^), the tube is (a - eta)^2 + e^2 <= kappa^2; on the side
+// b > 0 it meets the plane of the line and O between A1 = (h + rho) h^ + smin V and A2 = (h - rho) h^ + smx V, smin = sqrt(R^2 - (h +
+// rho)^2), smx = sqrt(R^2 - (h - rho)^2).  The cap about their bisector m^ that passes through both holds the whole stretch: for a
+// fixed `a` the point of the stretch farthest from m^ = (cm, sm, 0), sm > 0, has the largest e allowed (the smallest b), there
+// b^2 = 1 - kappa^2 + eta^2 - 2 eta a, and cos(distance) = a cm + sm sqrt(1 - kappa^2 + eta^2 - 2 eta a) is concave in a, so its minimum
+// over a in [eta - kappa, eta + kappa] is at an end: A1 or A2, both at the cap's rim.  m^ is the direction of A1 + A2 = 2 H + (smin +
+// smx) V, i.e. of the line's point at parameter sM = (smin + smx)/2 from the foot, and |A2 - A1|^2 = 4 rho^2 + (smx - smin)^2 =
+// 4 R^2 sin^2 w.  (Until round 4 the cap was drawn about the piercing point F with the chord sqrt(ext^2 + rho^2), ext the longer of
+// the two stretches of the LINE inside the tube's ends: the same for lines through O, up to twice the radius for lines that pass O at
+// 0.5-0.8 R -- a fifth of the BRDF source's candidates.)  Binary32 with slack: |A2 - A1|^2 takes 1e-4 relative + 4e-3 cm^2, cos w
+// another 2e-6; the directions carry the roundings that cap_rows / prep_cols' slack terms cover, as before.
 struct CapShared {
-  double wv;         // line parameter of the foot of O, negated: the piercing points are at +-sF - wv
-  float sF, ch, ch2;
-  int kind;          // 0 the line has caps, -1 no caps: grazing line (box windows), -2 the line cannot hit anything
+  double wv;              // line parameter of the foot of O, negated: the caps' centres are the directions of the points at +-sM - wv
+  float sM, iL, cosw;     // (smin + smx)/2, 1/|H + sM V|, cos w
+  int kind;               // 0 the line has caps, -1 no caps: grazing line, -2 the line cannot hit anything
 };
 __device__ __forceinline__ CapShared prep_shared(const GridConst& k, const V3& P, const V3& V) {
   CapShared o;
-  o.wv = 0.0; o.sF = o.ch = o.ch2 = 0.f; o.kind = -1;
+  o.wv = 0.0; o.sM = o.iL = o.cosw = 0.f; o.kind = -1;
   const double wz = P.z - (double)k.portz;
   const double wv = fma(P.x, V.x, fma(P.y, V.y, wz * V.z));
   const double hx = fma(-wv, V.x, P.x), hy = fma(-wv, V.y, P.y), hz = fma(-wv, V.z, wz);
@@ -1087,39 +1099,51 @@ __device__ __forceinline__ CapShared prep_shared(const GridConst& k, const V3& P
   const float a1 = dO + k.rho;
   if (dO - k.rho > 1.001f * k.Rf) { o.kind = -2; return o; }
   if (!(a1 < 0.999f * k.Rf)) return o;
-  const float sF = sqrt_cull(R2 - dO2);
-  const float smin = sqrt_cull(R2 - a1 * a1);
-  const float a0 = fmaxf(0.f, dO - k.rho);
-  const float smax = sqrt_cull(R2 - a0 * a0);
-  const float ext = fmaxf(sF - smin, smax - sF);
-  const float ch2 = fmaf(ext, ext, k.rho * k.rho) * 1.0001f + 1e-3f;
-  if (!(4.0f * (R2 - dO2) > 4.04f * ch2)) return o;
-  o.wv = wv; o.sF = sF; o.ch2 = ch2; o.ch = sqrt_cull(ch2); o.kind = 0;
+  const float am = dO - k.rho;
+  const float smin = sqrt_cull(fmaf(-a1, a1, R2));
+  const float smx = sqrt_cull(fmaf(-am, am, R2));
+  const float sM = 0.5f * (smin + smx), ds = smx - smin;
+  const float d2 = fmaf(ds, ds, 4.0f * k.rho * k.rho) * 1.0001f + 4e-3f;
+  const float iR = rcp_cull(k.Rf);
+  const float cosw = sqrt_cull(fmaxf(0.f, fmaf(-0.25f * d2, iR * iR, 1.0f))) - 2e-6f;
+  const float iL = __builtin_amdgcn_rsqf(fmaf(sM, sM, dO2));
+  const float sinw = sqrt_cull(fmaxf(0.f, fmaf(-cosw, cosw, 1.0f)));
+  // caps well apart (their centres are 2 asin(sM / L) apart as seen from O) and narrower than 60 degrees, or the line is taken as a
+  // grazing line (a cap about h^ and a band: right for any line)
+  if (!(cosw > 0.5f && sM * iL > fmaf(sinw, 1.01f, 1e-3f))) return o;
+  o.wv = wv; o.sM = sM; o.iL = iL; o.cosw = cosw; o.kind = 0;
   return o;
 }
-// z of the piercing point of side `side` (0: the larger line parameter), and whether its cap reaches detector rows at all
-__device__ __forceinline__ bool cap_is_low(const GridConst& k, const CapShared& sh, const V3& P, const V3& V, int side) {
-  const double s0 = side == 0 ? ((double)sh.sF - sh.wv) : (-(double)sh.sF - sh.wv);
-  return !((float)fma(s0, V.z, P.z) - sh.ch > k.portz);
+// chord^2 from a cap's centre ON the sphere to its rim: 2 R^2 (1 - cos w)
+__device__ __forceinline__ float cap_chord2(const GridConst& k, const CapShared& sh) { return 2.0f * k.Rf * k.Rf * (1.0f - sh.cosw); }
+// the centre of the cap of side `side` (0: the larger line parameter) as a point of the line: (x, y, z - portz), binary32
+__device__ __forceinline__ void cap_centre(const GridConst& k, const CapShared& sh, const V3& P, const V3& V, int side, float& mx, float& my,
+                                           float& mz) {
+  const double s0 = side == 0 ? ((double)sh.sM - sh.wv) : (-(double)sh.sM - sh.wv);
+  mx = (float)fma(s0, V.x, P.x); my = (float)fma(s0, V.y, P.y); mz = (float)(fma(s0, V.z, P.z) - (double)k.portz);
 }
-// Can a bin lie in the row ranges (cap_rows) of BOTH caps of the line?  The construction keeps the piercing points more than 2.01
-// chords apart, so the caps themselves are disjoint -- but a row range carries slack, and on a coarse grid the two ranges of one
-// column can meet (tools/soak_cull.py found exactly that on 2- and 3-row grids).  Along the meridian of column j the angular
-// distance D to the cap's piercing point obeys cos D = rho cos(theta - tc), rho = sqrt(a^2 + b^2) <= 1; cap_rows hands out the rows
-// with |theta_i - tc| <= acos(cos w / rho) + s, s <= 2.5e-3 + 1e-4 (acos_cull) + 2e-5 (atan2_cull) + 1e-3 rows (<= 1.6e-3 rad on a
-// one-row grid) <= 4.3e-3, with cos w and rho good to 3e-6 (the 2e-6 taken off cos w, binary32 rounding): for those
-// cos D >= cos w - s sqrt(rho^2 - cos^2 w) - s^2/2 - 3e-6 >= cos w - s sin w - 1.3e-5 >= cos(w + 5e-3), i.e. every row handed out has
-// its centre within w + 5e-3 rad of the piercing point.  A common bin therefore needs the piercing points within 2 w + 1e-2 of each
-// other as seen from O; they are 2 asin(sF / R) apart.  Hence: no common bin if sF / R > sin(w + 5e-3), for which
-// sF / R > sin w + 5e-3 suffices while w + 5e-3 < pi/2.  Evaluated in binary32 with its own margin (8e-3, 1e-4 relative; cos w > 0.05).
-// A line that fails the test AND has its second cap among the detector rows takes the box windows for the whole line (bin_culled:
-// one pass over the tube around the line, every bin at most once) instead of its two caps: rare (none in any BASELINE
-// configuration: there sF / R >= 0.6 against sin w ~ 0.2), correct for any line.
+// whether the cap of side `side` reaches detector rows at all (its lowest point lies below the port plane)
+__device__ __forceinline__ bool cap_is_low(const GridConst& k, const CapShared& sh, const V3& P, const V3& V, int side) {
+  float mx, my, mz;
+  cap_centre(k, sh, P, V, side, mx, my, mz);
+  return !(mz * sh.iL * k.Rf - sqrt_cull(cap_chord2(k, sh)) > 0.f);
+}
+// Can a bin lie in the row ranges (cap_rows) of BOTH caps of the line?  prep_shared keeps the caps' centres more than 2.02 sin w
+// apart (as sines of half their distance seen from O), so the caps themselves are disjoint -- but a row range carries slack, and on a
+// coarse grid the two ranges of one column can meet (tools/soak_cull.py found exactly that on 2- and 3-row grids).  Along the
+// meridian of column j the angular distance D to the cap's centre obeys cos D = rho cos(theta - tc), rho = sqrt(a^2 + b^2) <= 1;
+// cap_rows hands out the rows with |theta_i - tc| <= acos(cos w / rho) + s, s <= 2.5e-3 + 1e-4 (acos_cull) + 2e-5 (atan2_cull) + 1e-3
+// rows (<= 1.6e-3 rad on a one-row grid) <= 4.3e-3, with cos w and rho good to 3e-6 (the 2e-6 taken off cos w, binary32 rounding):
+// for those cos D >= cos w - s sqrt(rho^2 - cos^2 w) - s^2/2 - 3e-6 >= cos w - s sin w - 1.3e-5 >= cos(w + 5e-3), i.e. every row
+// handed out has its centre within w + 5e-3 rad of the cap's centre.  A common bin therefore needs the centres within 2 w + 1e-2 of
+// each other as seen from O; they are 2 asin(sM / L) apart, L = |H + sM V|.  Hence: no common bin if sM / L > sin(w + 5e-3), for
+// which sM / L > sin w + 5e-3 suffices while w + 5e-3 < pi/2.  Evaluated in binary32 with its own margin (8e-3, 1e-4 relative;
+// cos w > 0.05).  A line that fails the test AND has its second cap among the detector rows is taken as a grazing line (one cap about
+// h^ and the band: every bin at most once) instead of its two caps: rare (none in any BASELINE configuration: there sM / L >= 0.6
+// against sin w ~ 0.2), correct for any line.
 __device__ __forceinline__ bool caps_may_touch(const GridConst& k, const CapShared& sh) {
-  const float iR = rcp_cull(k.Rf);
-  const float cosw = fmaf(-0.5f * sh.ch2, iR * iR, 1.0f) - 2e-6f;   // (prep_cols' cos w)
-  const float sinw = sqrt_cull(fmaxf(0.f, fmaf(-cosw, cosw, 1.0f)));
-  return !(cosw > 0.05f && sh.sF * iR > fmaf(sinw, 1.0001f, 8e-3f));
+  const float sinw = sqrt_cull(fmaxf(0.f, fmaf(-sh.cosw, sh.cosw, 1.0f)));
+  return !(sh.cosw > 0.05f && sh.sM * sh.iL > fmaf(sinw, 1.0001f, 8e-3f));
 }
 // The cap of side `side` of a line with caps as the ROW producer wants it (prep_record's and bin_culled's formulas and margins):
 // own.{smax, smin, vxy, avz} carry {Fz, AF, jf, ch2} of the CapWin (the producer's per-owner data is one BoxLine either way),
@@ -1127,19 +1151,21 @@ __device__ __forceinline__ bool caps_may_touch(const GridConst& k, const CapShar
 __device__ __forceinline__ void cap_rows_pre(const GridConst& k, const V3& P, const V3& V, const CapShared& sh, int side, BoxLine& own,
                                              int& ilo, int& ihi) {
   ilo = 0; ihi = -1;
-  const double s0 = side == 0 ? ((double)sh.sF - sh.wv) : (-(double)sh.sF - sh.wv);
-  const float Fz0 = (float)fma(s0, V.z, P.z);
-  if (Fz0 - sh.ch > k.portz) return;                                 // cap entirely above every detector row
-  const float Fx = (float)fma(s0, V.x, P.x), Fy = (float)fma(s0, V.y, P.y);
-  const float AF2 = fmaf(Fx, Fx, Fy * Fy);
-  const float AF = sqrt_cull(AF2);
-  float phiF = atan2_cull(Fy, Fx);
+  float mx, my, mz;
+  cap_centre(k, sh, P, V, side, mx, my, mz);
+  const float ch2 = cap_chord2(k, sh), ch = sqrt_cull(ch2);
+  const float sc = sh.iL * k.Rf;                                     // the centre ON the sphere: G = O + R m^
+  const float Gz = fmaf(mz, sc, k.portz);
+  if (Gz - ch > k.portz) return;                                     // cap entirely above every detector row
+  const float Gx = mx * sc, Gy = my * sc;
+  const float AF = sqrt_cull(fmaf(Gx, Gx, Gy * Gy));
+  float phiF = atan2_cull(Gy, Gx);
   if (phiF < 0.f) phiF += 6.28318530718f;
-  const float omega = cap_angle(sh.ch, rcp_cull(k.Rf));
-  const float thF = atan2_cull(AF, k.portz - Fz0);
+  const float omega = cap_angle(ch, rcp_cull(k.Rf));
+  const float thF = atan2_cull(AF, k.portz - Gz);
   ilo = max((int)floorf((thF - omega) * k.inv_dth - 0.5f - 1e-3f), 0);
   ihi = min((int)ceilf((thF + omega) * k.inv_dth - 0.5f + 1e-3f), k.n_theta - 1);
-  own.smax = Fz0; own.smin = AF; own.vxy = phiF * k.inv_dphi - 0.5f; own.avz = sh.ch2;
+  own.smax = Gz; own.smin = AF; own.vxy = phiF * k.inv_dphi - 0.5f; own.avz = ch2;
 }
 
 // producer of isx_bin_slots_kernel: the rows of the lines of a batch that take part in one pass, packed over the lanes -- lane =
@@ -1233,13 +1259,11 @@ __device__ __forceinline__ ColPre prep_cols(const GridConst& k, int n_phi, const
   ColPre o;
   o.fx = o.fy = o.a = o.cosw = 0.f; o.jlo = 0; o.ncol = 0; o.kind = sh.kind;
   if (sh.kind != 0) return o;
-  const double s0 = side == 0 ? ((double)sh.sF - sh.wv) : (-(double)sh.sF - sh.wv);
-  const float Fz0 = (float)fma(s0, V.z, P.z);
-  if (Fz0 - sh.ch > k.portz) { o.kind = -3; return o; }              // cap entirely above every detector row
-  const float Fx = (float)fma(s0, V.x, P.x), Fy = (float)fma(s0, V.y, P.y);
-  const float iR = rcp_cull(k.Rf);
-  o.fx = Fx * iR; o.fy = Fy * iR; o.a = (k.portz - Fz0) * iR;
-  o.cosw = fmaf(-0.5f * sh.ch2, iR * iR, 1.0f) - 2e-6f;              // cos w = 1 - ch^2 / 2R^2 (a little smaller: a little wider)
+  float Fx, Fy, mz;
+  cap_centre(k, sh, P, V, side, Fx, Fy, mz);
+  if (mz * sh.iL * k.Rf - sqrt_cull(cap_chord2(k, sh)) > 0.f) { o.kind = -3; return o; }   // cap entirely above every detector row
+  o.fx = Fx * sh.iL; o.fy = Fy * sh.iL; o.a = -(mz * sh.iL);
+  o.cosw = sh.cosw;
   o.kind = 0;
   // columns: sin theta_F |sin(phi - phi_F)| <= sin w
   const float sinF = sqrt_cull(fmaf(o.fx, o.fx, o.fy * o.fy));
@@ -2974,8 +2998,17 @@ isx_trace_assist_discpos_kernel(const Geom g, const DetGrid d, const Work wk) { 
 //   2. lane = (pair, disc of the cluster): the exact test of SINK_DISC (segment_hits_tube: bounding-ball cull in binary64, then
 //      the tube) on the segment read back from wave-private LDS; a hit increments the disc's bin.
 // ~100 pairs per batch instead of 64 x 362 tests.  Same decisions, so the same counts.
-constexpr int kPairCap = 1024, kDiscsInLds = 1024;
-extern "C" __global__ void __launch_bounds__(512)
+// (LDS sets the occupancy here: with 1024 pairs per wave and 512-thread workgroups ONE workgroup fitted a CU -- 2 waves per SIMD,
+//  1.45 ms for configs[3]; 256 pairs and 256-thread workgroups: four workgroups, 4 waves per SIMD, 0.96 ms.  -D to re-tune.)
+#ifndef ISX_PAIR_CAP
+#define ISX_PAIR_CAP 256
+#endif
+#ifndef ISX_DISC_BIN_BLOCK
+#define ISX_DISC_BIN_BLOCK 256
+#endif
+constexpr int kPairCap = ISX_PAIR_CAP, kDiscsInLds = 1024, kDiscBinBlock = ISX_DISC_BIN_BLOCK;
+static_assert(kPairCap >= 128 && kPairCap % 2 == 0, "a batch adds up to 64 pairs per cluster before the list is flushed");
+extern "C" __global__ void __launch_bounds__(kDiscBinBlock)
 isx_bin_discs_kernel(const DetGrid d_arg, const Work wk) {
   extern __shared__ __align__(16) unsigned char smem[];
   uint32_t* hist = reinterpret_cast<uint32_t*>(smem);

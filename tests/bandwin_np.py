@@ -81,38 +81,45 @@ def line_slots(P, V, cfg):
     dO = sqrt_cull(dO2)
     a1 = f32(dO + rho)
     kind = -1
-    sF = ch = ch2 = f32(0)
     if dO - rho > f32(1.001) * R:
         return "far", []
+    sM = iL = ch2 = cosw = f32(0)
     if a1 < f32(0.999) * R:
-        sF = sqrt_cull(R2 - dO2)
+        # the tube of radius rho about the line meets S(O,R), in the plane of the line and O, between the points
+        # A1 = (dO + rho) h^ + smin V and A2 = (dO - rho) h^ + smx V: the cap about their bisector through both holds the whole
+        # footprint; the bisector is the direction of the line's point at parameter (smin + smx)/2 from the foot
+        am = f32(dO - rho)
         smin = sqrt_cull(R2 - a1 * a1)
-        a0 = max(f32(0), f32(dO - rho))
-        smax = sqrt_cull(R2 - a0 * a0)
-        ext = max(f32(sF - smin), f32(smax - sF))
-        ch2 = f32(f32(ext * ext + rho * rho) * f32(1.0001) + f32(1e-3))
-        if f32(4.0) * f32(R2 - dO2) > f32(4.04) * ch2:
+        smx = sqrt_cull(R2 - am * am)
+        sM = f32(f32(0.5) * f32(smin + smx))
+        ds = f32(smx - smin)
+        d2 = f32(f32(f32(4.0) * rho * rho + ds * ds) * f32(1.0001) + f32(4e-3))      # |A2 - A1|^2 = 4 R^2 sin^2 w
+        s2w = f32(f32(0.25) * d2 / R2)
+        cosw = f32(sqrt_cull(max(f32(0), f32(1) - s2w)) - f32(2e-6))
+        iL = f32(1) / sqrt_cull(f32(dO2 + sM * sM))
+        sinw = sqrt_cull(max(f32(0), f32(1) - cosw * cosw))
+        if cosw > f32(0.5) and sM * iL > sinw * f32(1.01) + f32(1e-3):
             kind = 0
+            ch2 = f32(f32(2.0) * R2 * f32(f32(1) - cosw))                              # chord^2 from the cap's centre to its rim
             ch = sqrt_cull(ch2)
     iR = f32(1) / R
     slots = []
     if kind == 0:
         def side(s):
-            s0 = (float(sF) - wv) if s == 0 else (-float(sF) - wv)
-            return s0, f32(P[2] + s0 * V[2])
-        low2 = not (side(1)[1] - ch > portz)
-        cosw = f32(f32(f32(-0.5) * ch2 * iR * iR + f32(1)) - f32(2e-6))
+            s0 = (float(sM) - wv) if s == 0 else (-float(sM) - wv)
+            return s0, f32(f32(f32(wz + s0 * V[2]) * iL) * R)                          # z - portz of the cap's centre ON the sphere
+        low2 = not (side(1)[1] - ch > 0)
         sinw = sqrt_cull(max(f32(0), f32(1) - cosw * cosw))
-        touch = not (cosw > f32(0.05) and sF * iR > sinw * f32(1.0001) + f32(8e-3))
+        touch = not (cosw > f32(0.05) and sM * iL > sinw * f32(1.0001) + f32(8e-3))
         if low2 and touch:
             kind = -1                                                   # the whole line as a grazing line
     if kind == 0:
         for s in ((0, 1) if low2 else (0,)):
-            s0, Fz0 = side(s)
-            if Fz0 - ch > portz:
+            s0, Gz = side(s)
+            if Gz - ch > 0:
                 continue
-            Fx, Fy = f32(P[0] + s0 * V[0]), f32(P[1] + s0 * V[1])
-            fx, fy, a = f32(Fx * iR), f32(Fy * iR), f32((portz - Fz0) * iR)
+            fx, fy = f32(f32(P[0] + s0 * V[0]) * iL), f32(f32(P[1] + s0 * V[1]) * iL)
+            a = f32(-f32(wz + s0 * V[2]) * iL)
             jlo, ncol = col_range(fx, fy, cosw, inv_dphi, n_phi, False)
             js = (jlo + np.arange(ncol)) % n_phi
             ilo, cnt = cap_rows(fx, fy, a, cosw, c32[js], s32[js], inv_dth, n_theta)
