@@ -91,6 +91,34 @@ def test_second_caps_never_count_a_bin_twice(isx, case):
         _reset(isx)
 
 
+@pytest.mark.parametrize("case", range(4))
+def test_caps_about_the_bisector_hold_every_hit(isx, case):
+    """Round 4: the cap of an exit line is drawn about the bisector of the two ends of the tube's footprint in the plane of the line
+    and O (prep_shared), not about the piercing point.  The lines that differ most are those that pass O at 0.4-0.9 R: the BRDF source
+    sends rays through the port in every direction, and detector spheres smaller than the port's reach make most of them such lines.
+    culled == brute force through every binning kernel, detectors from 2 % to 60 % of R, grids from coarse to fine."""
+    rng = np.random.default_rng(4300 + case)
+    try:
+        for _ in range(3):
+            c = _brdf(isx)
+            c.det_distance = float(rng.choice([25.0, 40.0, 70.0, 100.0]))
+            c.det_diameter = float(c.det_distance * 2 * rng.choice([0.02, 0.1, 0.2, 0.35, 0.6]))
+            c.n_theta = int(rng.choice([7, 45, 90, 180])); c.n_phi = int(rng.choice([6, 24, 90, 120]))
+            n = 80_000
+            _reset(isx)
+            isx.set_option("bin_mode", 0)
+            ref, rst = isx.fluxmap(c, n, SEED + case, 0)
+            isx.set_option("bin_mode", 1)
+            for slots, cols in ((1, 1), (1, 0), (0, 0)):
+                isx.set_option("bin_slots", slots); isx.set_option("bin_cols", cols)
+                h, st = isx.fluxmap(c, n, SEED + case, 0)
+                assert np.array_equal(h, ref), (c.det_distance, c.det_diameter, c.n_theta, c.n_phi, slots, cols)
+                _same(st, rst)
+            assert int(ref.sum()) > 0
+    finally:
+        _reset(isx)
+
+
 def test_disc_sweep_with_more_discs_than_the_pipeline_can_hold(isx):
     """isx_bin_discs_kernel keeps histogram + cluster table + per-wave lists in LDS; above ~16 000 discs that does not
     fit and the call must fall through to the fused SINK_DISC kernel (it returned ISX_ERR_BAD_CONFIG).  20 000 discs,
