@@ -62,6 +62,8 @@ struct State {
   int assist = 1;                               // 1: trace kernels with an assist wave per workgroup (assist_body)
   int bin_cols = 1;                             // 1 (2: the same): isx_bin_cols_kernel ((line, column) slots) where bin_slots applies; 0: row slots
   int bin_slots = 1;                            // 1: isx_bin_slots_kernel (slot queues by window length) where the grid allows it
+  int surface_pipeline = 1;                     // 1 (default): the lobe / rough-specular borders and the origin-compat hit line on the assist-wave
+                                                // pipeline (round 5); 0: round 1's fused isx_trace_bin_full_kernel
   // options
   int bin_mode = 1;
   int blocks_per_cu = 1;   // 1024-thread blocks: 16 waves/CU, 4 per SIMD
@@ -367,10 +369,21 @@ int enqueue(int sink, const isx_config* c, uint64_t n, uint64_t seed, uint64_t f
   wk.seed = seed; wk.first = first; wk.n = n; wk.hist = d_hist; wk.stats = d_stats ? d_stats : S.d_stats;
   wk.ctr = nullptr; wk.sub = 0; wk.pad = 0;
   // the lean kernel serves the headline configuration; anything else takes the full-featured variant
-  const bool lean_surface = c->lambertian && c->surface_model == ISX_SURFACE_ROBAST && c->hit_line_mode == ISX_HITLINE_LAST_SEGMENT;
+  const bool lambert = c->lambertian && c->surface_model == ISX_SURFACE_ROBAST;
+  const bool compat = c->hit_line_mode != ISX_HITLINE_LAST_SEGMENT;
+  const bool lean_surface = lambert && !compat;
   const bool lean = lean_surface && c->source_model == ISX_SOURCE_PENCIL;
   const bool chord = lean && c->trace_mode == ISX_TRACE_CHORD;
   const bool brdf = lean_surface && c->source_model == ISX_SOURCE_BRDF && c->trace_mode != ISX_TRACE_CHORD;
+  // what the assist-wave pipeline serves beyond that (round 5; `surface_pipeline` = 0: round 1's fused kernel as before): the
+  // origin-compat hit line (the assist wave writes the line the binning kernel is to see) and the two other border models with
+  // the pencil source -- the chord identity is a property of the Lambertian border, so trace_mode says nothing there
+  const bool sp = S.surface_pipeline != 0;
+  const bool p_lean = lambert && c->source_model == ISX_SOURCE_PENCIL && (!compat || sp);
+  const bool p_chord = p_lean && c->trace_mode == ISX_TRACE_CHORD;
+  const bool p_brdf = lambert && c->source_model == ISX_SOURCE_BRDF && c->trace_mode != ISX_TRACE_CHORD && (!compat || sp);
+  const bool p_lobe = sp && c->surface_model == ISX_SURFACE_LOBE && c->source_model == ISX_SOURCE_PENCIL;
+  const bool p_rough = sp && c->surface_model == ISX_SURFACE_ROBAST && !c->lambertian && c->source_model == ISX_SOURCE_PENCIL;
   // kernel variant: lean builds serve the headline surface/source configuration, the full builds everything else
   typedef void (*KernelFn)(const Geom, const DetGrid, const Work);
   const bool lean_explicit = lean && !chord;
@@ -398,10 +411,12 @@ int enqueue(int sink, const isx_config* c, uint64_t n, uint64_t seed, uint64_t f
   };
   hipEvent_t e0;
   // ---- two-kernel pipeline (lean flux maps: headline, chord mode, BRDF source): trace kernel -> exit lines in HBM -> binning kernel, chunk by chunk
-  if (sink == SINK_FLUX && (lean || brdf) && S.pipeline && S.bin_mode != 0) {
+  const bool pipe_assist = (p_lean || p_brdf || p_lobe || p_rough) && S.assist != 0;   // (the kernels without an assist wave know the lean cases only)
+  if (sink == SINK_FLUX && (lean || brdf || pipe_assist) && S.pipeline && S.bin_mode != 0) {
     // trace kernel: with an assist wave per workgroup (ISX_ASSIST_BLOCK threads; isx_kernels.hpp: assist_body) or without
     const bool assist = S.assist != 0;
-    const KernelFn rec_fn = assist ? (chord ? isx_trace_assist_chord_kernel : brdf ? isx_trace_assist_brdf_kernel : isx_trace_assist_kernel)
+    const KernelFn rec_fn = assist ? (p_lobe ? isx_trace_assist_lobe_kernel : p_rough ? isx_trace_assist_rough_kernel :
+                                      p_chord ? isx_trace_assist_chord_kernel : p_brdf ? isx_trace_assist_brdf_kernel : isx_trace_assist_kernel)
                                    : (chord ? isx_trace_rec_chord_kernel : brdf ? isx_trace_rec_brdf_kernel : isx_trace_rec_kernel);
     const size_t lds_trace = 16 + 64 + sizeof(Geom) + sizeof(DetGrid) +
                              (assist ? 16 + sizeof(AssistQueues) + (size_t)(kResumeCap + kPendCap) * 64 : 0);
@@ -446,6 +461,10 @@ int enqueue(int sink, const isx_config* c, uint64_t n, uint64_t seed, uint64_t f
         HIPCHK(hipGetLastError());
         if (traced) { HIPCHK(hipEventRecord(traced, st)); HIPCHK(hipStreamWaitEvent(sb, traced, 0)); }
         else { r = span(1, nullptr); if (r) return r; }
+        if (compat && S.bin_mode != 2) {   // ISX_HITLINE_ORIGIN_COMPAT: the lines the binning kernel is to see (isx_compat_lines_kernel)
+          hipLaunchKernelGGL(isx_compat_lines_kernel, dim3(S.cu_count * 8), dim3(256), 0, sb, S.d_rec[buf], S.d_rec_counts[buf], w2.ctr);
+          HIPCHK(hipGetLastError());
+        }
         if (S.bin_mode != 2) {       // bin_mode 2: diagnostic, trace only
           DetGrid db = d;
           db.rec_lines = S.d_rec[buf]; db.rec_counts = S.d_rec_counts[buf];
@@ -847,6 +866,7 @@ int isx_set_option(const char* key, int64_t value) {
   if (!std::strcmp(key, "assist")) { if (value < 0 || value > 1) return ISX_ERR_BAD_ARG; S.assist = (int)value; return ISX_OK; }
   if (!std::strcmp(key, "bin_cols")) { if (value < 0 || value > 2) return ISX_ERR_BAD_ARG; S.bin_cols = (int)value; return ISX_OK; }
   if (!std::strcmp(key, "bin_slots")) { if (value < 0 || value > 1) return ISX_ERR_BAD_ARG; S.bin_slots = (int)value; return ISX_OK; }
+  if (!std::strcmp(key, "surface_pipeline")) { if (value < 0 || value > 1) return ISX_ERR_BAD_ARG; S.surface_pipeline = (int)value; return ISX_OK; }
   if (!std::strcmp(key, "ray_sub")) { if (value < 0 || value > (1 << 20)) return ISX_ERR_BAD_ARG; S.ray_sub = (int)value; return ISX_OK; }
   if (!std::strcmp(key, "pipeline")) { if (value < 0 || value > 1) return ISX_ERR_BAD_ARG; S.pipeline = (int)value; return ISX_OK; }
   // (a launch addresses its rays by 30-bit offsets -- bits 30 and 31 of Ray::ido are flags in the queue records -- and counts

@@ -15,6 +15,12 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+// gfx950 (MI355X, CDNA4) is the ONLY target: the device code uses v_bitop3_b32 (xor3 below), CDNA4's 160 KiB of LDS per
+// workgroup and its packed-f32 rates.  Another --offload-arch is refused here, at the top, instead of failing somewhere in Philox.
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(__gfx950__)
+#error "libisx is written for gfx950 (MI355X) only: build with --offload-arch=gfx950"
+#endif
+
 namespace isx {
 
 struct V3 { double x, y, z; };
@@ -433,29 +439,40 @@ __device__ __forceinline__ V3 tv_setmag1(const V3& a) {
 
 // "nonLambertianFlux copy.C":31-70 (NonLambertianSurface): cos^2 lobe within 60 deg of the normal by rejection.
 // Try k of interaction j draws from Philox block 2j + (stream>>1) of stream 16+k.
-__device__ inline V3 lobe_sample(const V3 normal, uint64_t seed, uint64_t ray, uint32_t j, uint32_t stream) {
+// ONE try of the rejection loop (generateScatteredDirection's loop body, "nonLambertianFlux copy.C":45-69): the candidate direction
+// and whether it is accepted.  The local frame (w, u, v) is a function of the normal alone, so a caller that spreads the tries of
+// one interaction over several steps (the tracer waves of the lobe pipeline: one try per step and lane, isx_kernels.hpp) forms it
+// again for every try and gets the very same numbers as the loop below.
+__device__ __forceinline__ bool lobe_try(const V3& normal, uint64_t seed, uint64_t ray, uint32_t j, uint32_t stream, uint32_t k, V3& sc) {
   const double maxAngle = 60.0 * 3.14159265358979323846 / 180.0;
   const V3 w = tv_unit(normal);
   V3 yxw; yxw.x = w.z; yxw.y = 0.0; yxw.z = -w.x;  // TVector3(0,1,0).Cross(w)
   const V3 u = tv_unit(yxw);
   const V3 vv = tv_cross(w, u);
-  V3 sc = w;
-  for (uint32_t k = 0; k < 64; k++) {
-    uint32_t r[4];
-    draw_block(seed, ray, 2u * j + (stream >> 1), 16u + k, r);
-    const double theta = maxAngle * u01(r[0]);
-    double st, ct, sp, cp;
-    sincos_cw(theta, st, ct);
-    sincos2pi(u01(r[1]), sp, cp);
-    const double x = st * cp, y = st * sp, z = ct;
-    V3 t;
-    t.x = x * u.x + y * vv.x + z * w.x; t.y = x * u.y + y * vv.y + z * w.y; t.z = x * u.z + y * vv.z + z * w.z;
-    sc = tv_unit(t);
-    const double c = sc.x * normal.x + sc.y * normal.y + sc.z * normal.z;
-    const double p = c * c;
-    if (u01(r[2]) <= p) break;
-  }
+  uint32_t r[4];
+  draw_block(seed, ray, 2u * j + (stream >> 1), 16u + k, r);
+  const double theta = maxAngle * u01(r[0]);
+  double st, ct, sp, cp;
+  sincos_cw(theta, st, ct);
+  sincos2pi(u01(r[1]), sp, cp);
+  const double x = st * cp, y = st * sp, z = ct;
+  V3 t;
+  t.x = x * u.x + y * vv.x + z * w.x; t.y = x * u.y + y * vv.y + z * w.y; t.z = x * u.z + y * vv.z + z * w.z;
+  sc = tv_unit(t);
+  const double c = sc.x * normal.x + sc.y * normal.y + sc.z * normal.z;
+  const double p = c * c;
+  return u01(r[2]) <= p;
+}
+constexpr uint32_t kLobeTries = 64;   // (the reference loops for ever; the acceptance is >= 1/4 per try, so 64 misses never happen: 2^-26 per 1e9 bounces)
+// NonLambertianSurface::Reflection's hemisphere fix ("nonLambertianFlux copy.C":205-207)
+__device__ __forceinline__ void lobe_hemisphere(const V3& normal, V3& sc) {
   if (sc.x * normal.x + sc.y * normal.y + sc.z * normal.z < 0) { sc.x = -sc.x; sc.y = -sc.y; sc.z = -sc.z; }
+}
+__device__ inline V3 lobe_sample(const V3 normal, uint64_t seed, uint64_t ray, uint32_t j, uint32_t stream) {
+  V3 sc = tv_unit(normal);
+  for (uint32_t k = 0; k < kLobeTries; k++)
+    if (lobe_try(normal, seed, ray, j, stream, k, sc)) break;
+  lobe_hemisphere(normal, sc);
   return sc;
 }
 
@@ -510,12 +527,26 @@ __device__ __forceinline__ bool interact_chord(const Hot& h, V3& T, uint32_t wa,
 
 // LEAN = the configuration of the headline path (ROBAST Lambertian border, pencil source): the other surface
 // models are compiled out so their registers and code do not burden the hot kernel.
-template <bool LEAN, class G>
+// SURF: the border's model at compile time -- SURF_LAMBERT (= LEAN), SURF_LOBE, SURF_ROUGH (ROBAST's non-Lambertian border:
+// specular reflection about a normal tilted by the Gaussian roughness) -- or SURF_ANY: decided at run time from h.surface_model /
+// h.lambertian (round 1's full-featured kernels and the end-state interface).
+enum : int { SURF_ANY = -1, SURF_LAMBERT = 0, SURF_LOBE = 1, SURF_ROUGH = 2 };
+// what interact() does to a lobe / rough-specular direction before it hands it back (also the tail of the lobe pipeline's tries)
+__device__ __forceinline__ void finish_direction(const V3& n, V3& w) {
+  // into-wall fix
+  const double dn = dot3(w, n);
+  if (dn <= 0.0) w = axpy(-2.0 * dn, n, w);
+  // one Newton step towards unit length (keeps the |v| error at rounding level instead of letting it
+  // random-walk multiplicatively through hit point -> normal -> new direction; DESIGN.md §3)
+  const double k = fma(-0.5, dot3(w, w), sconst(1.5));
+  w.x *= k; w.y *= k; w.z *= k;
+}
+template <bool LEAN, int SURF = (LEAN ? SURF_LAMBERT : SURF_ANY), class G>
 __device__ __forceinline__ bool interact(const Hot& h, const G& g, int kind, const V3& q, V3& v, uint64_t seed,
                                          uint64_t ray, uint32_t j, uint32_t stream, uint32_t wa, uint32_t wb) {
   if (!((unsigned long long)wb < h.rho_thr)) return false;   // u01(wb) < rho, decided on the integer
   V3 w;
-  if (LEAN || (h.surface_model != 1 && h.lambertian)) {
+  if (SURF == SURF_LAMBERT || (SURF == SURF_ANY && h.surface_model != 1 && h.lambertian)) {
     // cosine-law re-emission about the geometric normal; roughness does not act on a Lambertian border.
     // w = n + s, s uniform on the unit sphere in WORLD coordinates (z from word a, azimuth from word b): the direction of
     // n + s follows the cosine law about n exactly; no local frame, and w stays UN-NORMALISED on the inner sphere, where
@@ -541,7 +572,7 @@ __device__ __forceinline__ bool interact(const Hot& h, const G& g, int kind, con
     return true;
   }
   const V3 n = surface_normal(h, g, kind, q);
-  if (h.surface_model == 1) {
+  if (SURF == SURF_LOBE || (SURF == SURF_ANY && h.surface_model == 1)) {
     w = lobe_sample(n, seed, ray, j, stream);
   } else {
     V3 M = n;
@@ -567,13 +598,7 @@ __device__ __forceinline__ bool interact(const Hot& h, const G& g, int kind, con
     w = axpy(d2, M, v);
   }
   // (only the lobe and rough-specular surfaces get here: the cosine emission returned above)
-  // into-wall fix
-  const double dn = dot3(w, n);
-  if (dn <= 0.0) w = axpy(-2.0 * dn, n, w);
-  // one Newton step towards unit length (keeps the |v| error at rounding level instead of letting it
-  // random-walk multiplicatively through hit point -> normal -> new direction; DESIGN.md §3)
-  const double k = fma(-0.5, dot3(w, w), sconst(1.5));
-  w.x *= k; w.y *= k; w.z *= k;
+  finish_direction(n, w);
   v = w;
   return true;
 }

@@ -1336,13 +1336,15 @@ __device__ __forceinline__ ColPre prep_band(const GridConst& k, int n_phi, const
   if (h - k.rho > 1.001f * k.Rf) return o;                           // farther than R + rho_d from O: nothing can be hit (box_line's test)
   const float rs = fmaf(k.rho, 1.001f, 2e-3f);
   const float iR = rcp_cull(k.Rf);
-  float ex, ey, ez, cosw;
+  float ex, ey, ez, cosw, kap_extra = 0.f;
   if (h > 1e-3f * k.Rf) {
     const float ih = rcp_cull(h);
     ex = Hx * ih; ey = Hy * ih; ez = Hz * ih;
     cosw = fmaxf(-1.0f, (h - rs) * iR - 4e-6f);
   } else {
-    // the line passes through O (to 0.1 % of R): any unit vector perpendicular to V serves as h^, and the cap is the whole sphere
+    // the line passes through O (to 0.1 % of R): any unit vector perpendicular to V serves as h^, and the cap is the whole sphere.
+    // H.u is then no longer 0 but anything up to h, so the band |c.u| <= rho + |H.u| is wider by h / R
+    kap_extra = h * iR * 1.0001f;
     const float ax = fabsf(Vx), ay = fabsf(Vy), az = fabsf(Vz);
     float tx = 0.f, ty = 0.f, tz = 0.f;
     if (ax <= ay && ax <= az) tx = 1.f; else if (ay <= az) ty = 1.f; else tz = 1.f;
@@ -1354,7 +1356,7 @@ __device__ __forceinline__ ColPre prep_band(const GridConst& k, int n_phi, const
   }
   o.fx = ex; o.fy = ey; o.a = -ez; o.cosw = cosw; o.kind = 0;
   bp.ux = fmaf(Vy, ez, -(Vz * ey)); bp.uy = fmaf(Vz, ex, -(Vx * ez)); bp.uz = fmaf(Vx, ey, -(Vy * ex));
-  bp.kap = fmaf(rs * iR, 1.0001f, 4e-6f);
+  bp.kap = fmaf(rs * iR, 1.0001f, 4e-6f) + kap_extra;
   // columns the cap can reach (prep_cols): all of them if it holds the pole or is wider than a hemisphere
   const float sinF = sqrt_cull(fmaf(o.fx, o.fx, o.fy * o.fy));
   const float sinw = sqrt_cull(fmaxf(0.f, fmaf(-cosw, cosw, 1.0f)));
@@ -1782,6 +1784,8 @@ struct Ray {
   uint32_t j;       // mirror interactions of the current trace; track points = j + 1 (+1 once it left the box)
   int on;
   bool tgt;         // ISX_TRACE_CHORD: v holds the next wall point T, not a direction
+  uint32_t k;       // lobe pipeline (assist_body<.., SURF_LOBE>): 0, or 1 + the index of the NEXT try of the rejection sampler of the
+                    // interaction the ray is in (it sits at its new point p, v is still the old direction); unused elsewhere
   uint32_t cw[4];   // the Philox block this lane holds (bounce_words; unused with PH_DIRECT)
   __device__ __forceinline__ uint32_t offset() const { return ido & 0x7fffffffu; }
   __device__ __forceinline__ uint32_t stream() const { return (ido >> 31) << 1; }   // 0 primary, 2 scattered
@@ -1790,7 +1794,7 @@ struct Ray {
 
 template <class G>
 __device__ __forceinline__ void ray_start(const G& g, Ray& r, uint32_t ido) {
-  r.ido = ido; r.j = 0; r.on = K_NONE; r.tgt = false;
+  r.ido = ido; r.j = 0; r.on = K_NONE; r.tgt = false; r.k = 0;
   r.p.x = g.src[0]; r.p.y = g.src[1]; r.p.z = g.src[2];
   r.v.x = g.dir0[0]; r.v.y = g.dir0[1]; r.v.z = g.dir0[2];
 }
@@ -1800,7 +1804,7 @@ __device__ __forceinline__ void ray_start(const G& g, Ray& r, uint32_t ido) {
 // Returns 0 while running, else the end status of the CURRENT trace.
 // SET_ON = false (the tracer waves of assist_body, which only ever arrive on the inner sphere and tell a fresh ray by its
 // interaction count): Ray::on is not maintained -- one move and one compare less per bounce.
-template <bool KEEP_PREV, bool LEAN, int CH, int PH = PH_DIRECT, bool SET_ON = true, class G>
+template <bool KEEP_PREV, bool LEAN, int CH, int PH = PH_DIRECT, bool SET_ON = true, int SURF = (LEAN ? SURF_LAMBERT : SURF_ANY), class G>
 __device__ __forceinline__ int ray_arrive(const Hot& h, const G& g, Ray& r, uint64_t seed, uint64_t id_base, int kind, const V3& q) {
   const uint64_t rid = id_base + (uint64_t)r.offset();
   if (KEEP_PREV) r.prev = r.p;
@@ -1810,12 +1814,12 @@ __device__ __forceinline__ int ray_arrive(const Hot& h, const G& g, Ray& r, uint
   bool alive;
   uint32_t wa, wb;
   bounce_words<PH>(seed, rid, r.j, r.stream(), r.cw, wa, wb);
-  const bool eligible = (kind == K_INNER) && (LEAN || (h.lambertian && h.surface_model == 0));
+  const bool eligible = (kind == K_INNER) && (SURF == SURF_LAMBERT || (SURF == SURF_ANY && h.lambertian && h.surface_model == 0));
   if (CH != 0 && eligible && (CH == 1 || h.chord)) {
     alive = interact_chord(h, r.v, wa, wb);
     r.tgt = alive;
   } else {
-    alive = interact<LEAN>(h, g, kind, q, r.v, seed, rid, r.j, r.stream(), wa, wb);
+    alive = interact<LEAN, SURF>(h, g, kind, q, r.v, seed, rid, r.j, r.stream(), wa, wb);
   }
   r.j++;
   if (!alive) return ST_ABSORBED;
@@ -2458,7 +2462,7 @@ __device__ __forceinline__ void ray_unpack(const uint4& a, const uint4& b, const
   r.p.x = __longlong_as_double(((long long)a.y << 32) | a.x); r.p.y = __longlong_as_double(((long long)a.w << 32) | a.z);
   r.p.z = __longlong_as_double(((long long)b.y << 32) | b.x); r.v.x = __longlong_as_double(((long long)b.w << 32) | b.z);
   r.v.y = __longlong_as_double(((long long)c.y << 32) | c.x); r.v.z = __longlong_as_double(((long long)c.w << 32) | c.z);
-  r.ido = e.x & ~IDO_TARGET; r.tgt = (e.x & IDO_TARGET) != 0u; r.j = e.y;
+  r.ido = e.x & ~IDO_TARGET; r.tgt = (e.x & IDO_TARGET) != 0u; r.j = e.y; r.k = 0u;
 }
 
 // DISC (the shared-ray physical-disc sweep, integratingSphereDetectorSweep.C:134-172 / SINK_DISC): the assist wave writes, for
@@ -2467,9 +2471,18 @@ __device__ __forceinline__ void ray_unpack(const uint4& a, const uint4& b, const
 // PP (the per-position sinks, one launch for all positions): 1 = SINK_PERPOS (a ray is tested against the detector(s) of its own
 // group only), 2 = SINK_DISCPOS (its forward exit segment against its own disc only) -- per-lane work at the exit, so the
 // assist wave does it on the spot and adds the rare hit to the global bins; no exit lines, no second kernel.
-template <int CH, bool RESC, bool DISC = false, int PP = 0>
+// SURF (round 5): the border's model -- SURF_LAMBERT (the lean path), SURF_ROUGH (ROBAST's rough-specular border: the same steps
+// with another interact()), SURF_LOBE (the cos^2-lobe rejection sampler of "nonLambertianFlux copy.C":31-70, the de-facto
+// CustomMirror).  Rule S1' holds for ANY direction that leaves a point of the inner sphere inwards, so only the emission differs.
+// The lobe's rejection loop is not run inside a step (its length is geometric with acceptance 0.707: the 64 lanes of a wave would
+// wait for the longest of 64 loops, ~4.4 tries per step where 1.41 are needed); a lane takes ONE try per step instead -- a lane
+// whose try was rejected stays at its new point (Ray::k counts its tries) and tries again in the next step while its neighbours
+// go on to their next wall point.  The tries of an interaction are a function of (seed, ray, interaction, try index) alone, so
+// the schedule changes nothing: bit-equal to lobe_sample()'s loop (oracle: isxo lobe_sample).
+template <int CH, bool RESC, bool DISC = false, int PP = 0, int SURF = SURF_LAMBERT>
 __device__ __forceinline__ void assist_body(const Geom& g_arg, const DetGrid& d_arg, const Work& wk) {
-  constexpr bool LEAN = true;
+  constexpr bool LEAN = SURF == SURF_LAMBERT;
+  static_assert(LEAN || (CH == 0 && !RESC), "the chord identity and the BRDF re-scatter pipeline are built for the Lambertian border");
   extern __shared__ __align__(16) unsigned char smem[];
   unsigned long long* sstat = reinterpret_cast<unsigned long long*>(smem);
   Geom* g_lds = reinterpret_cast<Geom*>(sstat + 8);
@@ -2592,6 +2605,7 @@ __device__ __forceinline__ void assist_body(const Geom& g_arg, const DetGrid& d_
             if (__builtin_amdgcn_readfirstlane((int)gone)) break;
           }
           if (!drained) { drained = true; if (lane == 0) __hip_atomic_store(&Q->drain, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+          if (ld(&Q->failed) != 0u) break;                                                             // a wave of this workgroup gave up: the launch has failed
           { const uint32_t bt = ld(&Q->beat); if (bt != beat_seen) { beat_seen = bt; spins = 0u; } }   // somebody is still at work
           if (++spins > kSpinLimit) { if (lane == 0) add(&Q->failed, 1u); break; }
           ISX_TD_ADD(13, 1);
@@ -2608,14 +2622,63 @@ __device__ __forceinline__ void assist_body(const Geom& g_arg, const DetGrid& d_
       //  sits on the inner sphere unless it is fresh, so Ray::on is neither read nor written in the steps)
       bool ended = false, susp = false;
       auto arrive = [&](const V3& q, auto ph) {
-        const int st = ray_arrive<false, LEAN, CH, decltype(ph)::value, false>(h, g, r, seed, first, K_INNER, q);
+        const int st = ray_arrive<false, LEAN, CH, decltype(ph)::value, false, SURF>(h, g, r, seed, first, K_INNER, q);
         if (st != 0) { run = false; ended = true; susp = st == ST_SUSPENDED; }
+      };
+      // SURF_LOBE: one TRY of the lobe's rejection sampler for every lane that is in an interaction (Ray::k != 0)
+      auto lobe_try_pending = [&]() {
+        if (run && r.k != 0u) {
+          V3 n, sc;
+          n.x = r.p.x * h.ninv_rin; n.y = r.p.y * h.ninv_rin; n.z = r.p.z * h.ninv_rin;   // surface_normal(K_INNER)
+          const uint32_t idx = r.k - 1u;
+          const bool acc = lobe_try(n, seed, first + (uint64_t)r.offset(), r.j - 1u, r.stream(), idx, sc);   // (j was counted at the arrival)
+          if (acc || idx + 1u == kLobeTries) {
+            lobe_hemisphere(n, sc);
+            finish_direction(n, sc);
+            r.v = sc; r.k = 0u;
+          } else r.k++;
+        }
+      };
+      // SURF_LOBE: one step = the next wall point for the lanes that have a direction (ray_arrive's order: move, absorb test on the
+      // interaction's word b, count, bounce limit -- the direction of an absorbed or suspended ray is never formed: nothing reads it),
+      // then one try for every lane that needs a direction
+      auto lobe_step = [&](bool step0) {
+        if (run && r.k == 0u) {
+          V3 q;
+          bool arrived = false;
+          const bool fresh = step0 && r.j == 0u && !r.scattered();
+          if (fresh) {
+            if (g.q0_ok) { q.x = g.q0[0]; q.y = g.q0[1]; q.z = g.q0[2]; arrived = true; }
+            else { hand = true; run = false; }
+          } else if (next_hit_s1<false>(h, g, r.p, r.v, K_INNER, q)) arrived = true;
+          else { hand = true; run = false; }
+          if (arrived) {
+            r.p = q;
+            uint32_t w4[4];
+            draw_block(seed, first + (uint64_t)r.offset(), r.j >> 1, r.stream(), w4);
+            const uint32_t wb = (r.j & 1u) ? w4[3] : w4[1];
+            r.j++;
+            if (!((unsigned long long)wb < h.rho_thr)) { run = false; ended = true; }
+            else if ((int)r.j + 1 > h.limit) { run = false; ended = true; susp = true; }
+            else r.k = 1u;
+          }
+        }
+        lobe_try_pending();
       };
       auto hot_search = [&](V3& q) -> bool {
         if (CH != 0 && r.tgt) return chord_arrive<true>(h, r, q);
         return next_hit_s1<false>(h, g, r.p, r.v, K_INNER, q);
       };
       if (next == kDry) { ISX_TD_ADD(14, 1); ISX_TD_ADD(15, __popcll(__ballot(run))); }   // (-DISX_DIAG: trips after the launch's queue ran dry)
+      if constexpr (SURF == SURF_LOBE) {
+        ISX_TD_ADD(4, __popcll(__ballot(run)));
+        lobe_step(true);
+        static_steps<1, kStepsPerTrip>([&](auto rep) {
+          (void)rep;
+          ISX_TD_ADD(4, __popcll(__ballot(run)));
+          lobe_step(false);
+        });
+      } else {
       {
         V3 q;
         bool arrived = false;
@@ -2640,6 +2703,7 @@ __device__ __forceinline__ void assist_body(const Geom& g_arg, const DetGrid& d_
         }
         if (arrived) arrive(q, std::integral_constant<int, (decltype(rep)::value & 1) ? PH_ODD : PH_EVEN>());
       });
+      }
       ISX_TD_MARK(1);
       // ---- rays that ended on the inner sphere (absorbed, suspended): census, or the BRDF re-scatter of a primary
       if (RESC && ended && h.source_model == 1 && !r.scattered()) {
@@ -2689,6 +2753,7 @@ __device__ __forceinline__ void assist_body(const Geom& g_arg, const DetGrid& d_
           if (lane == 0) { add(&Q->busy, cnt); add(&Q->pend_pub, cnt); }
         } else {
           ISX_TD_ADD(10, 1);
+          if (ld(&Q->failed) != 0u) break;   // no room and the assist wave has given up: nobody will make any
         }
       }
       ISX_TD_MARK(3);
@@ -2722,6 +2787,8 @@ __device__ __forceinline__ void assist_body(const Geom& g_arg, const DetGrid& d_
           ok = (uint32_t)__builtin_amdgcn_readfirstlane((int)ok);
           base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
           if (ok) {
+            // (a queue record has no room for a try count: a lane that is in the middle of an interaction finishes its tries first)
+            if constexpr (SURF == SURF_LOBE) { while (__ballot(run && r.k != 0u) != 0ull) lobe_try_pending(); }
             if (run) {
               const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(live >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)live, 0u));
               // (the record the assist wave writes for a ray that returns: at the top of a trip a lane with an odd interaction
@@ -2760,6 +2827,7 @@ __device__ __forceinline__ void assist_body(const Geom& g_arg, const DetGrid& d_
       const uint32_t n = pub == res ? res - hd : 0u;                 // everything below res is written once pub has caught up
       if (n == 0u) {
         if (res == hd && ld(&Q->tracers_done) == (uint32_t)n_tracers) break;
+        if (ld(&Q->failed) != 0u && ld(&Q->tracers_done) == (uint32_t)n_tracers) break;             // (a failed launch: whatever is reserved stays unpublished)
         { const uint32_t bt = ld(&Q->beat); if (bt != beat_seen) { beat_seen = bt; spins = 0u; } }   // the tracers are at work
         if (++spins > kSpinLimit) { if (lane == 0) add(&Q->failed, 1u); break; }
         __builtin_amdgcn_s_sleep(4);
@@ -2806,7 +2874,7 @@ __device__ __forceinline__ void assist_body(const Geom& g_arg, const DetGrid& d_
           else if (r.on == K_INNER) unit_dir(r.v);   // handed over by a tracer whose rule S1' failed: unit direction from here on
           V3 q;
           const int kind = next_hit_generic(g, r.p, r.v, r.on, q);
-          st = ray_arrive<DISC || PP == 2, LEAN, CH, PH_DIRECT>(h, g, r, seed, first, kind, q);   // (DISC: r.prev = start of this segment)
+          st = ray_arrive<DISC || PP == 2, LEAN, CH, PH_DIRECT, true, SURF>(h, g, r, seed, first, kind, q);   // (DISC: r.prev = start of this segment)
           if (RESC && st != 0 && h.source_model == 1 && !r.scattered()) {   // nonLambertianFlux.C:253-268
             n_wall += r.j;
             ray_rescatter(g, r, seed, first);
@@ -2861,16 +2929,17 @@ __device__ __forceinline__ void assist_body(const Geom& g_arg, const DetGrid& d_
           else if ((grp + 1) * rpg <= rel) grp++;
           if (PP == 1) {
             const double* table = d_arg.table;
+            const V3 lp = r.p, lv = r.v;
             if (d_arg.fold == 2) {
               const int nphi = d_arg.n_phi, half = nphi / 2;
               const int i = (int)(grp / (uint64_t)half), j = (int)(grp % (uint64_t)half);
               b0 = i * nphi + j;
               b1 = b0 + half;
-              hit1 = check_intersection(table + 6 * (size_t)b1, d_arg.half_w2, r.p, r.v);
+              hit1 = check_intersection(table + 6 * (size_t)b1, d_arg.half_w2, lp, lv);
             } else {
               b0 = (int)grp;
             }
-            hit0 = check_intersection(table + 6 * (size_t)b0, d_arg.half_w2, r.p, r.v);
+            hit0 = check_intersection(table + 6 * (size_t)b0, d_arg.half_w2, lp, lv);
           } else {
             b0 = (int)grp;
             V3 dl; dl.x = r.p.x - r.prev.x; dl.y = r.p.y - r.prev.y; dl.z = r.p.z - r.prev.z;
@@ -2900,8 +2969,10 @@ __device__ __forceinline__ void assist_body(const Geom& g_arg, const DetGrid& d_
             dst[0] = make_double2(r.prev.x, r.prev.y); dst[1] = make_double2(r.prev.z, r.v.x); dst[2] = make_double2(r.v.y, r.v.z);
             dst[3] = make_double2(dot3(dl, r.v), 0.0);
           } else {
+            // (ISX_HITLINE_ORIGIN_COMPAT: isx_compat_lines_kernel rewrites the lines between this kernel and the binning kernel)
+            const V3 lp = r.p, lv = r.v;
             double2* dst = reinterpret_cast<double2*>(d_arg.rec_lines + 6ull * slot);
-            dst[0] = make_double2(r.p.x, r.p.y); dst[1] = make_double2(r.p.z, r.v.x); dst[2] = make_double2(r.v.y, r.v.z);
+            dst[0] = make_double2(lp.x, lp.y); dst[1] = make_double2(lp.z, lv.x); dst[2] = make_double2(lv.y, lv.z);
           }
         }
         reg_slot += cnt; reg_left -= cnt;
@@ -2913,9 +2984,12 @@ __device__ __forceinline__ void assist_body(const Geom& g_arg, const DetGrid& d_
         const uint32_t cnt = (uint32_t)__popcll(bm);
         // room?  (the tracers never wait for this wave; slots are reserved by compare-and-swap: waves that give their last rays
         // away write to this ring as well)
-        uint32_t pubr = 0, w = 0;
+        uint32_t pubr = 0, w = 0, gave_up = 0;
         if (lane == 0) {
           for (;;) {
+#ifdef ISX_TEST_GIVEUP   // (test build only, tests/test_gpu_round5.py: the first batch of workgroup 0 finds "no room, no progress")
+            if (blockIdx.x == 0u) { add(&Q->failed, 1u); gave_up = 1u; break; }
+#endif
             const uint32_t rs = ld(&Q->resume_res);
             if (rs + cnt - ld(&Q->resume_head) <= kResumeCap) {
               uint32_t expect = rs;
@@ -2924,11 +2998,15 @@ __device__ __forceinline__ void assist_body(const Geom& g_arg, const DetGrid& d_
               continue;
             }
             { const uint32_t bt = ld(&Q->beat); if (bt != beat_seen) { beat_seen = bt; w = 0u; } }
-            if (++w > kSpinLimit) { add(&Q->failed, 1u); pubr = rs; break; }   // (gives up: the launch is reported as failed)
+            // gives up: nothing is reserved, nothing written, nothing published (the ring stays consistent); the launch is
+            // reported as failed and every wave of the workgroup leaves as soon as it sees the flag
+            if (++w > kSpinLimit) { add(&Q->failed, 1u); gave_up = 1u; break; }
             __builtin_amdgcn_s_sleep(2);
           }
         }
+        gave_up = (uint32_t)__builtin_amdgcn_readfirstlane((int)gave_up);
         pubr = (uint32_t)__builtin_amdgcn_readfirstlane((int)pubr);
+        if (gave_up) break;
         if (back) {
           const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(bm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bm, 0u));
           uint32_t cw2 = 0u, cw3 = 0u;
@@ -2988,6 +3066,38 @@ extern "C" __global__ void ISX_ASSIST_ATTR
 isx_trace_assist_perpos_kernel(const Geom g, const DetGrid d, const Work wk) { assist_body<0, false, false, 1>(g, d, wk); }
 extern "C" __global__ void ISX_ASSIST_ATTR
 isx_trace_assist_discpos_kernel(const Geom g, const DetGrid d, const Work wk) { assist_body<0, false, false, 2>(g, d, wk); }
+// the other border models on the same pipeline (round 5; until then round 1's fused isx_trace_bin_full_kernel served them):
+// the cos^2 lobe of "nonLambertianFlux copy.C":31-70,188-221 and ROBAST's rough-specular border (EnableLambertian(false))
+#ifndef ISX_LOBE_WAVES
+#define ISX_LOBE_WAVES 4
+#endif
+#ifndef ISX_ROUGH_WAVES
+#define ISX_ROUGH_WAVES 4
+#endif
+extern "C" __global__ void __launch_bounds__(ISX_ASSIST_BLOCK) __attribute__((amdgpu_waves_per_eu(ISX_LOBE_WAVES, ISX_LOBE_WAVES)))
+isx_trace_assist_lobe_kernel(const Geom g, const DetGrid d, const Work wk) { assist_body<0, false, false, 0, SURF_LOBE>(g, d, wk); }
+extern "C" __global__ void __launch_bounds__(ISX_ASSIST_BLOCK) __attribute__((amdgpu_waves_per_eu(ISX_ROUGH_WAVES, ISX_ROUGH_WAVES)))
+isx_trace_assist_rough_kernel(const Geom g, const DetGrid d, const Work wk) { assist_body<0, false, false, 0, SURF_ROUGH>(g, d, wk); }
+
+// ISX_HITLINE_ORIGIN_COMPAT on the pipeline (round 5): what fluxAtObserverFast.C:1181-1201,1285-1288 effectively tested is the line
+// from the origin along lastPoint/|lastPoint| (hit_line_compat).  The trace kernels write last point + final direction as always;
+// this kernel rewrites the exit lines of a chunk in place -- one thread per line, region by region -- before the binning kernel
+// reads them, so neither the trace kernels nor the binning kernels carry the switch (2 x 48 B per line: ~0.3 ms per 5e7 rays).
+extern "C" __global__ void __launch_bounds__(256)
+isx_compat_lines_kernel(double* __restrict__ rec_lines, const uint32_t* __restrict__ rec_counts, const uint32_t* __restrict__ ctr) {
+  const uint32_t n_regions = ctr[Q_REGIONS];
+  for (uint32_t reg = blockIdx.x; reg < n_regions; reg += gridDim.x) {
+    const uint32_t cnt = rec_counts[reg];
+    for (uint32_t i = threadIdx.x; i < cnt; i += blockDim.x) {
+      double* p6 = rec_lines + 6ull * ((uint64_t)reg * kRegion + i);
+      V3 P, V;
+      load_line(p6, P, V);
+      hit_line_compat(P, V);
+      double2* dst = reinterpret_cast<double2*>(p6);
+      dst[0] = make_double2(P.x, P.y); dst[1] = make_double2(P.z, V.x); dst[2] = make_double2(V.y, V.z);
+    }
+  }
+}
 
 // ------------------------------------------------------------------ disc-binning kernel of the shared-ray disc sweep
 // Persistent waves take quarter regions of exit segments (isx_trace_assist_disc_kernel) off the launch's queue, 64 segments at a

@@ -186,6 +186,10 @@ int isx_last_kernel_ms(double* single_ms, double* trace_ms, double* bin_ms);
  *   "bin_slots"    1 (default): binning kernels with slot queues by window length (grids up to 256 x 255); 0: round 2's
  *   "bin_cols"     1 (default; 2 is accepted and means the same): (line, COLUMN) slots for every source -- caps of the lines that
  *                  pass near the detector sphere's centre, cap-and-band windows for grazing lines; 0: (line, row) slots
+ *   "surface_pipeline"  1 (default, round 5): the cos^2-lobe and rough-specular borders (pencil source) and the origin-compat hit
+ *                  line run on the assist-wave pipeline too (isx_trace_assist_lobe_kernel / ..._rough_kernel; the compat lines are
+ *                  rewritten by isx_compat_lines_kernel between the trace and the binning kernel); 0: round 1's fused
+ *                  isx_trace_bin_full_kernel
  *   "bin_block", "bin_blocks_per_cu"  shape of round 2's binning kernel (0 workgroups per CU = what is resident)
  *   "ray_sub"      rays a wave takes off a launch's ray queue at a time (0 = default: 128)
  *   "overlap", "overlap_trace_streams"  cut a flux-map call into k chunks, binning of chunk i on a second stream while chunk

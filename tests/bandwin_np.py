@@ -130,10 +130,12 @@ def line_slots(P, V, cfg):
     Vx, Vy, Vz = f32(V[0]), f32(V[1]), f32(V[2])
     h = sqrt_cull(Hx * Hx + Hy * Hy + Hz * Hz)
     rs = f32(rho * f32(1.001) + f32(2e-3))
+    kap_extra = f32(0)
     if h > f32(1e-3) * R:
         ex, ey, ez = f32(Hx / h), f32(Hy / h), f32(Hz / h)
         cosw = max(f32(-1), f32((h - rs) * iR - f32(4e-6)))
     else:
+        kap_extra = f32(h * iR * f32(1.0001))   # H.u can reach h when h^ is a stand-in: the band is that much wider
         ax, ay, az = abs(Vx), abs(Vy), abs(Vz)
         t = np.zeros(3, f32)
         t[0 if (ax <= ay and ax <= az) else (1 if ay <= az else 2)] = 1
@@ -144,7 +146,7 @@ def line_slots(P, V, cfg):
         cosw = f32(-1)
     fx, fy, a = ex, ey, f32(-ez)
     ux, uy, uz = f32(Vy * ez - Vz * ey), f32(Vz * ex - Vx * ez), f32(Vx * ey - Vy * ex)
-    kap = f32(rs * iR * f32(1.0001) + f32(4e-6))
+    kap = f32(rs * iR * f32(1.0001) + f32(4e-6)) + kap_extra
     jlo, ncol = col_range(fx, fy, cosw, inv_dphi, n_phi, True)
     js = (jlo + np.arange(ncol)) % n_phi
     ilo, cnt = cap_rows(fx, fy, a, cosw, c32[js], s32[js], inv_dth, n_theta)

@@ -106,3 +106,16 @@ def test_column_slots_contain_every_hit():
         lp = np.concatenate([lp, tgt - 120.0 * V]); d = np.concatenate([d, V])
         r = bw.check(c, lp, d)
         assert r["hits"] > 0 and r["missed"] == 0 and r["twice"] == 0, (n_theta, n_phi, diam, dist)
+    # the degenerate branch of prep_band: detectors of 175-195 % of their sphere's radius (no caps: every line is a
+    # band line) and lines within 1e-3 R of O, where a stand-in replaces h^ and the band needs the extra h / R
+    for n_theta, n_phi, frac in ((180, 90, 1.76), (45, 20, 1.9), (17, 4, 1.95)):
+        c = orc.default_config()
+        c.n_theta, c.n_phi, c.det_distance = n_theta, n_phi, 100.0
+        c.det_diameter = frac * c.det_distance
+        m = 300
+        off = rng.standard_normal((m, 3)); off /= np.linalg.norm(off, axis=1)[:, None]
+        off *= rng.uniform(0.0, 1.5e-3, (m, 1)) * c.det_distance
+        V = rng.standard_normal((m, 3)); V /= np.linalg.norm(V, axis=1)[:, None]
+        tgt = np.array([0.0, 0.0, c.exit_port_z]) + off
+        r = bw.check(c, tgt - 120.0 * V, V)
+        assert r["hits"] > 0 and r["missed"] == 0 and r["twice"] == 0, (n_theta, n_phi, frac)

@@ -255,3 +255,166 @@ def test_wall_points_uniform_on_sphere(orc, mode):
     phi = np.arctan2(lp[sel, 1], lp[sel, 0])
     h2, _ = np.histogram(phi, bins=36, range=(-np.pi, np.pi))
     assert ((h2 - sel.sum() / 36.0) ** 2 / (sel.sum() / 36.0)).sum() < 75
+
+
+# ------------------------------------------------------------------------------------------------ round 5: the reference's data files
+# that no test had used so far ("next" #1; tests/golden/README.md lists every data file of the reference)
+def test_traceonce_file_at_the_older_source_position_is_the_origin_compat_pattern(orc, golden):
+    """results/fluxmap_traceonce_50000rays_180x90_src-60_0_-80.csv: ONE 50 000-ray trace-once map (all bins share the rays).  Its
+    header records rays and detector size only; source (-60,0,-80), direction (5,2,0), port 170 are ASSUMED from the sibling files of
+    the same evening (fixture: "assumed").  The file is one draw of a distribution of which the oracle makes independent draws:
+    sum and theta profile must lie inside the oracle's own scatter with hit_line_mode = 1 -- and far outside with the canonical line
+    (on-axis 0.0091 against 0.0155)."""
+    g = golden["traceonce_src_m80"]
+    assert g["rays"] == 50000 and g["row0"][0] == pytest.approx(0.00908)
+    c = orc.default_config()
+    for k in range(3):
+        c.src[k] = g["assumed"]["source_position"][k]; c.dir[k] = g["assumed"]["source_direction"][k]
+    c.hit_line_mode = 1
+    sums, profs = [], []
+    for s in range(16):
+        h, _ = orc.fluxmap(c, g["rays"], SEED + 100 + s)
+        sums.append(h.sum() / g["rays"]); profs.append((h / g["rays"]).mean(axis=1))
+    sums, profs = np.array(sums), np.array(profs)
+    z_sum = (g["sum_fraction"] - sums.mean()) / sums.std(ddof=1)
+    assert abs(z_sum) < 4, (z_sum, g["sum_fraction"], sums.mean())            # measured: +0.8
+    gold = np.array(g["theta_profile"])
+    # ten bands of 15 rows (theta < 75 deg): each band's mean against the scatter of the oracle's sixteen maps
+    zb = []
+    for b in range(10):
+        mine = profs[:, 15 * b:15 * b + 15].mean(axis=1)
+        zb.append((gold[15 * b:15 * b + 15].mean() - mine.mean()) / mine.std(ddof=1))
+    assert np.abs(zb).max() < 5, zb
+    c.hit_line_mode = 0
+    h, _ = orc.fluxmap(c, 200_000, SEED)
+    assert (h.sum() / 200_000) / g["sum_fraction"] == pytest.approx(1.43, abs=0.04)   # the canonical line is 28 sigma away
+
+
+@pytest.mark.parametrize("name", ["pp_03_31_3", "pp_04_1_4"])
+def test_cut_short_per_position_maps(orc, name):
+    """The two per-position runs that were interrupted (source direction (5,6,0): 12 867 rows; port 175 deg: 2 715 rows; 50 000 fresh
+    rays per row, tests/golden/reference_maps.npz): every row present against 4e5 oracle rays, binomial sigmas.  A new direction and
+    a new port angle; the known residual (a smooth factor of theta, +1.3 % on axis) shows in the 175-degree file, whose rows stop at
+    theta = 15 deg: ratio 0.988 +- 0.004."""
+    import json
+    import os
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "reference_maps.npz"))
+    info = [i for i in json.loads(str(z["index_json"])) if i["name"] == name][0]
+    ref = z[name + "_hits"].astype(np.int64).reshape(-1)
+    have = ref >= 0
+    assert not info["complete"] and have.sum() == info["rows_present"] and have[:info["rows_present"]].all()
+    c = orc.default_config()
+    c.theta_max_deg = info["port_deg"]
+    for a in range(3):
+        c.src[a] = info["source_position"][a]; c.dir[a] = info["source_direction"][a]
+    n, n_ref = 400_000, info["rays_per_position"]
+    h, _ = orc.fluxmap(c, n, SEED + 7)
+    h = h.reshape(-1).astype(np.int64)
+    p = (np.where(have, ref, 0) + h) / (n_ref + n)
+    var = p * (1 - p) * (1.0 / n_ref + 1.0 / n)
+    use = have & (p * n_ref >= 5)
+    chi2 = (((ref / n_ref - h / n) ** 2)[use] / var[use]).sum() / use.sum()
+    ratio = (h[have].sum() / n) / (ref[have].sum() / n_ref)
+    assert use.sum() > 0.95 * have.sum() and chi2 < 1.15, (name, chi2)
+    assert abs(ratio - 1) < 0.02, (name, ratio)
+
+
+def test_unbinned_exit_log(orc, golden):
+    """3dRayLog.txt (distributionSphereDetectorSweep.C:76-100: 100 000 exit directions, rho 1, no roughness, ONE thread): the joint
+    distribution of (dz, azimuth) of the oracle's exit directions against the log's -- 2-d chi2 over 10 x 12 cells and the two 1-d
+    distributions.  Measured: chi2 114 for 119 dof; KS p = 0.17 (dz), 0.11 (azimuth)."""
+    from scipy import stats
+    g = golden["ray_log_3d"]
+    assert g["n"] == 100000 and g["upward"] == 0 and g["max_norm_error"] < 1e-5
+    c = orc.default_config()
+    c.src[2] = -80.0; c.reflectance = 1.0; c.roughness_rad = 0.0; c.max_points = 10000; c.box_half = 200.0
+    n = 400_000
+    ids, d, cnt = orc.exit_directions(c, n, SEED + 31)
+    assert cnt == n and (d[:, 2] < 0).all()                                   # rho = 1: every ray leaves, downwards
+    az = np.arctan2(d[:, 1], d[:, 0])
+    Hr = np.array(g["dz_az_10x12"], dtype=float)
+    Ho, _, _ = np.histogram2d(d[:, 2], az, bins=[np.linspace(-1.0, 0.0, 11), np.linspace(-np.pi, np.pi, 13)])
+    assert Hr.sum() == g["n"] and Ho.sum() == n
+    p = (Hr + Ho) / (Hr.sum() + Ho.sum())
+    use = p * Hr.sum() >= 20
+    chi2 = (((Hr / Hr.sum() - Ho / Ho.sum()) ** 2)[use] / (p * (1 / Hr.sum() + 1 / Ho.sum()))[use]).sum()
+    assert stats.chi2.sf(chi2, use.sum() - 1) > 1e-4, (chi2, use.sum())
+    for key, vals, lo, hi, nb in (("dz_hist", d[:, 2], -1.0, 0.0, 200), ("az_hist", az, -np.pi, np.pi, 180)):
+        hr = np.array(g[key], dtype=float)
+        ho = np.histogram(vals, bins=np.linspace(lo, hi, nb + 1))[0].astype(float)
+        pp = (hr + ho) / (hr.sum() + ho.sum())
+        u = pp * hr.sum() >= 20
+        x2 = (((hr / hr.sum() - ho / ho.sum()) ** 2)[u] / (pp * (1 / hr.sum() + 1 / ho.sum()))[u]).sum()
+        assert stats.chi2.sf(x2, u.sum() - 1) > 1e-4, (key, x2, u.sum())
+
+
+def test_physical_disc_sweep_at_one_degree(orc, golden):
+    """detector_sweep2.txt: the physical-disc sweep at 1 deg x 1 deg (46 complete theta rows, 1000 rays per position), phi-mean per
+    theta: all rows within 4 sigma (measured: max 2.9, chi2/dof 1.2, total ratio 0.987) -- with the TGeoRotation quirk of DESIGN 2.4."""
+    g = golden["disc_sweep2"]
+    cfg = orc.default_config()
+    cfg.r_out = 105.0; cfg.src[2] = -80.0; cfg.reflectance = 1.0; cfg.roughness_rad = 0.0
+    cfg.max_points = 10000; cfg.box_half = 200.0
+    thetas, phis = np.array(g["theta_deg"]), np.arange(0, 360, 15.0)
+    assert len(thetas) == 46 and g["rows_dropped"] == 219
+    ca = []
+    for t in thetas:
+        for p in phis:
+            tr, pr = np.deg2rad(t), np.deg2rad(p)
+            x, y, z = 200 * np.sin(tr) * np.cos(pr), 200 * np.sin(tr) * np.sin(pr), -200 * np.cos(tr)
+            rot_theta = -np.arctan2(np.sqrt(x * x + y * y), -100.0 - z)
+            ca.append([x, y, z, np.sin(rot_theta), 0.0, np.cos(rot_theta)])
+    n = 400_000
+    hits, _ = orc.disc_sweep(cfg, np.array(ca), 5.0, 0.1, n, SEED)
+    got = (hits.reshape(len(thetas), len(phis)) / n).mean(axis=1)
+    gold = np.array(g["phi_mean_fraction"])
+    sig = np.hypot(np.sqrt(np.maximum(gold, 1e-5) / (g["rays_per_position"] * g["n_phi"])), np.sqrt(np.maximum(got, 1e-6) / (n * len(phis))))
+    zz = (got - gold) / sig
+    assert np.abs(zz).max() < 4 and (zz ** 2).mean() < 1.8, (np.abs(zz).max(), (zz ** 2).mean())
+    assert got.sum() / gold.sum() == pytest.approx(1.0, abs=0.04)
+
+
+def test_small_and_cut_short_files_of_identified_revisions(orc, golden):
+    """Six small files whose macro revision the file name / header identifies (fluxAtObserver.C: src z -80, dir (5,2,0), rho 1,
+    sigma 0.5, 10 cm detector; fluxAtObserverOptimize/Fast.C at src z -80): the hits of the rows present against the oracle's bin
+    probabilities -- the sum within 4 sigma of its Poisson noise (twofold rows share their rays in pairs: sigma x sqrt 2).
+    Measured ratios oracle / file: 1.000, 1.014, 0.993, 1.016, 1.003, 1.026."""
+    cache = {}
+    for f in golden["small_files"]:
+        cf = f["config"]
+        key = (cf["macro"], cf["n_theta"], cf["n_phi"], cf["det_diameter"])
+        if key not in cache:
+            c = orc.default_config()
+            for k in range(3):
+                c.src[k] = cf["src"][k]; c.dir[k] = cf["dir"][k]
+            c.reflectance, c.roughness_rad, c.max_points, c.box_half = cf["reflectance"], cf["roughness"], cf["max_points"], cf["box_half"]
+            c.n_theta, c.n_phi, c.det_diameter = cf["n_theta"], cf["n_phi"], cf["det_diameter"]
+            n = 300_000
+            h, _ = orc.fluxmap(c, n, SEED + len(cache))
+            cache[key] = h / n
+        p = cache[key]
+        th, ph, hits = np.array(f["theta"]), np.array(f["phi"]), np.array(f["hits"], dtype=float)
+        i = np.rint(th / (90.0 / cf["n_theta"]) - 0.5).astype(int)
+        j = np.rint(ph / (360.0 / cf["n_phi"]) - 0.5).astype(int)
+        assert np.abs((i + 0.5) * 90.0 / cf["n_theta"] - th).max() < 1e-4 and np.abs((j + 0.5) * 360.0 / cf["n_phi"] - ph).max() < 1e-4
+        expect = p[i, j] * f["rays_per_position"]
+        sig = np.sqrt(expect.sum() * (2.0 if cf.get("fold") == 2 else 1.0) * (1.0 + f["rays_per_position"] * len(hits) / 300_000 * 0.01))
+        z = (hits.sum() - expect.sum()) / sig
+        assert abs(z) < 4, (f["file"], hits.sum(), expect.sum(), z)
+
+
+@pytest.mark.xfail(strict=True, reason="results/detector_data_50000rays*.csv come from an older revision of fluxAtObserver.C whose source and "
+                                       "detector model are not recorded: with today's detector normal the sum ratio is 0.951 (10 cm disc) / 3.80 "
+                                       "(20 cm disc) and rows beyond 60 deg are 0.25-0.68 of the file's; with normals facing the port 1.40 "
+                                       "(2.5-3.4 beyond 50 deg).  No second check of DESIGN 2.3 can be drawn from them")
+def test_detector_data_files_of_the_older_revision(orc, golden):
+    """VERDICT r04 'next' 1(b): sigma = 0.75, '20cm x 20cm', Lambertian.  Kept as a strict xfail that states the measured ratios."""
+    g = golden["detector_data_sigma075"]
+    assert g["roughness"] == 0.75 and len(g["coarse"]) == 4
+    c = orc.default_config()
+    c.det_diameter = 10.0; c.roughness_rad = 0.75
+    n = 300_000
+    h, _ = orc.fluxmap(c, n, SEED)
+    prof, gold = (h / n).mean(axis=1), np.array(g["theta_profile"])
+    assert abs((h.sum() / n) / g["sum_fraction"] - 1) < 0.02
+    assert abs(prof[120:].sum() / gold[120:].sum() - 1) < 0.1

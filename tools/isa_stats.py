@@ -4,12 +4,13 @@
 usage: tools/isa_stats.py [--check] [--keep DIR] [extra -D flags for hipcc]
 
 Compiles csrc/isx_api.hip for gfx950 with --save-temps and counts, per kernel, flat_ / global_ / scratch_ / ds_
-instructions.  --check fails (exit 1) on the two traps DESIGN.md section 5 describes:
-  * a `flat_*` access in one of the binning kernels (a pointer whose address space hipcc could not infer: flat
-    operations complete out of order and force s_waitcnt vmcnt(0) lgkmcnt(0) together, so every line fetch also
-    drains the wave's LDS queue);
-  * any `flat_* ... sc0 sc1` (a volatile access through a generic pointer: system scope).
-and prints scratch use so that a spill inside a batch loop is seen at build time.
+instructions.  --check fails (exit 1) on the traps DESIGN.md section 5 describes:
+  * a `flat_*` access in ANY kernel (a pointer whose address space hipcc could not infer: flat operations complete
+    out of order and force s_waitcnt vmcnt(0) lgkmcnt(0) together, so every line fetch also drains the wave's LDS
+    queue);
+  * any `flat_* ... sc0 sc1` (a volatile access through a generic pointer: system scope);
+  * scratch in a kernel of NO_SCRATCH (the binning kernels and the trace kernels of the BASELINE configurations).
+Scratch of every other kernel is printed as a report ("SCRATCH ..."), so that a spill inside a loop is seen at build time.
 """
 import os
 import re
@@ -20,8 +21,10 @@ import tempfile
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SRC = os.path.join(ROOT, "altair-raytracing_amd", "csrc", "isx_api.hip")
 FLAGS = ["-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "-ffp-contract=off", "-fno-fast-math", "-Wno-unused-function"]
-# kernels whose inner loops must not touch memory through generic pointers
-NO_FLAT = ("isx_bin_cols_kernel", "isx_bin_slots_kernel", "isx_bin_lines_kernel", "isx_bin_discs_kernel")
+# kernels that must not spill: the binning kernels and the trace kernels the BASELINE configurations run
+NO_SCRATCH = ("isx_bin_cols_kernel", "isx_bin_slots_kernel", "isx_bin_lines_kernel", "isx_bin_discs_kernel",
+              "isx_trace_assist_kernel", "isx_trace_assist_brdf_kernel", "isx_trace_assist_chord_kernel",
+              "isx_trace_assist_perpos_kernel", "isx_trace_assist_lobe_kernel", "isx_trace_assist_rough_kernel")
 
 
 def compile_isa(extra, keep=None):
@@ -67,7 +70,7 @@ def main():
         args = [a for i, a in enumerate(args) if a != "--keep" and (i == 0 or args[i - 1] != "--keep")]
     extra = [a for a in args if a != "--check"]
     path = compile_isa(extra, keep)
-    bad = []
+    bad, report = [], []
     print("%-36s %4s %4s %7s %3s | %7s %7s %7s %4s | %7s %7s %7s | %6s %6s | %5s" % (
         "kernel", "vgpr", "sgpr", "scratch", "occ", "flat_ld", "flat_st", "flat_at", "sys", "glob_ld", "glob_st", "glob_at", "scr_ld", "scr_st", "ds"))
     for name, body in kernels(path):
@@ -77,8 +80,15 @@ def main():
             c["glob_ld"], c["glob_st"], c["glob_at"], c["scr_ld"], c["scr_st"], c["ds"]))
         if c["flat_sys"]:
             bad.append("%s: %d system-scope flat accesses" % (name, c["flat_sys"]))
-        if name in NO_FLAT and (c["flat_ld"] + c["flat_st"] + c["flat_at"]):
+        if c["flat_ld"] + c["flat_st"] + c["flat_at"]:
             bad.append("%s: %d flat_ accesses" % (name, c["flat_ld"] + c["flat_st"] + c["flat_at"]))
+        if c["scratch"] > 0:
+            if name in NO_SCRATCH:
+                bad.append("%s: %d B of scratch (%d loads, %d stores)" % (name, c["scratch"], c["scr_ld"], c["scr_st"]))
+            else:
+                report.append("SCRATCH %s: %d B (%d loads, %d stores)" % (name, c["scratch"], c["scr_ld"], c["scr_st"]))
+    if report:
+        print("\n".join(report))
     if check and bad:
         print("\n".join("TRAP " + b for b in bad))
         sys.exit(1)
