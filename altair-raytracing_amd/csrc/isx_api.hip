@@ -13,6 +13,7 @@
 #include <cstring>
 #include <algorithm>
 #include <map>
+#include <tuple>
 #include <vector>
 
 using namespace isx;
@@ -58,6 +59,8 @@ struct State {
   int ray_sub = 0;                        // rays a wave takes off the queue at a time (0: by launch size)
   int bin_block = 512, bin_blocks_per_cu = 0;   // binning kernel: workgroup size, workgroups per CU in the grid (0: what is resident)
   int assist_block = ISX_ASSIST_BLOCK;          // its workgroup size: (assist_block / 64 - 1) tracer waves + 1 assist wave
+  bool assist_block_set = false;                // set through isx_set_option: then it holds for small launches too (small_shape)
+  int rays_per_lane = 0;                        // 0: by launch size (small_shape); > 0: the grid is sized for this many rays per tracer lane
   int disc_pipeline = 1;                        // 1 (default): the shared-ray disc sweep as assist-wave trace kernel + isx_bin_discs_kernel; 0: fused SINK_DISC kernel
   int assist = 1;                               // 1: trace kernels with an assist wave per workgroup (assist_body)
   int bin_cols = 1;                             // 1 (2: the same): isx_bin_cols_kernel ((line, column) slots) where bin_slots applies; 0: row slots
@@ -80,6 +83,14 @@ struct State {
   int trace_block = 512, trace_blocks_per_cu = 0;
   // hipFuncSetAttribute(MaxDynamicSharedMemorySize) is made once per kernel and size, not once per launch
   std::map<const void*, size_t> attr_lds;
+  // ... and so is the occupancy query (resident_per_cu): (kernel, workgroup size, LDS bytes) -> workgroups per CU
+  std::map<std::tuple<const void*, int, size_t>, int> occ;
+  // small calls are bound by host round trips: results and census go through ONE pinned staging buffer
+  // (asynchronous copies, one synchronisation per call), and a blocking call that finds nothing enqueued before it skips the
+  // census round trip at its start
+  unsigned char* h_pin = nullptr;
+  size_t cap_pin = 0;
+  bool pending = false;                    // launches enqueued since the last collect_stats()
 } S;
 
 // Scratch device allocation of one call: freed on every return path.
@@ -252,11 +263,24 @@ int get_event(hipEvent_t* ev) {
   return ISX_OK;
 }
 
-int pick_grid(uint64_t n, int block = kBlock, int blocks_per_cu = 0) {
+// Launch shape of a SMALL launch (round 5; measured in profiles/r05_small_call_sweep.json).  A launch cannot end before its longest
+// ray has -- about ln(n) / 0.0175 bounces, one after the other (620 for 5e4 rays) -- so a small launch is bound by latency, not by
+// throughput: few rays per tracer lane (the bulk of the work is then short next to the longest ray) and few waves per SIMD (a
+// wave that shares its SIMD with five others takes six times as long per bounce).  5e4 rays per call is the reference's own call
+// size (traceRaysParallel, fluxAtObserverOptimize.C:568: 0.82 -> 0.29 ms per call).  From ~1.4e6 rays on the grid is what is resident.
+struct Shape { int block; uint64_t rays_per_lane; };
+Shape small_shape(uint64_t n, int block_default) {
+  Shape sh;
+  sh.block = (!S.assist_block_set && n < 1000000ull && block_default > 256) ? 256 : block_default;   // 3 tracer waves + the assist wave: one wave per SIMD
+  sh.rays_per_lane = S.rays_per_lane > 0 ? (uint64_t)S.rays_per_lane : (n < 150000ull ? 1ull : n < 300000ull ? 2ull : 4ull);
+  return sh;
+}
+// workgroups of a launch of n rays: `tracer_waves` waves per workgroup trace (all of them unless the workgroup has an assist wave)
+int pick_grid(uint64_t n, int block = kBlock, int blocks_per_cu = 0, int tracer_waves = 0, uint64_t rays_per_lane = 4) {
   if (S.grid_blocks > 0) return S.grid_blocks;
   const int full = S.cu_count * (blocks_per_cu > 0 ? blocks_per_cu : S.blocks_per_cu);
-  // keep >= 16 rays per lane so the refill loop has something to refill from
-  const uint64_t want = (n + (uint64_t)block * 16 - 1) / ((uint64_t)block * 16);
+  const uint64_t lanes = (uint64_t)(tracer_waves > 0 ? tracer_waves : block / 64) * 64ull * (rays_per_lane ? rays_per_lane : 1ull);
+  const uint64_t want = (n + lanes - 1) / lanes;
   if (want < 1) return 1;
   return want < (uint64_t)full ? (int)want : full;
 }
@@ -264,8 +288,12 @@ int pick_grid(uint64_t n, int block = kBlock, int blocks_per_cu = 0) {
 // workgroups of `fn` (workgroup size `block`, `lds` bytes of dynamic LDS) that are resident on one CU at a time
 template <class F>
 int resident_per_cu(F fn, int block, size_t lds) {
+  const auto key = std::make_tuple((const void*)fn, block, lds);
+  const auto it = S.occ.find(key);
+  if (it != S.occ.end()) return it->second;
   int nb = 0;
   if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, fn, block, lds) != hipSuccess || nb < 1) nb = 1;
+  S.occ[key] = nb;
   return nb;
 }
 
@@ -282,8 +310,32 @@ int next_ctr(uint32_t** ctr) {
   uint32_t* c = S.d_ctr + (S.ctr_next++ % State::kCtrRing) * Q_WORDS;
   HIPCHK(hipMemsetAsync(c, 0, Q_WORDS * sizeof(uint32_t), S.stream));
   *ctr = c;
+  S.pending = true;   // (every launch takes a block: from here on the stream holds work whose census has not been collected)
   return ISX_OK;
 }
+
+// pinned staging buffer of at least `bytes` bytes: [0, 64) the census words, [64, ...) a call's result
+int ensure_pin(size_t bytes) {
+  bytes += 64 + 4096;   // (+ the last 4 KB: upload_aux's slot for a short list)
+  if (bytes > S.cap_pin) {
+    HIPCHK(hipStreamSynchronize(S.stream));
+    if (S.h_pin) HIPCHK(hipHostFree(S.h_pin));
+    S.h_pin = nullptr; S.cap_pin = 0;
+    const size_t cap = bytes < (1u << 18) ? (1u << 18) : bytes;
+    HIPCHK(hipHostMalloc((void**)&S.h_pin, cap, hipHostMallocDefault));
+    S.cap_pin = cap;
+  }
+  return ISX_OK;
+}
+// D2H of a call's result: enqueued into the staging buffer (no synchronisation here: collect_stats() has the one of the call);
+// fetch_result() copies it out once the stream has been synchronised
+int stage_result(const void* dev, size_t bytes) {
+  const int rc = ensure_pin(bytes);
+  if (rc) return rc;
+  HIPCHK(hipMemcpyAsync(S.h_pin + 64, dev, bytes, hipMemcpyDeviceToHost, S.stream));
+  return ISX_OK;
+}
+void fetch_result(void* host, size_t bytes) { std::memcpy(host, S.h_pin + 64, bytes); }
 
 // one launch addresses its rays by 31-bit offsets from its first ray: larger jobs are cut into launches of this many rays
 constexpr uint64_t kLaunchMax = 1ull << 30;
@@ -432,7 +484,10 @@ int enqueue(int sink, const isx_config* c, uint64_t n, uint64_t seed, uint64_t f
                       lds_tables + (size_t)(d.n_theta + 4) * sizeof(RowX) + (size_t)(kBlock / 64) * kColWaveWords * 4 <= S.lds_limit;
     typedef void (*BinFn)(const DetGrid, const Work);
     const BinFn bin_fn = cols ? isx_bin_cols_kernel : slots ? isx_bin_slots_kernel : isx_bin_lines_kernel;
-    const int pblock = assist ? S.assist_block : S.trace_block, bblock = slots ? kBlock : S.bin_block;
+    const uint64_t chunk0 = n < S.pipe_chunk ? n : S.pipe_chunk;
+    const Shape shp = assist ? small_shape(chunk0, S.assist_block) : Shape{S.trace_block, 4};
+    const int pblock = shp.block, bblock = slots ? kBlock : S.bin_block;
+    const int ptracers = assist ? pblock / 64 - 1 : pblock / 64;
     const size_t lds_bin = lds_tables + (cols ? (size_t)(d.n_theta + 4) * sizeof(RowX) + (size_t)(bblock / 64) * kColWaveWords * 4
                                          : slots ? (size_t)(2 * d.n_phi) * sizeof(ColP) + (size_t)(bblock / 64) * kSlotWaveWords * 4 : (size_t)(bblock / 64) * 128 * 4);
     if (lds_bin <= S.lds_limit) {
@@ -457,7 +512,8 @@ int enqueue(int sink, const isx_config* c, uint64_t n, uint64_t seed, uint64_t f
         DetGrid dt = d;              // the trace kernel keeps no histogram
         dt.nbins = 1; dt.n_theta = 0; dt.n_phi = 0;
         dt.rec_lines = S.d_rec[buf]; dt.rec_counts = S.d_rec_counts[buf];
-        hipLaunchKernelGGL(rec_fn, dim3(pick_grid(cnt, pblock, tres)), dim3(pblock), lds_trace, st, g, dt, w2);
+        const int tgrid = pick_grid(cnt, pblock, tres, ptracers, shp.rays_per_lane);
+        hipLaunchKernelGGL(rec_fn, dim3(tgrid), dim3(pblock), lds_trace, st, g, dt, w2);
         HIPCHK(hipGetLastError());
         if (traced) { HIPCHK(hipEventRecord(traced, st)); HIPCHK(hipStreamWaitEvent(sb, traced, 0)); }
         else { r = span(1, nullptr); if (r) return r; }
@@ -468,7 +524,11 @@ int enqueue(int sink, const isx_config* c, uint64_t n, uint64_t seed, uint64_t f
         if (S.bin_mode != 2) {       // bin_mode 2: diagnostic, trace only
           DetGrid db = d;
           db.rec_lines = S.d_rec[buf]; db.rec_counts = S.d_rec_counts[buf];
-          const uint64_t bwant = cnt / (uint64_t)(kRegion * (bblock / 64)) + 1;   // (an upper bound of the regions per workgroup >= 1)
+          // work units of the binning kernel = quarter regions: at most cnt / 256 full ones + the open region every writing wave of
+          // the trace kernel leaves behind (one per workgroup with an assist wave) -- a wave per unit, a workgroup per bblock / 64 units
+          const uint64_t writers = assist ? (uint64_t)tgrid : (uint64_t)tgrid * (uint64_t)(pblock / 64);
+          const uint64_t units = cnt / (kRegion / 4) + writers;
+          const uint64_t bwant = (units + (uint64_t)(bblock / 64) - 1) / (uint64_t)(bblock / 64);
           const int bfull = S.cu_count * bres;
           const int gb = S.grid_blocks > 0 ? S.grid_blocks : (bwant < (uint64_t)bfull ? (int)bwant : bfull);
           hipLaunchKernelGGL(bin_fn, dim3(gb), dim3(bblock), lds_bin, sb, db, w2);
@@ -477,7 +537,7 @@ int enqueue(int sink, const isx_config* c, uint64_t n, uint64_t seed, uint64_t f
         }
         return ISX_OK;
       };
-      const int cgrid = pick_grid(chunk, pblock, tres);
+      const int cgrid = pick_grid(chunk, pblock, tres, ptracers, shp.rays_per_lane);
       if (S.overlap > 1 && S.bin_mode == 1 && n >= (uint64_t)S.overlap * 65536) {
         // ---- overlapped: chunk k is binned on the second stream while chunk k+1 is traced on the first; chunk k+3 reuses the
         // workspace of chunk k.  (Timing: one wall-clock span around everything; the kernels' own times overlap.)
@@ -485,7 +545,7 @@ int enqueue(int sink, const isx_config* c, uint64_t n, uint64_t seed, uint64_t f
         if (!S.stream3) HIPCHK(hipStreamCreateWithFlags(&S.stream3, hipStreamNonBlocking));
         const uint64_t per = ((n + (uint64_t)S.overlap - 1) / (uint64_t)S.overlap + 63) & ~63ull;
         const uint64_t oc = per < S.pipe_chunk ? per : S.pipe_chunk;
-        const int ogrid = pick_grid(oc, pblock, tres);
+        const int ogrid = pick_grid(oc, pblock, tres, ptracers, shp.rays_per_lane);
         for (int b = 0; b < State::kRecBufs; ++b) { rc = ensure_pipeline((size_t)oc, (size_t)ogrid * (pblock / 64), b); if (rc) return rc; }
         rc = span(0, &e0); if (rc) return rc;
         std::vector<hipEvent_t> binned;
@@ -534,7 +594,8 @@ int enqueue(int sink, const isx_config* c, uint64_t n, uint64_t seed, uint64_t f
                               (size_t)(kDiscBinBlock / 64) * (64 * 7 + kPairCap / 2) * sizeof(double);
   if (sink == SINK_DISC && lean_explicit && S.pipeline && S.assist && S.disc_pipeline && g_disc_clusters.n == (size_t)d.nbins &&
       d_discs == S.d_aux && lds_disc_bin <= S.lds_limit) {
-    const int pblock = S.assist_block, bblock = kDiscBinBlock;
+    const Shape shp = small_shape(n < S.pipe_chunk ? n : S.pipe_chunk, S.assist_block);
+    const int pblock = shp.block, bblock = kDiscBinBlock;
     const size_t lds_trace = 16 + 64 + sizeof(Geom) + sizeof(DetGrid) + 16 + sizeof(AssistQueues) + (size_t)(kResumeCap + kPendCap) * 64;
     const size_t lds_bin = lds_disc_bin;
     const KernelFn rec_fn = isx_trace_assist_disc_kernel;
@@ -548,7 +609,7 @@ int enqueue(int sink, const isx_config* c, uint64_t n, uint64_t seed, uint64_t f
     }
     const int tres = resident_per_cu(rec_fn, pblock, lds_trace), bres = resident_per_cu(isx_bin_discs_kernel, bblock, lds_bin);
     const uint64_t chunk = n < S.pipe_chunk ? n : S.pipe_chunk;
-    rc = ensure_pipeline((size_t)chunk, (size_t)pick_grid(chunk, pblock, tres) * (pblock / 64), 0, 8);
+    rc = ensure_pipeline((size_t)chunk, (size_t)pick_grid(chunk, pblock, tres, pblock / 64 - 1, shp.rays_per_lane) * (pblock / 64), 0, 8);
     if (rc) return rc;
     rc = span(0, &e0); if (rc) return rc;
     for (uint64_t off = 0; off < n; off += chunk) {
@@ -563,10 +624,11 @@ int enqueue(int sink, const isx_config* c, uint64_t n, uint64_t seed, uint64_t f
       dt.clusters = reinterpret_cast<const float*>(S.d_aux + g_disc_clusters.off_clusters);
       dt.disc_perm = reinterpret_cast<const int*>(S.d_aux + g_disc_clusters.off_perm);
       dt.n_clusters = g_disc_clusters.n_clusters;
-      hipLaunchKernelGGL(rec_fn, dim3(pick_grid(cnt, pblock, tres)), dim3(pblock), lds_trace, S.stream, g, dt, w2);
+      const int tgrid = pick_grid(cnt, pblock, tres, pblock / 64 - 1, shp.rays_per_lane);
+      hipLaunchKernelGGL(rec_fn, dim3(tgrid), dim3(pblock), lds_trace, S.stream, g, dt, w2);
       HIPCHK(hipGetLastError());
       rc = span(1, nullptr); if (rc) return rc;
-      const uint64_t bwant = cnt / (uint64_t)(kRegion * (bblock / 64)) + 1;
+      const uint64_t bwant = (cnt / (kRegion / 4) + (uint64_t)tgrid + (uint64_t)(bblock / 64) - 1) / (uint64_t)(bblock / 64);   // (quarter regions per workgroup, as above)
       const int bfull = S.cu_count * bres;
       const int gb = S.grid_blocks > 0 ? S.grid_blocks : (bwant < (uint64_t)bfull ? (int)bwant : bfull);
       hipLaunchKernelGGL(isx_bin_discs_kernel, dim3(gb), dim3(bblock), lds_bin, S.stream, dt, w2);
@@ -579,7 +641,8 @@ int enqueue(int sink, const isx_config* c, uint64_t n, uint64_t seed, uint64_t f
   // assist wave per workgroup as well: the one exact test per exiting ray is per-lane work the assist wave does on the spot
   if ((sink == SINK_PERPOS || sink == SINK_DISCPOS) && lean_explicit && S.pipeline && S.assist) {
     const KernelFn afn = sink == SINK_PERPOS ? isx_trace_assist_perpos_kernel : isx_trace_assist_discpos_kernel;
-    const int pblock = S.assist_block;
+    const Shape shp = small_shape(n < kLaunchMax ? n : kLaunchMax, S.assist_block);
+    const int pblock = shp.block;
     const size_t lds_trace = 16 + 64 + sizeof(Geom) + sizeof(DetGrid) + 16 + sizeof(AssistQueues) + (size_t)(kResumeCap + kPendCap) * 64;
     if (S.attr_lds[(const void*)afn] != lds_trace) {
       HIPCHK(hipFuncSetAttribute((const void*)afn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_trace));
@@ -591,7 +654,7 @@ int enqueue(int sink, const isx_config* c, uint64_t n, uint64_t seed, uint64_t f
       Work w2 = wk;
       w2.first = first + off; w2.n = n - off < kLaunchMax ? n - off : kLaunchMax; w2.sub = pick_sub(w2.n);
       rc = next_ctr(&w2.ctr); if (rc) return rc;
-      hipLaunchKernelGGL(afn, dim3(pick_grid(w2.n, pblock, tres)), dim3(pblock), lds_trace, S.stream, g, d, w2);
+      hipLaunchKernelGGL(afn, dim3(pick_grid(w2.n, pblock, tres, pblock / 64 - 1, shp.rays_per_lane)), dim3(pblock), lds_trace, S.stream, g, d, w2);
       HIPCHK(hipGetLastError());
     }
     return span(0, nullptr);
@@ -621,6 +684,15 @@ int upload_aux(const double* host, size_t n_doubles) {
     const size_t cap = n_doubles < 4096 ? 4096 : n_doubles;
     HIPCHK(hipMalloc(&S.d_aux, cap * sizeof(double)));
     S.cap_aux = cap;
+  }
+  if (n_doubles * sizeof(double) <= 4096 && ensure_pin(1u << 17) == ISX_OK) {
+    // a short list (traceRays' one detector): through the far end of the pinned staging buffer -- the copy engine reads it when the
+    // stream gets there, the caller's `host` is free at once, and nothing waits (every blocking call ends with a synchronisation,
+    // so the next call cannot overwrite it too early)
+    unsigned char* slot = S.h_pin + S.cap_pin - 4096;
+    std::memcpy(slot, host, n_doubles * sizeof(double));
+    HIPCHK(hipMemcpyAsync(S.d_aux, slot, n_doubles * sizeof(double), hipMemcpyHostToDevice, S.stream));
+    return ISX_OK;
   }
   HIPCHK(hipMemcpyAsync(S.d_aux, host, n_doubles * sizeof(double), hipMemcpyHostToDevice, S.stream));
   HIPCHK(hipStreamSynchronize(S.stream));   // `host` may be a temporary of the caller
@@ -712,7 +784,15 @@ int ensure_hist(size_t nb) {
 }
 
 int collect_stats(isx_stats* out) {
+  // the census through the pinned staging buffer: copy and re-zero enqueued, ONE synchronisation (it also covers a result staged
+  // by stage_result()); a call that finds nothing enqueued since the last collection has nothing to wait for
+  if (!S.pending && S.spans.empty() && !out) return ISX_OK;
+  int rcp = ensure_pin(0);
+  if (rcp) return rcp;
+  HIPCHK(hipMemcpyAsync(S.h_pin, S.d_stats, 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost, S.stream));
+  HIPCHK(hipMemsetAsync(S.d_stats, 0, 8 * sizeof(unsigned long long), S.stream));   // (ahead of whatever this stream launches next)
   HIPCHK(hipStreamSynchronize(S.stream));
+  S.pending = false;
   double ms = 0;
   S.last_ms[0] = S.last_ms[1] = S.last_ms[2] = 0;
   for (const State::Span& sp : S.spans) {
@@ -724,8 +804,7 @@ int collect_stats(isx_stats* out) {
   S.spans.clear();
   S.ev_used = 0;
   unsigned long long h[8];
-  HIPCHK(hipMemcpy(h, S.d_stats, sizeof(h), hipMemcpyDeviceToHost));
-  HIPCHK(hipMemsetAsync(S.d_stats, 0, sizeof(h), S.stream));   // (ahead of whatever this stream launches next: no second blocking call)
+  std::memcpy(h, S.h_pin, sizeof(h));
   // stats[7]: a wave of an assist-wave trace kernel gave up a bounded wait (its results are incomplete): never seen, never silent
   if (h[7] != 0) { S.last_hip = (int)hipErrorLaunchFailure; return ISX_ERR_HIP; }
   if (out) {
@@ -824,6 +903,8 @@ void isx_shutdown(void) {
   if (S.d_stats) (void)hipFree(S.d_stats);
   if (S.d_aux) (void)hipFree(S.d_aux);
   S.d_aux = nullptr; S.cap_aux = 0;
+  if (S.h_pin) (void)hipHostFree(S.h_pin);
+  S.h_pin = nullptr; S.cap_pin = 0; S.pending = false; S.occ.clear();
   for (int b = 0; b < State::kRecBufs; ++b) {
     if (S.d_rec[b]) (void)hipFree(S.d_rec[b]);
     if (S.d_rec_counts[b]) (void)hipFree(S.d_rec_counts[b]);
@@ -861,7 +942,13 @@ int isx_set_option(const char* key, int64_t value) {
   if (!std::strcmp(key, "bin_block")) { if (value != 256 && value != 512 && value != 1024) return ISX_ERR_BAD_ARG; S.bin_block = (int)value; return ISX_OK; }
   if (!std::strcmp(key, "overlap_trace_streams")) { if (value < 1 || value > 2) return ISX_ERR_BAD_ARG; S.overlap_trace_streams = (int)value; return ISX_OK; }
   if (!std::strcmp(key, "overlap")) { if (value < 0 || value > 64) return ISX_ERR_BAD_ARG; S.overlap = (int)value; return ISX_OK; }
-  if (!std::strcmp(key, "assist_block")) { if (value < 128 || value > ISX_ASSIST_BLOCK || value % 64) return ISX_ERR_BAD_ARG; S.assist_block = (int)value; return ISX_OK; }
+  // ("assist_block" 0: back to the default -- 768 threads, 256 for launches below 1e6 rays)
+  if (!std::strcmp(key, "assist_block")) {
+    if (value == 0) { S.assist_block = ISX_ASSIST_BLOCK; S.assist_block_set = false; return ISX_OK; }
+    if (value < 128 || value > ISX_ASSIST_BLOCK || value % 64) return ISX_ERR_BAD_ARG;
+    S.assist_block = (int)value; S.assist_block_set = true; return ISX_OK;
+  }
+  if (!std::strcmp(key, "rays_per_lane")) { if (value < 0 || value > 4096) return ISX_ERR_BAD_ARG; S.rays_per_lane = (int)value; return ISX_OK; }
   if (!std::strcmp(key, "disc_pipeline")) { if (value < 0 || value > 1) return ISX_ERR_BAD_ARG; S.disc_pipeline = (int)value; return ISX_OK; }
   if (!std::strcmp(key, "assist")) { if (value < 0 || value > 1) return ISX_ERR_BAD_ARG; S.assist = (int)value; return ISX_OK; }
   if (!std::strcmp(key, "bin_cols")) { if (value < 0 || value > 2) return ISX_ERR_BAD_ARG; S.bin_cols = (int)value; return ISX_OK; }
@@ -918,8 +1005,11 @@ int isx_fluxmap(const isx_config* cfg, uint64_t n_rays, uint64_t seed, uint64_t 
   HIPCHK(hipMemsetAsync(S.d_hist, 0, nb * sizeof(unsigned long long), S.stream));
   rc = enqueue(SINK_FLUX, cfg, n_rays, seed, first_ray, S.d_hist, 0, nullptr, 0, 0);
   if (rc) return rc;
-  HIPCHK(hipMemcpyAsync(hits, S.d_hist, nb * sizeof(unsigned long long), hipMemcpyDeviceToHost, S.stream));
-  return collect_stats(stats);
+  rc = stage_result(S.d_hist, nb * sizeof(unsigned long long));
+  if (rc) return rc;
+  rc = collect_stats(stats);
+  if (rc == ISX_OK) fetch_result(hits, nb * sizeof(unsigned long long));
+  return rc;
 }
 
 int isx_trace_endstates(const isx_config* cfg, uint64_t n, uint64_t seed, uint64_t first, int32_t* status,
@@ -1067,11 +1157,9 @@ int isx_trace_rays_detector(const isx_config* cfg, const double* detector, doubl
   pp.map_first = first_ray; pp.rays_per_group = n_rays > 0 ? n_rays : 1; pp.fold = 1; pp.d_table = S.d_aux; pp.width = width;
   rc = enqueue(SINK_PERPOS, cfg, n_rays, seed, first_ray, S.d_hist, 1, nullptr, 0, 0, &pp);
   unsigned long long h = 0;
-  if (rc == ISX_OK) {
-    const hipError_t e = hipMemcpyAsync(&h, S.d_hist, sizeof(h), hipMemcpyDeviceToHost, S.stream);
-    if (e != hipSuccess) { S.last_hip = (int)e; rc = ISX_ERR_HIP; }
-  }
+  if (rc == ISX_OK) rc = stage_result(S.d_hist, sizeof(h));
   const int rc2 = collect_stats(stats);
+  if (rc == ISX_OK && rc2 == ISX_OK) fetch_result(&h, sizeof(h));
   *hit_count = h;
   return rc ? rc : rc2;
 }

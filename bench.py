@@ -57,6 +57,8 @@ def parse():
                          "algorithm); chord: ISX_TRACE_CHORD, next wall point sampled directly (same distribution)")
     ap.add_argument("--reduce", choices=["auto", "device", "host"], default="auto",
                     help="where the histogram lives for the all-reduce")
+    ap.add_argument("--no-extras", action="store_true",
+                    help="skip the extra timed legs of the N = 1 line (configs0 / configs2 / configs3 / perpos_8p1e8 / size_sweep / surfaces)")
     return ap.parse_args()
 
 
@@ -96,6 +98,172 @@ def cpu_baseline(seed, n_req):
     return {"value": n_req / dt / 1e6, "unit": "Mrays/s", "cores": threads, "kind": "port", "reference_published": REFERENCE_PUBLISHED,
             "sample": f"{n_req} rays of the same workload (180x90 map, src(-60,0,-75), port 170deg), "
                       f"oracle/libisx_oracle.so, OpenMP {threads} threads, {dt:.1f} s"}
+
+
+def load_pmc():
+    """profiles/pmc_summary.json (tools/summarize_profile.py) if it was measured on THIS kernel code -> (dict, note)"""
+    pj, note = {}, "no profiles/pmc_summary.json"
+    pmc = os.path.join(ROOT, "profiles", "pmc_summary.json")
+    if os.path.exists(pmc):
+        try:
+            pj = json.load(open(pmc))
+            sha = kernel_source_sha()
+            if pj.get("kernel_source_sha") != sha:
+                note = (f"STALE: profiles/pmc_summary.json (tag {pj.get('tag')}) was measured on kernel sources "
+                        f"{pj.get('kernel_source_sha')}, this build is {sha}: executed-instruction rooflines omitted")
+                pj = {}
+            else:
+                note = f"profiles/pmc_summary.json tag {pj.get('tag')}, kernel sources {sha}"
+        except Exception as e:  # a broken file is reported, not fatal
+            pj, note = {}, f"unreadable profiles/pmc_summary.json: {e}"
+    return pj, note
+
+
+def issue_block(kernel, live_ms, pk, n, cus):
+    """VALU-issue roofline of one kernel: executed SQ_INSTS_VALU per ray (its PMC pass) x rays / its LIVE time.
+    `peak` / `frac` price the executed mix by class (`cycle_prices`, each with its source in `cycle_price_sources`: the
+    guide's cycle constants or tools/ubench/inst_rate.hip measured on MI355X; a PACKED f32 instruction costs what an f64 one
+    does) against 1024 SIMDs x 2.4 GHz -- `peak` is the wave-instruction rate this mix could issue at best, `frac` = achieved /
+    peak (= `frac_mix`); `frac_spec` prices f64 and packed f32 at the guide's 4 cycles (78.6 TFLOP/s vector FP64) instead of the
+    4.6 measured; `frac_4cycle` / `peak_4cycle` charge every instruction 4 cycles (the convention of rounds 1-2: a
+    mixed stream can exceed it); `valu_idle` says whether the VALU had idle cycles at all (`valu_busy_counter_ratio` is
+    4 x SQ_ACTIVE_INST_VALU / SIMD-cycles: overlapping issue is counted more than once, so it exceeds 1 on a saturated
+    kernel -- a counter ratio, not a fraction)."""
+    peak_issue = cus * 4 * VALU_CLOCK_GHZ / 4.0
+    blk = {"bound": "valu_issue", "kernel": kernel, "kernel_ms": live_ms, "peak": peak_issue, "unit": "G wave-instr/s",
+           "achieved": None, "frac": None, "traffic": (pk or {}).get("hbm_bytes_per_launch")}
+    if pk and pk.get("valu_wave_insts_per_ray") and live_ms > 0:
+        ach = pk["valu_wave_insts_per_ray"] * n / (live_ms * 1e-3) / 1e9
+        blk.update(achieved=ach, frac=ach / peak_issue, valu_wave_insts_per_ray=pk["valu_wave_insts_per_ray"],
+                   valu_idle=pk.get("valu_idle"), valu_busy_counter_ratio=pk.get("valu_busy_counter_ratio"),
+                   valu_lane_utilization=pk.get("valu_lane_utilization"),
+                   profiled_kernel_ms=pk.get("kernel_ms"), profiled_clock_ghz=pk.get("clock_ghz"))
+        mix = pk.get("issue_mix")
+        if mix:
+            # the roofline proper: what THIS instruction mix can issue per second (peak), against what it did (achieved)
+            simd_cycles = cus * 4 * VALU_CLOCK_GHZ * 1e9 * live_ms * 1e-3
+            fm = mix["cycles_per_ray"] * n / simd_cycles
+            blk.update(peak_mix_cycles_per_ray=mix["cycles_per_ray"], frac_mix=fm, frac_4cycle=ach / peak_issue,
+                       peak_4cycle=peak_issue, peak=ach / fm, frac=fm, cycle_prices=mix.get("cycles"),
+                       cycle_price_sources=mix.get("price_sources"))
+            if mix.get("cycles_per_ray_spec"):
+                blk.update(frac_spec=mix["cycles_per_ray_spec"] * n / simd_cycles, spec_cycles_per_ray=mix["cycles_per_ray_spec"],
+                           spec_prices=mix.get("cycles_spec"))
+    return blk
+
+
+def disc_positions(np):
+    """rootMacros::detectorDiskPlacement (integratingSphereDetectorSweep.C:145-172): 181 x 2 discs at 200 cm from the origin, tube
+    axis (sin rotTheta, 0, cos rotTheta) for every phi (TGeoRotation::RotateY left-multiplies: DESIGN.md section 2.4)."""
+    import math
+    discs = []
+    for th in np.arange(-45.0, 45.0 + 1e-9, 0.5):
+        for ph in (0.0, 180.0):
+            t_, p_ = math.radians(th), math.radians(ph)
+            x, y, z = 200 * math.sin(t_) * math.cos(p_), 200 * math.sin(t_) * math.sin(p_), -200 * math.cos(t_)
+            rot = -math.atan2(math.sqrt(x * x + y * y), -100 - z)
+            discs.append([x, y, z, math.sin(rot), 0.0, math.cos(rot)])
+    return np.array(discs)
+
+
+def extra_legs(isx, np, seed, cus, pj):
+    """The other BASELINE configurations as timed legs of the N = 1 line (VERDICT r04 'next' 2): every number is wall clock around
+    blocking calls of the C ABI (host synchronisation included), next to the library's HIP-event kernel times.  Extra keys only:
+    the headline loop above is untouched and runs first."""
+    sections = pj.get("sections", {}) if pj else {}
+
+    def timed(fn, reps, warm=1):
+        for _ in range(warm):
+            fn()
+        isx.sync()
+        t0 = time.perf_counter()
+        ks, kinds, st = [], [], None
+        for _ in range(reps):
+            st = fn()
+            ks.append(st.t_kernel_ms)
+            kinds.append(isx.last_kernel_ms())
+        wall = (time.perf_counter() - t0) * 1e3 / reps
+        return wall, float(np.mean(ks)), [float(np.mean([k[i] for k in kinds])) for i in range(3)], st
+
+    def blocks(section, kinds, n):
+        sec = sections.get(section, {}).get("kernels", {})
+        out = {}
+        for kname, pk in sec.items():
+            live = kinds[1] if "trace" in kname else kinds[2]
+            out[kname] = issue_block(kname, live, pk, n, cus)
+        return out or None
+
+    legs = {}
+    # ---- configs[0]: the reference's own call size (fluxAtObserverOptimize.C:568: 50 000 rays per call, 16 200 calls per map)
+    c = isx.default_config()
+    det = isx.detector_table(c)[90 * c.n_phi + 45]
+    n0 = 50_000
+    k = [0]
+
+    def small_flux():
+        k[0] += 1
+        return isx.fluxmap(c, n0, seed, k[0] * n0)[1]
+
+    def small_det():
+        k[0] += 1
+        return isx.trace_rays_detector(c, det, c.det_diameter, n0, seed, k[0] * n0)[1]
+
+    w1, k1, kk1, _ = timed(small_flux, 50, 3)
+    w2, k2, kk2, _ = timed(small_det, 50, 3)
+    legs["configs0"] = {"workload": "BASELINE configs[0]: 50 000 rays per call, src(-60,0,-75), 180x90 grid (fluxAtObserver.C / fluxAtObserverOptimize.C:568)",
+                        "isx_fluxmap": {"ms_per_call": w1, "kernel_ms": k1, "trace_ms": kk1[1], "bin_ms": kk1[2], "Mrays_s": n0 / w1 / 1e3},
+                        "isx_trace_rays_detector": {"ms_per_call": w2, "kernel_ms": k2, "Mrays_s": n0 / w2 / 1e3,
+                                                    "map_of_16200_calls_s": 16200 * w2 / 1e3}}
+    # ---- configs[2]: nonLambertianFlux.C source model (BRDF re-scatter), 5e7 rays
+    c2 = isx.default_config()
+    c2.source_model = isx.SOURCE_BRDF; c2.brdf[0], c2.brdf[1], c2.brdf[2] = 0.3, 0.4, 0.6
+    c2.roughness_rad = 0.5; c2.reflectance = 1.0; c2.max_points = 10000; c2.box_half = 200.0
+    n2 = 50_000_000
+    w, km, kk, st = timed(lambda: isx.fluxmap(c2, n2, seed)[1], 3)
+    legs["configs2"] = {"workload": "BASELINE configs[2]: nonLambertianFlux.C:235-304 source model (primary trace, BRDF re-scatter, second trace), 5e7 rays, "
+                                    "same geometry and grid", "rays": n2, "value": n2 / w / 1e3, "unit": "Mrays/s", "ms_per_call": w, "kernel_ms": km,
+                        "trace_ms": kk[1], "bin_ms": kk[2], "wall_hits_per_ray": st.wall_hits / n2, "exit_lines_per_ray": st.counted_below_z / n2,
+                        "issue_blocks": blocks("brdf", kk, n2)}
+    # ---- configs[3]: integratingSphereDetectorSweep.C:31-105, 362 disc positions -- sharing 1e7 rays, and the macro's own loop
+    c3 = isx.default_config()
+    c3.r_out = 105.0; c3.reflectance = 1.0; c3.roughness_rad = 0.0; c3.max_points = 10000; c3.box_half = 200.0
+    c3.src[2] = -80.0
+    discs = disc_positions(np)
+    n3 = 10_000_000
+    w, km, kk, st = timed(lambda: isx.disc_sweep(c3, discs, 5.0, 0.1, n3, 7)[1], 3)
+    rpp = 1_000_000
+    wp, kmp, kkp, stp = timed(lambda: isx.disc_sweep_per_position(c3, discs, 5.0, 0.1, rpp, 7)[1], 2)
+    legs["configs3"] = {"workload": "BASELINE configs[3]: integratingSphereDetectorSweep.C, 362 disc positions (r 5 cm, 200 cm from the origin), shell 100.1-105 cm, rho 1",
+                        "shared_rays": {"rays": n3, "value": n3 / w / 1e3, "unit": "Mrays/s", "ms_per_call": w, "kernel_ms": km, "trace_ms": kk[1],
+                                        "bin_ms": kk[2], "wall_hits_per_ray": st.wall_hits / n3, "issue_blocks": blocks("discs", kk, n3)},
+                        "per_position_loop": {"rays": rpp * len(discs), "rays_per_position": rpp, "value": rpp * len(discs) / wp / 1e3, "unit": "Mrays/s",
+                                              "ms_per_call": wp, "kernel_ms": kmp}}
+    # ---- the reference's 12 524 s run: 50 000 fresh rays per detector position, 16 200 positions (fluxAtObserverOptimize.C:542-579)
+    c = isx.default_config()
+    w, km, kk, st = timed(lambda: isx.fluxmap_per_position(c, 50_000, seed)[1], 2)
+    legs["perpos_8p1e8"] = {"workload": "fluxAtObserverOptimize.C:542-579: 50 000 fresh rays per position x 16 200 positions (the reference: 12 523.9 s)",
+                            "rays": 50_000 * 16200, "value": 50_000 * 16200 / w / 1e3, "unit": "Mrays/s", "ms_per_call": w, "kernel_ms": km,
+                            "speedup_vs_reference_published": 12523.937 / (w / 1e3)}
+    # ---- size sweep of the headline map (north_star: "50k -> 1e9-ray runs"): one blocking isx_fluxmap call per size
+    sweep = []
+    for n, reps in ((50_000, 30), (500_000, 20), (5_000_000, 8), (50_000_000, 3), (1_000_000_000, 1)):
+        w, km, kk, st = timed(lambda: isx.fluxmap(c, n, seed)[1], reps, 1 if n < 10 ** 9 else 0)
+        sweep.append({"rays": n, "Mrays_s": n / w / 1e3, "ms_per_call": w, "kernel_ms": km, "trace_ms": kk[1], "bin_ms": kk[2]})
+    legs["size_sweep"] = sweep
+    # ---- the other border models / hit line on the same pipeline (SURVEY.md 8 f3; "nonLambertianFlux copy.C":31-70,188-221)
+    surf = {}
+    for name, setup, sec in (("lobe_rho0p99", lambda q: setattr(q, "surface_model", 1), "lobe"),
+                             ("rough_specular_sigma0p5", lambda q: (setattr(q, "lambertian", 0), setattr(q, "roughness_rad", 0.5)), "rough"),
+                             ("origin_compat_hit_line", lambda q: setattr(q, "hit_line_mode", 1), None)):
+        q = isx.default_config()
+        setup(q)
+        ns = 50_000_000
+        w, km, kk, st = timed(lambda: isx.fluxmap(q, ns, seed)[1], 2)
+        surf[name] = {"rays": ns, "value": ns / w / 1e3, "unit": "Mrays/s", "ms_per_call": w, "kernel_ms": km, "trace_ms": kk[1], "bin_ms": kk[2],
+                      "wall_hits_per_ray": st.wall_hits / ns, "bin_increments_per_ray": st.bin_increments / ns,
+                      "issue_blocks": blocks(sec, kk, ns) if sec else None}
+    legs["surfaces"] = surf
+    return legs
 
 
 def main():
@@ -335,6 +503,10 @@ def main():
                     "rays_per_gpu_per_step": n3, "n_discs": int(len(discs)), "value": n3 * world * a.steps / dt3 / 1e6, "unit": "Mrays/s",
                     "ms_per_step": dt3 / a.steps * 1e3, "kernel_ms_min_max_over_ranks": over_ranks(k3),
                     "allreduce_ms_min_max_over_ranks": over_ranks(ar3), "disc_hits_last_step": int(disc_dev.sum().item())}
+    # the other BASELINE configurations as timed legs of the N = 1 line (extra keys only; the headline loop above ran first)
+    legs = None
+    if world == 1 and a.rays <= 0 and not a.no_extras:
+        legs = extra_legs(isx, np, a.seed, cus, load_pmc()[0])
     if rank == 0:
         rays_total = n * world * a.steps
         value = rays_total / dt / 1e6
@@ -354,61 +526,23 @@ def main():
         fp64_tflops = n * f_ray / (k_ms * 1e-3) / 1e12
         # executed-instruction counters come from the committed rocprofv3 PMC passes (profiles/pmc_summary.json,
         # written by tools/summarize_profile.py).  They are used only if they were measured on THIS kernel code.
-        pj, pmc_note = {}, "no profiles/pmc_summary.json"
-        pmc = os.path.join(ROOT, "profiles", "pmc_summary.json")
-        if os.path.exists(pmc):
-            try:
-                pj = json.load(open(pmc))
-                sha = kernel_source_sha()
-                if pj.get("kernel_source_sha") != sha:
-                    pmc_note = (f"STALE: profiles/pmc_summary.json (tag {pj.get('tag')}) was measured on kernel sources "
-                                f"{pj.get('kernel_source_sha')}, this build is {sha}: executed-instruction rooflines omitted")
-                    pj = {}
-                else:
-                    pmc_note = f"profiles/pmc_summary.json tag {pj.get('tag')}, kernel sources {sha}"
-            except Exception as e:  # a broken file is reported, not fatal
-                pj, pmc_note = {}, f"unreadable profiles/pmc_summary.json: {e}"
+        pj, pmc_note = load_pmc()
         traffic, fp64 = pj.get("hbm_bytes_per_launch"), pj.get("fp64_executed")
         peak_issue = cus * 4 * VALU_CLOCK_GHZ / 4.0
-
-        def issue_block(kernel, live_ms, pk):
-            """VALU-issue roofline of one kernel: executed SQ_INSTS_VALU per ray (its PMC pass) x rays / its LIVE time.
-            `peak` / `frac` price the executed mix by class (`cycle_prices`, each with its source in `cycle_price_sources`: the
-            guide's cycle constants or tools/ubench/inst_rate.hip measured on MI355X; a PACKED f32 instruction costs what an f64 one
-            does) against 1024 SIMDs x 2.4 GHz -- `peak` is the wave-instruction rate this mix could issue at best, `frac` = achieved /
-            peak (= `frac_mix`); `frac_4cycle` / `peak_4cycle` charge every instruction 4 cycles (the convention of rounds 1-2: a
-            mixed stream can exceed it); `valu_idle` says whether the VALU had idle cycles at all (`valu_busy_counter_ratio` is
-            4 x SQ_ACTIVE_INST_VALU / SIMD-cycles: overlapping issue is counted more than once, so it exceeds 1 on a saturated
-            kernel -- a counter ratio, not a fraction)."""
-            blk = {"bound": "valu_issue", "kernel": kernel, "kernel_ms": live_ms, "peak": peak_issue, "unit": "G wave-instr/s",
-                   "achieved": None, "frac": None, "traffic": (pk or {}).get("hbm_bytes_per_launch")}
-            if pk and pk.get("valu_wave_insts_per_ray") and live_ms > 0:
-                ach = pk["valu_wave_insts_per_ray"] * n / (live_ms * 1e-3) / 1e9
-                blk.update(achieved=ach, frac=ach / peak_issue, valu_wave_insts_per_ray=pk["valu_wave_insts_per_ray"],
-                           valu_idle=pk.get("valu_idle"), valu_busy_counter_ratio=pk.get("valu_busy_counter_ratio"),
-                           valu_lane_utilization=pk.get("valu_lane_utilization"),
-                           profiled_kernel_ms=pk.get("kernel_ms"), profiled_clock_ghz=pk.get("clock_ghz"))
-                mix = pk.get("issue_mix")
-                if mix:
-                    # the roofline proper: what THIS instruction mix can issue per second (peak), against what it did (achieved)
-                    fm = mix["cycles_per_ray"] * n / (cus * 4 * VALU_CLOCK_GHZ * 1e9 * live_ms * 1e-3)
-                    blk.update(peak_mix_cycles_per_ray=mix["cycles_per_ray"], frac_mix=fm, frac_4cycle=ach / peak_issue,
-                               peak_4cycle=peak_issue, peak=ach / fm, frac=fm, cycle_prices=mix.get("cycles"),
-                               cycle_price_sources=mix.get("price_sources"))
-            return blk
+        del peak_issue
 
         kern = pj.get("kernels", {})
         k_trace = next((k for k in kern if "trace" in k), "isx_trace_assist_kernel")
         k_bin = next((k for k in kern if "bin" in k), "isx_bin_cols_kernel")
         if pipeline:
-            b_trace = issue_block(k_trace, t_trace, kern.get(k_trace))
-            b_bin = issue_block(k_bin, t_bin, kern.get(k_bin))
+            b_trace = issue_block(k_trace, t_trace, kern.get(k_trace), n, cus)
+            b_bin = issue_block(k_bin, t_bin, kern.get(k_bin), n, cus)
             b_trace["algorithmic_hbm_bytes"], b_bin["algorithmic_hbm_bytes"] = alg_bytes_trace, alg_bytes_bin
             for b in (b_trace, b_bin):   # HBM bytes the counters saw per launch / the bytes the algorithm needs (1 = no wasted traffic)
                 b["traffic_ratio"] = (b["traffic"] / b["algorithmic_hbm_bytes"]) if b.get("traffic") else None
             dominant, other = (b_bin, b_trace) if t_bin >= t_trace else (b_trace, b_bin)
         else:
-            dominant, other = issue_block("isx_trace_bin_kernel", t_single or k_ms, pj if not kern else None), None
+            dominant, other = issue_block("isx_trace_bin_kernel", t_single or k_ms, pj if not kern else None, n, cus), None
         dominant["note"] = (f"binding resource: VALU issue (no MFMA, HBM idle).  achieved = executed SQ_INSTS_VALU per ray from "
                             f"{pmc_note} x rays / the kernel's live time (HIP events on the library's stream); peak = the rate at which "
                             f"{cus} CUs x 4 SIMDs x {VALU_CLOCK_GHZ} GHz can issue THIS kernel's executed instruction mix (cycles per class in "
@@ -446,7 +580,12 @@ def main():
             # per-rank means of the timed steps, [min, max] over the ranks: kernel time, its two halves, the one all-reduce
             "per_rank_ms_min_max": per_rank,
             "configs4": configs4,
-            "configs3": configs3,
+            "configs3": (legs or {}).get("configs3", configs3),
+            "configs0": (legs or {}).get("configs0"),
+            "configs2": (legs or {}).get("configs2"),
+            "perpos_8p1e8": (legs or {}).get("perpos_8p1e8"),
+            "size_sweep": (legs or {}).get("size_sweep"),
+            "surfaces": (legs or {}).get("surfaces"),
             # the HBM figure the north star asks for: algorithmic bytes (exit lines written once and read once, 48 B each, plus
             # one 129.6 KB histogram) / kernel time against 8 TB/s
             "roofline_hbm": {"bound": "hbm", "achieved": hbm_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",

@@ -21,7 +21,7 @@ def _same(a, b):
 
 
 def _reset(isx):
-    for k, v in (("assist", 1), ("assist_block", 768), ("bin_slots", 1), ("bin_cols", 1), ("pipeline", 1), ("ray_sub", 0), ("grid_blocks", 0),
+    for k, v in (("assist", 1), ("assist_block", 0), ("bin_slots", 1), ("bin_cols", 1), ("pipeline", 1), ("ray_sub", 0), ("grid_blocks", 0),
                  ("overlap", 0), ("overlap_trace_streams", 1), ("trace_block", 512), ("trace_blocks_per_cu", 0), ("disc_pipeline", 1),
                  ("bin_mode", 1), ("pipeline_chunk", 1 << 26), ("surface_pipeline", 1)):
         isx.set_option(k, v)

@@ -14,7 +14,7 @@ import altair_raytracing_amd as isx  # noqa: E402
 
 import argparse
 ap = argparse.ArgumentParser()
-ap.add_argument("--only", choices=["all", "flux", "chord", "brdf", "discs", "perpos"], default="all",
+ap.add_argument("--only", choices=["all", "flux", "chord", "brdf", "discs", "perpos", "lobe", "rough", "compat"], default="all",
                 help="run one configuration only (what tools/profile.sh profiles)")
 ap.add_argument("--reps", type=int, default=0, help="launches per configuration (0: the defaults below)")
 ARGS = ap.parse_args()
@@ -44,6 +44,23 @@ if want("chord"):
     c.trace_mode = 1
     ms, st = best(lambda: isx.fluxmap(c, n, 0x5EED0001)[1])
     out["configs[1] chord mode"] = {"ms": ms, "Mrays_s": n / ms / 1e3}
+
+# the other border models and the origin-compat hit line (round 5: on the assist-wave pipeline; --surface-pipeline 0 = before)
+for name, setup in (("lobe", lambda q: setattr(q, "surface_model", 1)),
+                    ("rough", lambda q: (setattr(q, "lambertian", 0), setattr(q, "roughness_rad", 0.5))),
+                    ("compat", lambda q: setattr(q, "hit_line_mode", 1))):
+    if want(name):
+        c = isx.default_config()
+        setup(c)
+        row = {}
+        for sp in ((1, 0) if ARGS.only == "all" else (1,)):
+            isx.set_option("surface_pipeline", sp)
+            ms, st = best(lambda: isx.fluxmap(c, n, 0x5EED0001)[1], reps=2)
+            row["pipeline" if sp else "fused kernel of round 1 (before)"] = {"ms": ms, "Mrays_s": n / ms / 1e3, "kinds_ms": isx.last_kernel_ms()}
+        isx.set_option("surface_pipeline", 1)
+        row["wall_hits_per_ray"] = st.wall_hits / n
+        out[{"lobe": "cos^2-lobe border (nonLambertianFlux copy.C:31-70), rho 0.99, 5e7", "rough": "rough-specular border, sigma 0.5, rho 0.99, 5e7",
+             "compat": "origin-compat hit line (fluxAtObserverFast.C:1181-1201), 5e7"}[name]] = row
 
 if want("brdf"):
     c = isx.default_config()

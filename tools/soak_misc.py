@@ -47,7 +47,7 @@ for k in range(NG):
         if not ok:
             print("MISMATCH (schedule)", opts, c.trace_mode, c.source_model, flush=True)
 for key, val in dict(pipeline=1, pipeline_chunk=1 << 26, trace_block=512, trace_blocks_per_cu=0, blocks_per_cu=1, grid_blocks=0,
-                     sched_mask=3, sched_min=12, ray_sub=0, assist=1, assist_block=768, bin_slots=1, bin_cols=1, bin_block=512, bin_blocks_per_cu=0,
+                     sched_mask=3, sched_min=12, ray_sub=0, assist=1, assist_block=0, bin_slots=1, bin_cols=1, bin_block=512, bin_blocks_per_cu=0,
                      overlap=0, overlap_trace_streams=1).items():
     isx.set_option(key, val)
 print("schedule soak:", NG, "settings x 3 configurations,", bad, "mismatches", flush=True)

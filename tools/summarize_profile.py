@@ -25,15 +25,17 @@ ap.add_argument("--kernel", default="isx_trace_bin_kernel",
                      "kernel (<tag>_<kernel>) and, with --headline, a combined profiles/pmc_summary.json")
 ap.add_argument("--rays", type=float, default=5e7, help="rays per full-size launch (per-ray figures)")
 ap.add_argument("--headline", action="store_true", help="also write profiles/pmc_summary.json (bench.py's source)")
+ap.add_argument("--section", default="", help="with a kernel list: merge the kernels into profiles/pmc_summary.json under sections[NAME] (what bench.py's "
+                                              "extra legs -- configs2 / configs3 / surfaces -- price their kernels with); same source fingerprint required")
 ap.add_argument("--command", default="python3 bench.py --steps 3 --warmup 1 --cpu-rays 0")
 a = ap.parse_args()
-if "," in a.kernel:   # several kernels of one profiled command: one pass per kernel, then the combined headline file
+if "," in a.kernel or a.section:   # several kernels of one profiled command: one pass per kernel, then the combined headline file
     import subprocess, sys
     parts = {}
     for kname in a.kernel.split(","):
         short = kname.replace("isx_", "").replace("_kernel", "")
         subprocess.check_call([sys.executable, os.path.abspath(__file__), f"{a.tag}_{short}", a.note, "--name", a.name, "--kernel", kname,
-                               "--rays", str(a.rays), "--command", a.command])
+                               "--rays", str(a.rays), "--command", a.command])   # (a single kernel with --section works the same way)
         parts[kname] = json.load(open(os.path.join(ROOT, "profiles", f"{a.tag}_{short}_pmc_summary.json")))
     if a.headline:
         comb = {"tag": a.tag, "kernel": a.kernel, "rays_per_launch": a.rays,
@@ -46,8 +48,23 @@ if "," in a.kernel:   # several kernels of one profiled command: one pass per ke
             comb["fp64_executed"] = {"wave_insts_per_ray": sum(x["wave_insts_per_ray"] for x in f64),
                                      "lane_flop_per_ray": sum(x["lane_flop_per_ray"] for x in f64),
                                      "share_of_valu": sum(x["wave_insts_per_ray"] for x in f64) / comb["valu_wave_insts_per_ray"]}
+        keep = {}
+        try:   # (sections measured on the same sources survive a new headline pass)
+            old = json.load(open(os.path.join(ROOT, "profiles", "pmc_summary.json")))
+            if old.get("kernel_source_sha") == comb["kernel_source_sha"]:
+                keep = old.get("sections", {})
+        except Exception:
+            pass
+        comb["sections"] = keep
         json.dump(comb, open(os.path.join(ROOT, "profiles", "pmc_summary.json"), "w"), indent=1)
         json.dump(comb, open(os.path.join(ROOT, "profiles", f"{a.tag}_pmc_summary.json"), "w"), indent=1)
+    if a.section:
+        head = json.load(open(os.path.join(ROOT, "profiles", "pmc_summary.json")))
+        sha = next(iter(parts.values()))["kernel_source_sha"]
+        if head.get("kernel_source_sha") != sha:
+            raise SystemExit(f"profiles/pmc_summary.json is for sources {head.get('kernel_source_sha')}, this pass for {sha}: run the headline pass first")
+        head.setdefault("sections", {})[a.section] = {"tag": a.tag, "rays_per_launch": a.rays, "command": a.command, "kernels": parts}
+        json.dump(head, open(os.path.join(ROOT, "profiles", "pmc_summary.json"), "w"), indent=1)
     raise SystemExit(0)
 tag, note, KERNEL, RAYS = a.tag, a.note, a.kernel, a.rays
 os.makedirs(os.path.join(ROOT, "profiles"), exist_ok=True)
@@ -199,7 +216,11 @@ if pmc:
         price = {"f64": 4.6, "f64_trans": 16.0, "f32_arith": 4.6 if packed else 2.35, "f32_trans": 4.0, "int64_mad": 7.0, "cvt": 4.0, "other_32bit": 2.0}
         mix_cycles = (price["f64"] * (add + mul + fma) + price["f64_trans"] * trans + price["f32_arith"] * f32n + price["f32_trans"] * f32[3] +
                       price["int64_mad"] * i64 + price["cvt"] * cvt + price["other_32bit"] * (i32 + other))
-        summ["issue_mix"] = {"cycles_per_ray": mix_cycles / RAYS, "uniform_4_cycles_per_ray": 4.0 * pmc["SQ_INSTS_VALU"] / RAYS,
+        # the same mix at the guide's prices ("spec": 78.6 TFLOP/s vector FP64 = one f64 wave-instruction per 4 cycles; packed f32 likewise)
+        spec = dict(price, f64=4.0, f32_arith=4.0 if packed else 2.0)
+        spec_cycles = (spec["f64"] * (add + mul + fma) + spec["f64_trans"] * trans + spec["f32_arith"] * f32n + spec["f32_trans"] * f32[3] +
+                       spec["int64_mad"] * i64 + spec["cvt"] * cvt + spec["other_32bit"] * (i32 + other))
+        summ["issue_mix"] = {"cycles_per_ray_spec": spec_cycles / RAYS, "cycles_spec": spec, "cycles_per_ray": mix_cycles / RAYS, "uniform_4_cycles_per_ray": 4.0 * pmc["SQ_INSTS_VALU"] / RAYS,
                              "unclassified_valu_per_ray": other / RAYS, "cycles": price, "f32_arithmetic_is_packed": packed,
                              "price_sources": {"f64": "tools/ubench/inst_rate.hip (4.36-4.69)", "f64_trans": "inst_rate.hip", "int64_mad": "inst_rate.hip",
                                                "f32_arith": "inst_rate.hip (v_pk_fma_f32 4.75 / v_pk_mul_f32 4.48 packed, v_fma_f32 2.35 scalar)",
@@ -213,6 +234,8 @@ if pmc:
             for label, clk in (("2.4 GHz", 2.4e9), ("the measured clock", summ.get("clock_ghz", 2.4) * 1e9)):
                 lines.append(f"  * fraction of the mix-aware issue peak at {label}: {mix_cycles / (1024 * clk * t):.3f}")
             summ["issue_mix"]["frac_at_2p4GHz"] = mix_cycles / (1024 * 2.4e9 * t)
+            summ["issue_mix"]["frac_spec_at_2p4GHz"] = spec_cycles / (1024 * 2.4e9 * t)
+            lines.append(f"  * at the guide's prices (f64 and packed f32 4 cycles): {spec_cycles/RAYS:.1f} cycles per ray, fraction {spec_cycles / (1024 * 2.4e9 * t):.3f} at 2.4 GHz")
             summ["issue_mix"]["frac_at_measured_clock"] = mix_cycles / (1024 * summ.get("clock_ghz", 2.4) * 1e9 * t)
         if big:
             tf = lane_flop / (sum(big) / len(big) * 1e-3) / 1e12
