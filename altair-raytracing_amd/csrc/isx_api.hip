@@ -485,7 +485,11 @@ int enqueue(int sink, const isx_config* c, uint64_t n, uint64_t seed, uint64_t f
     typedef void (*BinFn)(const DetGrid, const Work);
     const BinFn bin_fn = cols ? isx_bin_cols_kernel : slots ? isx_bin_slots_kernel : isx_bin_lines_kernel;
     const uint64_t chunk0 = n < S.pipe_chunk ? n : S.pipe_chunk;
-    const Shape shp = assist ? small_shape(chunk0, S.assist_block) : Shape{S.trace_block, 4};
+    // (the lobe / rough-specular kernels hold 87-93 VGPRs -- four waves per SIMD -- and hand over as often as the lean one at a third
+    //  of its pace: 512-thread workgroups, 7 tracer waves per assist wave and two workgroups per CU, measured 47.1 against 48.3 ms
+    //  and 33.4 against 34.0 ms for 5e7 rays, profiles/r05_surface_shapes.json)
+    const int ablock = (!S.assist_block_set && (p_lobe || p_rough)) ? 512 : S.assist_block;
+    const Shape shp = assist ? small_shape(chunk0, ablock) : Shape{S.trace_block, 4};
     const int pblock = shp.block, bblock = slots ? kBlock : S.bin_block;
     const int ptracers = assist ? pblock / 64 - 1 : pblock / 64;
     const size_t lds_bin = lds_tables + (cols ? (size_t)(d.n_theta + 4) * sizeof(RowX) + (size_t)(bblock / 64) * kColWaveWords * 4

@@ -3690,6 +3690,7 @@ extern "C" __global__ void isx_mathprobe_kernel(int op, const double* __restrict
     case 9: out[i] = neg_rcp_unit(a[i]); break;
     case 10: circle_point(a[i], co, s); out[i] = co; break;
     case 11: circle_point(a[i], co, s); out[i] = s; break;
+    case 12: case 13: case 14: { V3 v; v.x = a[i]; v.y = b[i]; v.z = c[i]; const V3 r = tv_unit_n(v); out[i] = op == 12 ? r.x : op == 13 ? r.y : r.z; break; }
     default: sincos_cw(a[i], s, co); out[i] = co; break;
   }
 }

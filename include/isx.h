@@ -204,7 +204,8 @@ int isx_set_option(const char* key, int64_t value);
 /* Device-side probe of the numeric contract (tests): out[i] = op(a[i],b[i],c[i]) with
  * op 0 sqrt, 1 a/b, 2 fma, 3 log, 4/5 sin/cos(2*pi*a), 6/7 sin/cos(a), 8 the hot loop's sqrt for operands
  * in [2^-33,1], 9 its -1/x for |x| in [1,2] (both must equal the IEEE results),
- * 10/11 cos/sin of the emission azimuth (oracle: isxo_circle_point). */
+ * 10/11 cos/sin of the emission azimuth (oracle: isxo_circle_point), 12/13/14 the x/y/z of TVector3(a,b,c).Unit() as the lobe
+ * sampler forms it (must equal the plain-operation result). */
 int isx_mathprobe(int op, const double* a, const double* b, const double* c, double* out, int32_t n);
 
 /*

@@ -190,3 +190,28 @@ def test_cut_short_reference_maps_bin_by_bin(isx, name):
     print(f"{name}: {rows} rows, chi2/dof {chi2:.4f} ({use.sum()} bins), total ratio {ratio:.5f}")
     assert use.sum() > 0.95 * rows and chi2 < 1.08, (name, chi2)
     assert 0.985 < ratio < 1.015, (name, ratio)
+
+
+def test_lobe_unit_vectors_are_tvector3_unit(isx):
+    """lobe_try() normalises with tv_unit_n(): sqrt / reciprocal without the general expansions' range scaling where the squared
+    length is in [2^-200, 2^200], TVector3::Unit's plain operations elsewhere.  Bit-equal to a * (1.0 / sqrt(x*x + y*y + z*z)) over
+    the operand families of the sampler: near-unit normals of the inner sphere, (w_z, 0, -w_x) projections down to 1e-30 and to
+    exact zero, near-unit combinations -- and wild magnitudes on both sides of the guard."""
+    rng = np.random.default_rng(5)
+    n = 2_000_000
+    v = rng.standard_normal((n, 3))
+    v /= np.linalg.norm(v, axis=1)[:, None]
+    fam = [v * (1.0 + rng.uniform(-1e-12, 1e-12, (n, 1))),                                    # normals: q * (-1/r_in)
+           np.stack([v[:, 2], np.zeros(n), -v[:, 0]], 1),                                      # TVector3(0,1,0).Cross(w)
+           np.stack([v[:, 2], np.zeros(n), -v[:, 0]], 1) * 10.0 ** rng.uniform(-30, 0, (n, 1)),
+           v * 10.0 ** rng.uniform(-140, 140, (n, 1)),                                          # across the guard at 2^-+100 in length
+           np.array([[0.0, 0.0, 0.0], [0.0, 1.0, 0.0], [1e-160, 0.0, 0.0], [3.0, 4.0, 12.0], [2.0 ** -100, 0.0, 0.0], [2.0 ** 100, 0.0, 0.0]])]
+    for a in fam:
+        x, y, z = (np.ascontiguousarray(a[:, k]) for k in range(3))
+        tot2 = x * x + y * y + z * z
+        with np.errstate(divide="ignore", invalid="ignore", over="ignore"):
+            tot = np.where(tot2 > 0, 1.0 / np.sqrt(tot2), 1.0)
+        for op, comp in ((12, x), (13, y), (14, z)):
+            got = isx.mathprobe(op, x, y, z)
+            want = comp * tot
+            assert np.array_equal(got.view(np.uint64), want.view(np.uint64)), op
