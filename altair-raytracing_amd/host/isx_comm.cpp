@@ -302,6 +302,19 @@ bool rccl_init(const Comm& c) {
 // RCCL transport: ONE in-place ncclAllReduce(ncclSum, ncclUint64) per call on one stream, one synchronisation ("a
 // single all-reduce of the histogram").  Everything that is not a sum travels as per-rank slots of the SUM buffer (see
 // reduce_collective): a slot is written by one rank and zero on all others, so its sum is that rank's value.
+// A rank that cannot ENTER the collective (a local HIP failure between rccl_init() and ncclAllReduce: no memory for the buffer,
+// a failed copy of its contribution) must not leave the others waiting in an all-reduce that has no time-out: it aborts the
+// communicator, which makes the peers' ncclAllReduce / stream synchronisation return an error -- every rank then reports a failure
+// (ADVICE r04).  After an abort this process has no communicator any more (R.failed: rccl_init() refuses to build a second one).
+bool abort_comm(const char* why) {
+  std::cerr << "Error: isx_comm: " << why << ": aborting the communicator so that no rank waits for this one" << std::endl;
+  if (R.ready) {
+    (void)ncclCommAbort(R.comm);
+    R.ready = false;
+    R.failed = true;
+  }
+  return false;
+}
 struct RcclTransport : Transport {
   bool reserve(size_t total) {
     if (total > R.cap) {
@@ -313,8 +326,9 @@ struct RcclTransport : Transport {
     return true;
   }
   bool exchange_sum(unsigned long long* buf, size_t n) override {
-    if (!reserve(n)) return false;
-    ISX_HIP_OK(hipMemcpyAsync(R.d_buf, buf, n * sizeof(unsigned long long), hipMemcpyHostToDevice, R.stream));
+    if (!reserve(n)) return abort_comm("no device buffer for the collective");
+    if (hipMemcpyAsync(R.d_buf, buf, n * sizeof(unsigned long long), hipMemcpyHostToDevice, R.stream) != hipSuccess)
+      return abort_comm("the copy of this rank's contribution failed");
     ISX_NCCL_OK(ncclAllReduce(R.d_buf, R.d_buf, n, ncclUint64, ncclSum, R.comm, R.stream));
     ISX_HIP_OK(hipMemcpyAsync(buf, R.d_buf, n * sizeof(unsigned long long), hipMemcpyDeviceToHost, R.stream));
     ISX_HIP_OK(hipStreamSynchronize(R.stream));
@@ -323,9 +337,10 @@ struct RcclTransport : Transport {
   // the first n_dev words are already in R.d_buf (the histogram, written there by the kernels: no D2H -> H2D round trip of the
   // 130 KB before the collective); the tail comes from the host.  The whole reduced buffer goes back to `buf`.
   bool exchange_sum_device_head(unsigned long long* buf, size_t n_dev, size_t n) {
-    if (n > R.cap) return false;   // (device_hist() reserved it)
-    if (n > n_dev)
-      ISX_HIP_OK(hipMemcpyAsync(R.d_buf + n_dev, buf + n_dev, (n - n_dev) * sizeof(unsigned long long), hipMemcpyHostToDevice, R.stream));
+    if (n > R.cap) return abort_comm("the collective's device buffer is smaller than the call");   // (device_hist() reserved it)
+    if (n > n_dev &&
+        hipMemcpyAsync(R.d_buf + n_dev, buf + n_dev, (n - n_dev) * sizeof(unsigned long long), hipMemcpyHostToDevice, R.stream) != hipSuccess)
+      return abort_comm("the copy of this rank's census failed");
     ISX_NCCL_OK(ncclAllReduce(R.d_buf, R.d_buf, n, ncclUint64, ncclSum, R.comm, R.stream));
     ISX_HIP_OK(hipMemcpyAsync(buf, R.d_buf, n * sizeof(unsigned long long), hipMemcpyDeviceToHost, R.stream));
     ISX_HIP_OK(hipStreamSynchronize(R.stream));
@@ -438,8 +453,10 @@ int Comm::reduce_device_hist(int local_rc, uint64_t* hits, size_t count, isx_sta
   const size_t ns = st ? (size_t)n_stats : 0;
   std::vector<unsigned long long> h(count + tail_words(ns, world), 0ull);
   pack_tail(h.data() + count, rank, world, local_rc, st, ns);
-  if (local_rc != ISX_OK && hipMemsetAsync(R.d_buf, 0, count * sizeof(unsigned long long), R.stream) != hipSuccess)
-    return local_rc;   // (a failed rank contributes zeros)
+  if (local_rc != ISX_OK && hipMemsetAsync(R.d_buf, 0, count * sizeof(unsigned long long), R.stream) != hipSuccess) {
+    (void)abort_comm("a failed rank could not zero its contribution");   // (a failed rank contributes zeros -- or nobody waits for it)
+    return local_rc;
+  }
   if (!g_rccl.exchange_sum_device_head(h.data(), count, h.size())) return local_rc != ISX_OK ? local_rc : ISX_ERR_HIP;
   const int rc = unpack_tail(h.data() + count, world, st, ns);
   if (rc != ISX_OK) return rc;
