@@ -506,7 +506,11 @@ def main():
     # the other BASELINE configurations as timed legs of the N = 1 line (extra keys only; the headline loop above ran first)
     legs = None
     if world == 1 and a.rays <= 0 and not a.no_extras:
-        legs = extra_legs(isx, np, a.seed, cus, load_pmc()[0])
+        try:
+            legs = extra_legs(isx, np, a.seed, cus, load_pmc()[0])
+        except Exception as e:   # an extra leg must never cost the headline line: report it and go on
+            import traceback
+            legs = {"error": f"{type(e).__name__}: {e}", "traceback": traceback.format_exc()[-1500:]}
     if rank == 0:
         rays_total = n * world * a.steps
         value = rays_total / dt / 1e6
@@ -586,6 +590,7 @@ def main():
             "perpos_8p1e8": (legs or {}).get("perpos_8p1e8"),
             "size_sweep": (legs or {}).get("size_sweep"),
             "surfaces": (legs or {}).get("surfaces"),
+            "extra_legs_error": (legs or {}).get("error"),
             # the HBM figure the north star asks for: algorithmic bytes (exit lines written once and read once, 48 B each, plus
             # one 129.6 KB histogram) / kernel time against 8 TB/s
             "roofline_hbm": {"bound": "hbm", "achieved": hbm_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",

@@ -191,6 +191,9 @@ int isx_last_kernel_ms(double* single_ms, double* trace_ms, double* bin_ms);
  *                  rewritten by isx_compat_lines_kernel between the trace and the binning kernel); 0: round 1's fused
  *                  isx_trace_bin_full_kernel
  *   "bin_block", "bin_blocks_per_cu"  shape of round 2's binning kernel (0 workgroups per CU = what is resident)
+ *                  (round 5: "assist_block" 0 = the default again -- 768 threads, 256 for launches below 1e6 rays, 512 for the lobe /
+ *                  rough-specular kernels; "rays_per_lane" > 0 sizes every grid for that many rays per tracer lane, 0 = by launch
+ *                  size: 1 below 1.5e5 rays, 2 below 3e5, else 4 -- a small launch is bound by its longest ray, not by throughput)
  *   "ray_sub"      rays a wave takes off a launch's ray queue at a time (0 = default: 128)
  *   "overlap", "overlap_trace_streams"  cut a flux-map call into k chunks, binning of chunk i on a second stream while chunk
  *                  i+1 is traced (measured slower on MI355X, default 0)

@@ -23,7 +23,7 @@ def _same(a, b):
 def _reset(isx):
     for k, v in (("assist", 1), ("assist_block", 0), ("bin_slots", 1), ("bin_cols", 1), ("pipeline", 1), ("ray_sub", 0), ("grid_blocks", 0),
                  ("overlap", 0), ("overlap_trace_streams", 1), ("trace_block", 512), ("trace_blocks_per_cu", 0), ("disc_pipeline", 1),
-                 ("bin_mode", 1), ("pipeline_chunk", 1 << 26), ("surface_pipeline", 1)):
+                 ("bin_mode", 1), ("pipeline_chunk", 1 << 26), ("surface_pipeline", 1), ("rays_per_lane", 0)):
         isx.set_option(k, v)
 
 
@@ -215,3 +215,45 @@ def test_lobe_unit_vectors_are_tvector3_unit(isx):
             got = isx.mathprobe(op, x, y, z)
             want = comp * tot
             assert np.array_equal(got.view(np.uint64), want.view(np.uint64)), op
+
+
+@pytest.mark.parametrize("n", [1, 63, 64, 65, 1000, 50_000, 149_999, 150_000, 299_999, 300_000, 999_999, 1_000_000])
+def test_small_launch_shapes_change_nothing(isx, orc, n):
+    """small_shape(): below 1e6 rays a launch takes 256-thread workgroups and 1 / 2 / 4 rays per tracer lane, its binning grid is
+    sized by work units, results come back through the pinned staging buffer.  Every boundary of that policy, every entry point a
+    small call uses: == oracle (flux map + census, one detector, disc sweep)."""
+    _reset(isx)
+    c, co = isx.default_config(), orc.default_config()
+    gh, gst = isx.fluxmap(c, n, SEED, 7)
+    oh, ost = orc.fluxmap(co, n, SEED, 7)
+    assert np.array_equal(gh, oh)
+    _same(gst, ost)
+    if n <= 300_000:
+        det = isx.detector_table(c)[20 * c.n_phi + 3]
+        g1, s1 = isx.trace_rays_detector(c, det, c.det_diameter, n, SEED, 11)
+        o1, t1 = orc.trace_rays_detector(co, det, co.det_diameter, n, SEED, 11)
+        assert g1 == o1 and s1.counted_below_z == t1.counted_below_z and s1.wall_hits == t1.wall_hits
+        discs = np.array([[0.0, 0.0, -200.0, 0.0, 0.0, 1.0], [30.0, 0.0, -197.0, 0.15, 0.0, 0.99]])
+        c3, o3 = isx.default_config(), orc.default_config()
+        for q in (c3, o3):
+            q.r_out = 105.0; q.reflectance = 1.0; q.max_points = 2000; q.box_half = 250.0
+        gd, _ = isx.disc_sweep(c3, discs, 5.0, 0.1, n, SEED, 3)
+        od, _ = orc.disc_sweep(o3, discs, 5.0, 0.1, n, SEED, 3)
+        assert np.array_equal(gd, od)
+
+
+def test_rays_per_lane_and_block_options(isx, orc):
+    """The two knobs of the launch shape (`rays_per_lane`, `assist_block`) over a mid-size launch: same histogram, same census."""
+    _reset(isx)
+    n = 200_000
+    oh, ost = orc.fluxmap(orc.default_config(), n, SEED, 1)
+    try:
+        for rpl in (0, 1, 3, 16, 4096):
+            for blk in (0, 128, 768):
+                isx.set_option("rays_per_lane", rpl); isx.set_option("assist_block", blk)
+                gh, gst = isx.fluxmap(isx.default_config(), n, SEED, 1)
+                assert np.array_equal(gh, oh), (rpl, blk)
+                _same(gst, ost)
+    finally:
+        isx.set_option("rays_per_lane", 0)
+        _reset(isx)
