@@ -66,6 +66,10 @@ def run(name, fn, n_rays):
     print(name, json.dumps(out, indent=1), flush=True)
 for which in (sys.argv[1:] or ["flux"]):
     c = isx.default_config()
+    if which == "lobe":      # "nonLambertianFlux copy.C":31-70: one rejection try per step (a "bounce step" of the tables = one try)
+        c.surface_model = 1
+    if which == "rough":
+        c.lambertian = 0; c.roughness_rad = 0.5
     if which == "brdf":
         c.source_model = isx.SOURCE_BRDF; c.roughness_rad = 0.5; c.reflectance = 1.0; c.max_points = 10000; c.box_half = 200.0
     if which == "discs":   # BASELINE configs[3]: 362 disc positions share 1e7 rays (shell 100.1-105, reflectance 1)
