@@ -512,6 +512,9 @@ int enqueue(int sink, const isx_config* c, uint64_t n, uint64_t seed, uint64_t f
         if (cnt > kLaunchMax) return ISX_ERR_TOO_LARGE;   // (cannot happen: pipeline_chunk <= 2^26)
         Work w2 = wk;
         w2.first = first + off; w2.n = cnt; w2.sub = pick_sub(cnt);
+        // (work units of the binning kernel: quarter regions of 256 exit lines; sixteenths -- 64 lines, one batch -- for a small
+        //  launch, whose few thousand lines then spread over as many waves as there are batches)
+        w2.pad = cnt < 1000000ull ? 2u : 0u;
         int r = next_ctr(&w2.ctr); if (r) return r;
         DetGrid dt = d;              // the trace kernel keeps no histogram
         dt.nbins = 1; dt.n_theta = 0; dt.n_phi = 0;
@@ -531,7 +534,7 @@ int enqueue(int sink, const isx_config* c, uint64_t n, uint64_t seed, uint64_t f
           // work units of the binning kernel = quarter regions: at most cnt / 256 full ones + the open region every writing wave of
           // the trace kernel leaves behind (one per workgroup with an assist wave) -- a wave per unit, a workgroup per bblock / 64 units
           const uint64_t writers = assist ? (uint64_t)tgrid : (uint64_t)tgrid * (uint64_t)(pblock / 64);
-          const uint64_t units = cnt / (kRegion / 4) + writers;
+          const uint64_t units = cnt / (kRegion >> (2u + w2.pad)) + writers;
           const uint64_t bwant = (units + (uint64_t)(bblock / 64) - 1) / (uint64_t)(bblock / 64);
           const int bfull = S.cu_count * bres;
           const int gb = S.grid_blocks > 0 ? S.grid_blocks : (bwant < (uint64_t)bfull ? (int)bwant : bfull);
@@ -621,6 +624,7 @@ int enqueue(int sink, const isx_config* c, uint64_t n, uint64_t seed, uint64_t f
       if (cnt > kLaunchMax) return ISX_ERR_TOO_LARGE;     // (cannot happen: pipeline_chunk <= 2^26)
       Work w2 = wk;
       w2.first = first + off; w2.n = cnt; w2.sub = pick_sub(cnt);
+      w2.pad = cnt < 1000000ull ? 2u : 0u;   // (64-segment work units for a small launch, as for the flux maps)
       rc = next_ctr(&w2.ctr); if (rc) return rc;
       DetGrid dt = d;
       dt.rec_lines = S.d_rec[0]; dt.rec_counts = S.d_rec_counts[0];
@@ -632,7 +636,7 @@ int enqueue(int sink, const isx_config* c, uint64_t n, uint64_t seed, uint64_t f
       hipLaunchKernelGGL(rec_fn, dim3(tgrid), dim3(pblock), lds_trace, S.stream, g, dt, w2);
       HIPCHK(hipGetLastError());
       rc = span(1, nullptr); if (rc) return rc;
-      const uint64_t bwant = (cnt / (kRegion / 4) + (uint64_t)tgrid + (uint64_t)(bblock / 64) - 1) / (uint64_t)(bblock / 64);   // (quarter regions per workgroup, as above)
+      const uint64_t bwant = (cnt / (kRegion >> (2u + w2.pad)) + (uint64_t)tgrid + (uint64_t)(bblock / 64) - 1) / (uint64_t)(bblock / 64);   // (work units per workgroup, as above)
       const int bfull = S.cu_count * bres;
       const int gb = S.grid_blocks > 0 ? S.grid_blocks : (bwant < (uint64_t)bfull ? (int)bwant : bfull);
       hipLaunchKernelGGL(isx_bin_discs_kernel, dim3(gb), dim3(bblock), lds_bin, S.stream, dt, w2);

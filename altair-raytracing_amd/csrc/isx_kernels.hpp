@@ -111,7 +111,7 @@ struct Work {
   // of what was left at its last visit, W = waves of the launch, at least 64): the waves then finish close together.
   // ctr[Q_REGIONS]: exit-line regions handed out (SINK_REC), ctr[Q_BIN]: quarter regions taken by the binning kernel.
   uint32_t* ctr;
-  uint32_t sub, pad;
+  uint32_t sub, pad;          // pad (binning kernels): work units are (quarter regions) >> pad -- 0, or 2 for small launches (64-line units)
 };
 enum : int { Q_RAYS = 0 /* 64-bit: words 0-1 (it keeps counting after the last ray) */, Q_REGIONS = 2, Q_BIN = 3, Q_WORDS = 4 };
 // SINK_REC: a wave appends its exit lines to a private REGION of kRegion slots of the workspace and reserves the next one
@@ -3153,6 +3153,7 @@ isx_bin_discs_kernel(const DetGrid d_arg, const Work wk) {
   const int* __restrict__ perm = d_arg.disc_perm;
   const double disc_r = d_arg.disc_r, disc_h = d_arg.disc_h;
   const uint32_t n_regions = wk.ctr[Q_REGIONS];
+  const uint32_t ushift = 2u + wk.pad;            // a work unit = 1024 >> ushift exit lines of one region: a quarter region; a sixteenth for small launches (Work::pad)
   // phase 2: the exact test for every (pair, disc of its cluster), 64 at a time
   auto flush = [&](int n_pairs) {
 #pragma unroll 1
@@ -3179,11 +3180,11 @@ isx_bin_discs_kernel(const DetGrid d_arg, const Work wk) {
     uint32_t unit = 0;
     if (lane == 0) unit = atomicAdd(&wk.ctr[Q_BIN], 1u);
     unit = (uint32_t)__builtin_amdgcn_readfirstlane((int)unit);
-    const uint32_t region = unit >> 2;
+    const uint32_t region = unit >> ushift;
     if (region >= n_regions) break;
     const uint32_t r_lines = (uint32_t)__builtin_amdgcn_readfirstlane((int)d_arg.rec_counts[region]);
-    const uint32_t q_first = (unit & 3u) * (kRegion / 4u);
-    const uint32_t n_lines = r_lines < q_first + kRegion / 4u ? r_lines : q_first + kRegion / 4u;
+    const uint32_t q_first = (unit & ((1u << ushift) - 1u)) * (kRegion >> ushift);
+    const uint32_t n_lines = r_lines < q_first + (kRegion >> ushift) ? r_lines : q_first + (kRegion >> ushift);
     const double* rec = d_arg.rec_lines + 8ull * ((uint64_t)region * kRegion);
 #pragma unroll 1
     for (uint32_t b0 = q_first; b0 < n_lines; b0 += 64u) {
@@ -3271,6 +3272,7 @@ isx_bin_lines_kernel(const DetGrid d_arg, const Work wk) {
 
   const int bin_mode = d_arg.bin_mode;
   const uint32_t n_regions = wk.ctr[Q_REGIONS];   // (the trace kernel of this launch has completed)
+  const uint32_t ushift = 2u + wk.pad;            // a work unit = 1024 >> ushift exit lines of one region: a quarter region; a sixteenth for small launches (Work::pad)
 #pragma unroll 1
   for (;;) {
     // (wave-uniform: through readfirstlane so that the region pointer lives in scalar registers)
@@ -3278,11 +3280,11 @@ isx_bin_lines_kernel(const DetGrid d_arg, const Work wk) {
     uint32_t unit = 0;
     if (lane == 0) unit = atomicAdd(&wk.ctr[Q_BIN], 1u);
     unit = (uint32_t)__builtin_amdgcn_readfirstlane((int)unit);
-    const uint32_t region = unit >> 2;
+    const uint32_t region = unit >> ushift;
     if (region >= n_regions) break;
     const uint32_t r_lines = (uint32_t)__builtin_amdgcn_readfirstlane((int)d_arg.rec_counts[region]);
-    const uint32_t q_first = (unit & 3u) * (kRegion / 4u);
-    const uint32_t n_lines = r_lines < q_first + kRegion / 4u ? r_lines : q_first + kRegion / 4u;
+    const uint32_t q_first = (unit & ((1u << ushift) - 1u)) * (kRegion >> ushift);
+    const uint32_t n_lines = r_lines < q_first + (kRegion >> ushift) ? r_lines : q_first + (kRegion >> ushift);
     const double* rec = d_arg.rec_lines + 6ull * ((uint64_t)region * kRegion);
 #pragma unroll 1
     for (uint32_t b0 = q_first; b0 < n_lines; b0 += 64u) {
@@ -3398,16 +3400,17 @@ isx_bin_slots_kernel(const DetGrid d_arg, const Work wk) {
   const volatile LdsDetGrid& d = *(const volatile LdsDetGrid*)d_lds;
 
   const uint32_t n_regions = wk.ctr[Q_REGIONS];   // (the trace kernel of this launch has completed)
+  const uint32_t ushift = 2u + wk.pad;            // a work unit = 1024 >> ushift exit lines of one region: a quarter region; a sixteenth for small launches (Work::pad)
 #pragma unroll 1
   for (;;) {
     uint32_t unit = 0;
     if (lane == 0) unit = atomicAdd(&wk.ctr[Q_BIN], 1u);
     unit = (uint32_t)__builtin_amdgcn_readfirstlane((int)unit);
-    const uint32_t region = unit >> 2;
+    const uint32_t region = unit >> ushift;
     if (region >= n_regions) break;
     const uint32_t r_lines = (uint32_t)__builtin_amdgcn_readfirstlane((int)d_arg.rec_counts[region]);
-    const uint32_t q_first = (unit & 3u) * (kRegion / 4u);
-    const uint32_t n_lines = r_lines < q_first + kRegion / 4u ? r_lines : q_first + kRegion / 4u;
+    const uint32_t q_first = (unit & ((1u << ushift) - 1u)) * (kRegion >> ushift);
+    const uint32_t n_lines = r_lines < q_first + (kRegion >> ushift) ? r_lines : q_first + (kRegion >> ushift);
     const double* lines = d_arg.rec_lines + 6ull * ((uint64_t)region * kRegion + q_first);   // the unit's lines
     ISX_BD_MARK(sq, 5);
     struct { int n_phi; double half_w2, portz; const double* table; } dfast;
@@ -3550,17 +3553,18 @@ isx_bin_cols_kernel(const DetGrid d_arg, const Work wk) {
   const volatile LdsDetGrid& d = *(const volatile LdsDetGrid*)d_lds;
 
   const uint32_t n_regions = wk.ctr[Q_REGIONS];   // (the trace kernel of this launch has completed)
+  const uint32_t ushift = 2u + wk.pad;            // a work unit = 1024 >> ushift exit lines of one region: a quarter region; a sixteenth for small launches (Work::pad)
   ISX_BD_INIT(sq);
 #pragma unroll 1
   for (;;) {
     uint32_t unit = 0;
     if (lane == 0) unit = atomicAdd(&wk.ctr[Q_BIN], 1u);
     unit = (uint32_t)__builtin_amdgcn_readfirstlane((int)unit);
-    const uint32_t region = unit >> 2;
+    const uint32_t region = unit >> ushift;
     if (region >= n_regions) break;
     const uint32_t r_lines = (uint32_t)__builtin_amdgcn_readfirstlane((int)d_arg.rec_counts[region]);
-    const uint32_t q_first = (unit & 3u) * (kRegion / 4u);
-    const uint32_t n_lines = r_lines < q_first + kRegion / 4u ? r_lines : q_first + kRegion / 4u;
+    const uint32_t q_first = (unit & ((1u << ushift) - 1u)) * (kRegion >> ushift);
+    const uint32_t n_lines = r_lines < q_first + (kRegion >> ushift) ? r_lines : q_first + (kRegion >> ushift);
     const double* lines = d_arg.rec_lines + 6ull * ((uint64_t)region * kRegion + q_first);   // the unit's lines
     struct { int n_phi, n_theta; double half_w2, portz, R; const double* table; } dcol;
     dcol.n_phi = d.n_phi; dcol.n_theta = d.n_theta; dcol.half_w2 = d.half_w2; dcol.portz = d_arg.portz; dcol.R = d_arg.R; dcol.table = d.table;
