@@ -263,6 +263,13 @@ def extra_legs(isx, np, seed, cus, pj):
                       "wall_hits_per_ray": st.wall_hits / ns, "bin_increments_per_ray": st.bin_increments / ns,
                       "issue_blocks": blocks(sec, kk, ns) if sec else None}
     legs["surfaces"] = surf
+    # ---- the optional chord mode of the headline configuration (ISX_TRACE_CHORD: the integrating-sphere identity samples the next wall
+    # point directly; same distribution, the oracle has the twin; the headline above keeps the reference-shaped explicit bounce)
+    q = isx.default_config()
+    q.trace_mode = 1
+    w, km, kk, st = timed(lambda: isx.fluxmap(q, 50_000_000, seed)[1], 3)
+    legs["chord_mode"] = {"rays": 50_000_000, "value": 50_000_000 / w / 1e3, "unit": "Mrays/s", "ms_per_call": w, "kernel_ms": km,
+                          "trace_ms": kk[1], "bin_ms": kk[2]}
     return legs
 
 
@@ -590,6 +597,7 @@ def main():
             "perpos_8p1e8": (legs or {}).get("perpos_8p1e8"),
             "size_sweep": (legs or {}).get("size_sweep"),
             "surfaces": (legs or {}).get("surfaces"),
+            "chord_mode": (legs or {}).get("chord_mode"),
             "extra_legs_error": (legs or {}).get("error"),
             # the HBM figure the north star asks for: algorithmic bytes (exit lines written once and read once, 48 B each, plus
             # one 129.6 KB histogram) / kernel time against 8 TB/s
