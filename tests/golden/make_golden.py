@@ -175,7 +175,10 @@ ds2 = np.array(rows2)
 full = [t for t in sorted(set(ds2[:, 0])) if (ds2[:, 0] == t).sum() == 360]
 fx["disc_sweep2"] = {"file": "detector_sweep2.txt", "theta_deg": [float(t) for t in full], "n_phi": 360, "rays_per_position": 1000,
                      "phi_mean_fraction": [float(ds2[ds2[:, 0] == t, 2].mean()) for t in full],
-                     "rows_total": int(len(ds2)), "rows_dropped": int(len(ds2) - 360 * len(full))}
+                     "rows_total": int(len(ds2)), "rows_dropped": int(len(ds2) - 360 * len(full)),
+                     # every position: hits of its 1000 rays, [theta][phi = 0..359 deg] (the phi structure pins addDetectorDisk's rotation quirk)
+                     "hits": [[int(round(x * 1000)) for x in ds2[ds2[:, 0] == t][np.argsort(ds2[ds2[:, 0] == t, 1]), 2]] for t in full]}
+fx["disc_sweep"]["hits"] = [[int(round(x * 1000)) for x in ds[ds[:, 0] == t][np.argsort(ds[ds[:, 0] == t, 1]), 2]] for t in thetas]
 
 # (e) small and cut-short files whose revision CAN be identified from the file name / header: rows present as integer hit counts
 small = []
