@@ -315,6 +315,31 @@ bool abort_comm(const char* why) {
   }
   return false;
 }
+// The wait for the collective is a POLL, not a blocking synchronisation: ncclAllReduce has no time-out, and a peer that died or
+// aborted its communicator (abort_comm) leaves this rank's all-reduce kernel waiting for data that will never come.  While the
+// stream is busy the communicator's asynchronous error state is checked (RCCL reports a lost peer there when its transport
+// notices), and a launch-wide time-out bounds what no transport notices (ISX_COLLECTIVE_TIMEOUT seconds, default 600: the ranks of a
+// launch do equal work, they reach the collective within milliseconds of each other).  Either way this rank aborts its own
+// communicator -- the only way to take a stuck collective kernel off the device -- and reports the failure.
+int collective_timeout_seconds() {
+  if (const char* s = std::getenv("ISX_COLLECTIVE_TIMEOUT")) { const int v = std::atoi(s); if (v >= 1 && v <= 86400) return v; }
+  return 600;
+}
+bool wait_collective() {
+  const auto t0 = std::chrono::steady_clock::now();
+  const auto limit = std::chrono::seconds(collective_timeout_seconds());
+  for (unsigned polls = 0;; ++polls) {
+    const hipError_t q = hipStreamQuery(R.stream);
+    if (q == hipSuccess) return true;
+    if (q != hipErrorNotReady) { std::cerr << "Error: isx_comm: the collective's stream failed: " << hipGetErrorString(q) << std::endl; return false; }
+    ncclResult_t ar = ncclSuccess;
+    if (ncclCommGetAsyncError(R.comm, &ar) != ncclSuccess || (ar != ncclSuccess && ar != ncclInProgress))
+      return abort_comm("a peer of the collective failed (asynchronous RCCL error)");
+    if (std::chrono::steady_clock::now() - t0 > limit) return abort_comm("the collective did not complete within ISX_COLLECTIVE_TIMEOUT");
+    if (polls < 2000) std::this_thread::yield();                       // (the 130 KB all-reduce takes tens of microseconds)
+    else std::this_thread::sleep_for(std::chrono::microseconds(200));
+  }
+}
 struct RcclTransport : Transport {
   bool reserve(size_t total) {
     if (total > R.cap) {
@@ -331,8 +356,7 @@ struct RcclTransport : Transport {
       return abort_comm("the copy of this rank's contribution failed");
     ISX_NCCL_OK(ncclAllReduce(R.d_buf, R.d_buf, n, ncclUint64, ncclSum, R.comm, R.stream));
     ISX_HIP_OK(hipMemcpyAsync(buf, R.d_buf, n * sizeof(unsigned long long), hipMemcpyDeviceToHost, R.stream));
-    ISX_HIP_OK(hipStreamSynchronize(R.stream));
-    return true;
+    return wait_collective();
   }
   // the first n_dev words are already in R.d_buf (the histogram, written there by the kernels: no D2H -> H2D round trip of the
   // 130 KB before the collective); the tail comes from the host.  The whole reduced buffer goes back to `buf`.
@@ -343,8 +367,7 @@ struct RcclTransport : Transport {
       return abort_comm("the copy of this rank's census failed");
     ISX_NCCL_OK(ncclAllReduce(R.d_buf, R.d_buf, n, ncclUint64, ncclSum, R.comm, R.stream));
     ISX_HIP_OK(hipMemcpyAsync(buf, R.d_buf, n * sizeof(unsigned long long), hipMemcpyDeviceToHost, R.stream));
-    ISX_HIP_OK(hipStreamSynchronize(R.stream));
-    return true;
+    return wait_collective();
   }
 } g_rccl;
 
