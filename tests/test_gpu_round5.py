@@ -257,3 +257,23 @@ def test_rays_per_lane_and_block_options(isx, orc):
     finally:
         isx.set_option("rays_per_lane", 0)
         _reset(isx)
+
+
+def test_surface_pipeline_under_every_host_side_schedule(isx, orc):
+    """The host-side switches around the new kernels: the overlapped pipeline (trace of chunk k+1 on one stream, compat rewrite +
+    binning of chunk k on another), kernels without an assist wave, the fused kernel, brute-force binning -- same histogram."""
+    _reset(isx)
+    n = 120_000
+    want = {k: orc.fluxmap(_surface(orc, k), n, SEED, 2) for k in ("lobe", "compat", "rough_0p5")}
+    try:
+        for opts in ({"overlap": 3}, {"overlap": 2, "overlap_trace_streams": 2}, {"assist": 0}, {"pipeline": 0}, {"bin_mode": 0},
+                     {"bin_cols": 0}, {"bin_slots": 0}, {"pipeline_chunk": 20_000, "overlap": 2}):
+            _reset(isx)
+            for key, val in opts.items():
+                isx.set_option(key, val)
+            for k, (oh, ost) in want.items():
+                gh, gst = isx.fluxmap(_surface(isx, k), n, SEED, 2)
+                assert np.array_equal(gh, oh), (opts, k)
+                _same(gst, ost)
+    finally:
+        _reset(isx)
