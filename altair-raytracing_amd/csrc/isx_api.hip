@@ -647,9 +647,13 @@ int enqueue(int sink, const isx_config* c, uint64_t n, uint64_t seed, uint64_t f
   }
   // ---- the per-position sinks (one launch for all positions: the reference's 12 524 s map, the macro's own disc loop) with an
   // assist wave per workgroup as well: the one exact test per exiting ray is per-lane work the assist wave does on the spot
-  if ((sink == SINK_PERPOS || sink == SINK_DISCPOS) && lean_explicit && S.pipeline && S.assist) {
-    const KernelFn afn = sink == SINK_PERPOS ? isx_trace_assist_perpos_kernel : isx_trace_assist_discpos_kernel;
-    const Shape shp = small_shape(n < kLaunchMax ? n : kLaunchMax, S.assist_block);
+  // (round 5: the lobe / rough-specular borders as well -- SINK_PERPOS only, last-segment hit line: the assist wave's exact test takes
+  //  the line as it is)
+  const bool pp_surface = sink == SINK_PERPOS && (p_lobe || p_rough) && !compat;
+  if ((sink == SINK_PERPOS || sink == SINK_DISCPOS) && (lean_explicit || pp_surface) && S.pipeline && S.assist) {
+    const KernelFn afn = sink == SINK_DISCPOS ? isx_trace_assist_discpos_kernel :
+                         (pp_surface ? (p_lobe ? isx_trace_assist_perpos_lobe_kernel : isx_trace_assist_perpos_rough_kernel) : isx_trace_assist_perpos_kernel);
+    const Shape shp = small_shape(n < kLaunchMax ? n : kLaunchMax, (!S.assist_block_set && pp_surface) ? 512 : S.assist_block);
     const int pblock = shp.block;
     const size_t lds_trace = 16 + 64 + sizeof(Geom) + sizeof(DetGrid) + 16 + sizeof(AssistQueues) + (size_t)(kResumeCap + kPendCap) * 64;
     if (S.attr_lds[(const void*)afn] != lds_trace) {

@@ -3078,6 +3078,12 @@ extern "C" __global__ void __launch_bounds__(ISX_ASSIST_BLOCK) __attribute__((am
 isx_trace_assist_lobe_kernel(const Geom g, const DetGrid d, const Work wk) { assist_body<0, false, false, 0, SURF_LOBE>(g, d, wk); }
 extern "C" __global__ void __launch_bounds__(ISX_ASSIST_BLOCK) __attribute__((amdgpu_waves_per_eu(ISX_ROUGH_WAVES, ISX_ROUGH_WAVES)))
 isx_trace_assist_rough_kernel(const Geom g, const DetGrid d, const Work wk) { assist_body<0, false, false, 0, SURF_ROUGH>(g, d, wk); }
+// ... and as per-position sinks: the macros that own these borders sweep one detector position at a time with fresh rays
+// ("nonLambertianFlux copy.C":306-345: 45 x 20 positions x 1e5 rays), i.e. isx_fluxmap_per_position / isx_trace_rays_detector
+extern "C" __global__ void __launch_bounds__(ISX_ASSIST_BLOCK) __attribute__((amdgpu_waves_per_eu(ISX_LOBE_WAVES, ISX_LOBE_WAVES)))
+isx_trace_assist_perpos_lobe_kernel(const Geom g, const DetGrid d, const Work wk) { assist_body<0, false, false, 1, SURF_LOBE>(g, d, wk); }
+extern "C" __global__ void __launch_bounds__(ISX_ASSIST_BLOCK) __attribute__((amdgpu_waves_per_eu(ISX_ROUGH_WAVES, ISX_ROUGH_WAVES)))
+isx_trace_assist_perpos_rough_kernel(const Geom g, const DetGrid d, const Work wk) { assist_body<0, false, false, 1, SURF_ROUGH>(g, d, wk); }
 
 // ISX_HITLINE_ORIGIN_COMPAT on the pipeline (round 5): what fluxAtObserverFast.C:1181-1201,1285-1288 effectively tested is the line
 // from the origin along lastPoint/|lastPoint| (hit_line_compat).  The trace kernels write last point + final direction as always;

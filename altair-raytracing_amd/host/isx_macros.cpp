@@ -927,6 +927,57 @@ void sweepDetector() {
 }  // namespace nonLambertianFlux
 
 // ---------------------------------------------------------------------------------------------
+// flux_at_observer/"nonLambertianFlux copy.C": the same sweep with the NonLambertianSurface border (cos^2 lobe within 60 deg of
+// the normal, :31-70,188-221) instead of ROBAST's own conditions -- ISX_SURFACE_LOBE; no BRDF re-scatter in this file
+namespace nonLambertianFluxCopy {
+
+void setupOpticsManager(OpticsManager* m) {
+  fluxAtObserver::setupOpticsManager(m);     // limit 10000, box 200, shell 100.1-101, port 170, AMirror's default reflectance (:213-255)
+  m->cfg.lambertian = 0;                     // condition->EnableLambertian(false) (:238); roughness 0.5 is inert: Reflection() is overridden
+  m->cfg.surface_model = ISX_SURFACE_LOBE;   // NonLambertianSurface::Reflection (:188-221)
+}
+
+int traceRays(OpticsManager* m, int n, double exitPortZ, Detector& det, bool) {
+  const double src[3] = {-60 * cm, 0 * cm, -80 * cm}, dir[3] = {5, 0, 0};  // ARay(0, 400 nm, -60, 0, -80, 0, 5, 0, 0) (:268-269)
+  return fluxAtObserver::trace_one_detector(m, n, exitPortZ, det, src, dir, ISX_SOURCE_PENCIL);
+}
+
+void sweepDetector() {
+  OpticsManager manager;
+  setupOpticsManager(&manager);
+  const long n = pick_n(100000);
+  const double exitPortZ = -100 * cm;
+  const int nThetaBins = 45, nPhiBins = 20;
+  Detector detector;   // 10 cm x 10 cm (:78)
+  if (!ready_everywhere()) return;
+  isx_config c = manager.cfg;
+  c.src[0] = -60; c.src[1] = 0; c.src[2] = -80; c.dir[0] = 5; c.dir[1] = 0; c.dir[2] = 0;
+  c.n_theta = nThetaBins; c.n_phi = nPhiBins; c.det_diameter = detector.width; c.det_distance = 100 * cm;
+  c.exit_port_z = exitPortZ; c.source_model = ISX_SOURCE_PENCIL;
+  std::vector<uint64_t> hits((size_t)nThetaBins * nPhiBins);
+  isx_stats st;
+  const uint64_t total = (uint64_t)n * hits.size();
+  // the macro's loop (:325-345) -- 900 positions x n fresh rays, one detector each -- in one launch
+  const int rc = fluxmap_per_position_all(&c, (uint64_t)n, 1, hits.size(), options().seed, take_rays(total), hits.data(), &st);
+  if (rc != ISX_OK) {
+    err() << "Error: isx_fluxmap_per_position: " << isx_strerror(rc) << std::endl;
+    return;
+  }
+  const std::string path = outputPath("fluxmap_data.csv");  // (:371; the reference overwrites, this driver never does)
+  std::ofstream csvFile(path);
+  if (!csvFile.is_open()) {
+    err() << "Error: Could not open file " << path << " for writing." << std::endl;
+    return;
+  }
+  csvFile << "theta,phi,fraction\n";
+  csvFile << fluxmap_rows(hits.data(), n, nThetaBins, nPhiBins);
+  csvFile.close();
+  say("\nFlux map data saved to '" + path + "'");
+}
+
+}  // namespace nonLambertianFluxCopy
+
+// ---------------------------------------------------------------------------------------------
 // root-level macros
 // ---------------------------------------------------------------------------------------------
 namespace rootMacros {

@@ -8,6 +8,7 @@
 //   isxhost::fluxAtObserverOptimize  flux_at_observer/fluxAtObserverOptimize.C
 //   isxhost::fluxAtObserverFast      flux_at_observer/fluxAtObserverFast.C
 //   isxhost::nonLambertianFlux       flux_at_observer/nonLambertianFlux.C
+//   isxhost::nonLambertianFluxCopy   flux_at_observer/"nonLambertianFlux copy.C"
 //   isxhost::rootMacros              makeIntegratingSphereNRays.C, integratingSphereDetectorSweep.C,
 //                                    distributionSphereDetectorSweep.C
 //
@@ -148,6 +149,13 @@ void setupOpticsManager(OpticsManager* manager);                                
 int traceRays(OpticsManager* manager, int n, double exitPortZ, Detector& detector, bool drawRays = false);        // :235-304
 void sweepDetector();                                                                                              // :307-387
 }  // namespace nonLambertianFlux
+
+// flux_at_observer/"nonLambertianFlux copy.C" (the de-facto CustomMirror: NonLambertianSurface, cos^2 lobe by rejection, :31-70,188-221)
+namespace nonLambertianFluxCopy {
+void setupOpticsManager(OpticsManager* manager);                                  // :213-255
+int traceRays(OpticsManager* manager, int n, double exitPortZ, Detector& detector, bool drawRays = false);  // :263-303
+void sweepDetector();                                                             // :306-386
+}  // namespace nonLambertianFluxCopy
 
 namespace rootMacros {
 void makeIntegratingSphereNRays();                                         // makeIntegratingSphereNRays.C:22-100

@@ -262,6 +262,14 @@ def extra_legs(isx, np, seed, cus, pj):
         surf[name] = {"rays": ns, "value": ns / w / 1e3, "unit": "Mrays/s", "ms_per_call": w, "kernel_ms": km, "trace_ms": kk[1], "bin_ms": kk[2],
                       "wall_hits_per_ray": st.wall_hits / ns, "bin_increments_per_ray": st.bin_increments / ns,
                       "issue_blocks": blocks(sec, kk, ns) if sec else None}
+    # "nonLambertianFlux copy.C":306-345 as the macro runs it: 45 x 20 detector positions x 1e5 fresh rays with the lobe border (rho 1,
+    # limit 10 000, box 200, src z -80, 10 cm detector) -- one launch of the per-position lobe kernel
+    q = isx.default_config()
+    q.surface_model = 1; q.lambertian = 0; q.roughness_rad = 0.5; q.reflectance = 1.0; q.max_points = 10000; q.box_half = 200.0
+    q.src[2] = -80.0; q.n_theta, q.n_phi, q.det_diameter = 45, 20, 10.0
+    w, km, kk, st = timed(lambda: isx.fluxmap_per_position(q, 100_000, seed)[1], 1)
+    surf["nlcopy_macro_sweep"] = {"workload": "nonLambertianFluxCopy::sweepDetector: 900 positions x 1e5 rays, lobe border, rho 1", "rays": 90_000_000,
+                                  "value": 90_000_000 / w / 1e3, "unit": "Mrays/s", "ms_per_call": w, "kernel_ms": km, "wall_hits_per_ray": st.wall_hits / 9e7}
     legs["surfaces"] = surf
     # ---- the optional chord mode of the headline configuration (ISX_TRACE_CHORD: the integrating-sphere identity samples the next wall
     # point directly; same distribution, the oracle has the twin; the headline above keeps the reference-shaped explicit bounce)

@@ -277,3 +277,31 @@ def test_surface_pipeline_under_every_host_side_schedule(isx, orc):
                 _same(gst, ost)
     finally:
         _reset(isx)
+
+
+@pytest.mark.parametrize("kind", ["lobe", "lobe_nlcopy", "rough_0p5"])
+def test_per_position_sinks_with_the_other_borders(isx, orc, kind):
+    """The macros that own these borders sweep one detector position at a time with fresh rays ("nonLambertianFlux copy.C":306-345):
+    isx_fluxmap_per_position (both folds) and isx_trace_rays_detector on isx_trace_assist_perpos_{lobe,rough}_kernel == oracle,
+    and == round 1's kernel (surface_pipeline = 0)."""
+    _reset(isx)
+    c, co = _surface(isx, kind), _surface(orc, kind)
+    for q in (c, co):
+        q.n_theta, q.n_phi, q.det_diameter = 45, 20, 10.0
+    for fold in (1, 2):
+        gh, gst = isx.fluxmap_per_position(c, 600, SEED, fold)
+        oh, ost = orc.fluxmap_per_position(co, 600, SEED, fold)
+        assert np.array_equal(gh, oh), (kind, fold)
+        _same(gst, ost)
+    det = isx.detector_table(c)[5 * c.n_phi + 7]
+    g1, s1 = isx.trace_rays_detector(c, det, c.det_diameter, 200_000, SEED, 4)
+    o1, t1 = orc.trace_rays_detector(co, det, co.det_diameter, 200_000, SEED, 4)
+    assert g1 == o1 and g1 > 0 and s1.wall_hits == t1.wall_hits and s1.counted_below_z == t1.counted_below_z
+    try:
+        isx.set_option("surface_pipeline", 0)
+        bh, bst = isx.fluxmap_per_position(c, 600, SEED, 1)
+        oh, ost = orc.fluxmap_per_position(co, 600, SEED, 1)
+        assert np.array_equal(bh, oh)
+        _same(bst, ost)
+    finally:
+        _reset(isx)

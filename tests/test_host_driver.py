@@ -341,6 +341,17 @@ def test_small_macros(cli, isx, tmp_path):
     _run(cli, tmp_path, "nonLambertianFlux::sweepDetector", rays=300, seed=3)
     meta, header, rows = parse_fluxmap(tmp_path / "fluxmap_data.csv")
     assert header == "theta,phi,fraction" and rows.shape == (900, 3) and meta == {}
+    # "nonLambertianFlux copy.C": the same sweep with the cos^2-lobe border; the file is the one isx_fluxmap_per_position gives
+    # (never overwritten: the second fluxmap_data.csv of this folder is fluxmap_data_1.csv, as the reference's own second file was)
+    _run(cli, tmp_path, "nonLambertianFluxCopy::sweepDetector", rays=400, seed=3)
+    meta, header, rows2 = parse_fluxmap(tmp_path / "fluxmap_data_1.csv")
+    assert header == "theta,phi,fraction" and rows2.shape == (900, 3) and meta == {}
+    c = isx.default_config()
+    c.max_points = 10000; c.box_half = 200.0; c.reflectance = 1.0; c.lambertian = 0; c.roughness_rad = 0.5; c.surface_model = 1
+    c.src[2] = -80.0; c.n_theta, c.n_phi, c.det_diameter = 45, 20, 10.0
+    h, st = isx.fluxmap_per_position(c, 400, 3)
+    assert np.allclose(rows2[:, 2], np.round(h.reshape(-1) / 400.0, 6), atol=1e-9) and h.sum() > 0
+    assert not np.array_equal(rows2[:, 2], rows[:, 2])
     _run(cli, tmp_path, "integratingSphereDetectorSweep", rays=2000, seed=3)
     txt = (tmp_path / "detector_sweep3.txt").read_text().splitlines()
     assert txt[0] == "Theta(deg)\tPhi(deg)\tHitFraction" and len(txt) == 1 + 181 * 2
