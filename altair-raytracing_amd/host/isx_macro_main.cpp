@@ -43,7 +43,8 @@ int main(int argc, char** argv) {
     std::cerr << "usage: isx_macro <file>::<function> [key=value ...]\n"
                  "  fluxAtObserver::sweepDetector | fluxAtObserverOptimize::sweepDetector | fluxAtObserverOptimize::sweepSeries |\n"
                  "  fluxAtObserverFast::sweepDetectorTwofold | fluxAtObserverFast::sweepDetectorTraceOnce | fluxAtObserverFast::sweepSeries |\n"
-                 "  nonLambertianFlux::sweepDetector | nonLambertianFluxCopy::sweepDetector | makeIntegratingSphereNRays |\n"
+                 "  nonLambertianFlux::sweepDetector | nonLambertianFluxCopy::sweepDetector | nonLambertianFluxCopy::visualizeDetectorText [theta= phi=] |\n"
+                 "  makeIntegratingSphereNRays |\n"
                  "  integratingSphereDetectorSweep |\n"
                  "  distributionSphereDetectorSweep | --selftest-writer <file> | --unique <path> | --shard <n> | --analyze <csv>... | --analyze <folder> [average]\n";
     return 2;
@@ -87,6 +88,7 @@ int main(int argc, char** argv) {
   else if (entry == "fluxAtObserverFast::sweepSeries") fluxAtObserverFast::sweepSeries();
   else if (entry == "nonLambertianFlux::sweepDetector") nonLambertianFlux::sweepDetector();
   else if (entry == "nonLambertianFluxCopy::sweepDetector") nonLambertianFluxCopy::sweepDetector();
+  else if (entry == "nonLambertianFluxCopy::visualizeDetectorText") nonLambertianFluxCopy::visualizeDetectorText(num(kv, "theta", 45.0), num(kv, "phi", 0.0));
   else if (entry == "makeIntegratingSphereNRays") rootMacros::makeIntegratingSphereNRays();
   else if (entry == "integratingSphereDetectorSweep") rootMacros::integratingSphereDetectorSweep();
   else if (entry == "distributionSphereDetectorSweep") rootMacros::distributionSphereDetectorSweep();

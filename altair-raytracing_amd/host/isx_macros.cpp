@@ -975,6 +975,41 @@ void sweepDetector() {
   say("\nFlux map data saved to '" + path + "'");
 }
 
+// :604-667: the text report of one detector position -- position, normal, rays detected -- and the macro's ASCII sketch
+void visualizeDetectorText(double theta, double phi) {
+  OpticsManager manager;
+  setupOpticsManager(&manager);
+  Detector detector(20 * cm, 20 * cm);
+  detector.setPosition(theta, phi, 100 * cm);
+  const int n = (int)pick_n(10000);
+  const double exitPortZ = -100 * cm;
+  if (!ready_everywhere()) return;
+  const int hitCount = traceRays(&manager, n, exitPortZ, detector, false);
+  std::ostream& o = std::cout;
+  o << "\n===================================" << std::endl;
+  o << "DETECTOR INFORMATION" << std::endl;
+  o << "===================================" << std::endl;
+  o << "Angular position: theta = " << theta << "°, phi = " << phi << "°" << std::endl;
+  o << "Position (x,y,z): (" << detector.x / cm << ", " << detector.y / cm << ", " << detector.z / cm << ") cm" << std::endl;
+  o << "Normal vector: (" << detector.nx << ", " << detector.ny << ", " << detector.nz << ")" << std::endl;
+  o << "Rays traced: " << n << std::endl;
+  o << "Rays detected: " << hitCount << " (" << 100.0 * hitCount / n << "%)" << std::endl;
+  o << "===================================" << std::endl;
+  o << "\nTop View (X-Z plane, Y=0):" << std::endl;
+  o << "    ^Z" << std::endl << "    |" << std::endl << "    |   ,-------," << std::endl << "    |  /         \\" << std::endl
+    << "    | |     *     | Mirror" << std::endl << "    |  \\         /" << std::endl << "    |   '-------'" << std::endl << "    |" << std::endl;
+  const int detX = (int)(detector.x / cm / 20) + 10;
+  const int detZ = -(int)((detector.z + 100 * cm) / cm / 10) + 15;
+  for (int z = 15; z >= 0; z--) {
+    o << "    |";
+    for (int x = 0; x < 20; x++) o << ((z == detZ && x == detX) ? "D" : " ");
+    if (z == 15) o << "  Exit Port at Z=-100cm";
+    if (z == detZ) o << "  <- Detector";
+    o << std::endl;
+  }
+  o << "    +---------------------> X" << std::endl;
+}
+
 }  // namespace nonLambertianFluxCopy
 
 // ---------------------------------------------------------------------------------------------

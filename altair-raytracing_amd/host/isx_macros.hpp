@@ -155,6 +155,7 @@ namespace nonLambertianFluxCopy {
 void setupOpticsManager(OpticsManager* manager);                                  // :213-255
 int traceRays(OpticsManager* manager, int n, double exitPortZ, Detector& detector, bool drawRays = false);  // :263-303
 void sweepDetector();                                                             // :306-386
+void visualizeDetectorText(double theta = 45.0, double phi = 0.0);                // :604-667 (the text report: one 20 cm detector, 10 000 rays)
 }  // namespace nonLambertianFluxCopy
 
 namespace rootMacros {

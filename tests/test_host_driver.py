@@ -352,6 +352,19 @@ def test_small_macros(cli, isx, tmp_path):
     h, st = isx.fluxmap_per_position(c, 400, 3)
     assert np.allclose(rows2[:, 2], np.round(h.reshape(-1) / 400.0, 6), atol=1e-9) and h.sum() > 0
     assert not np.array_equal(rows2[:, 2], rows[:, 2])
+    # ... and its text report of one detector position (:604-667): 20 cm detector, the counts of isx_trace_rays_detector
+    out = _run(cli, tmp_path, "nonLambertianFluxCopy::visualizeDetectorText", "theta=10", "phi=30", rays=20000, seed=3)
+    m = re.search(r"Rays traced: (\d+)\s+Rays detected: (\d+) \(([0-9.e+-]+)%\)", out)
+    assert m and int(m.group(1)) == 20000 and "Angular position: theta = 10°, phi = 30°" in out and "Exit Port at Z=-100cm" in out
+    assert "<- Detector" not in out    # (as in the reference: its row index -(z+100)/10 + 15 = 24 lies outside the 16 rows it draws)
+    det = np.zeros(6)
+    th, ph = np.deg2rad(10.0), np.deg2rad(30.0)
+    det[:3] = [100 * np.sin(th) * np.cos(ph), 100 * np.sin(th) * np.sin(ph), -100 - 100 * np.cos(th)]
+    dx, dy, dz = det[0], det[1], det[2] + 100
+    det[3:] = np.array([-dy, dx, dz]) / np.sqrt(dx * dx + dy * dy + dz * dz)
+    c.n_theta, c.n_phi = 180, 90
+    hits1, _ = isx.trace_rays_detector(c, det, 20.0, 20000, 3)
+    assert int(m.group(2)) == hits1 and hits1 > 0
     _run(cli, tmp_path, "integratingSphereDetectorSweep", rays=2000, seed=3)
     txt = (tmp_path / "detector_sweep3.txt").read_text().splitlines()
     assert txt[0] == "Theta(deg)\tPhi(deg)\tHitFraction" and len(txt) == 1 + 181 * 2
