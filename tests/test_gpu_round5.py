@@ -305,3 +305,23 @@ def test_per_position_sinks_with_the_other_borders(isx, orc, kind):
         _same(bst, ost)
     finally:
         _reset(isx)
+
+
+@pytest.mark.parametrize("kind,n", [("lobe", 20_000_000), ("compat", 30_000_000), ("rough_0p5", 20_000_000)])
+def test_new_pipelines_culled_equals_brute_force_at_scale(isx, kind, n):
+    """Tens of millions of rays through the new trace kernels + the column-slot binning kernel against the brute-force reference-order
+    test of all 16 200 positions (bin_mode 0: round 1's fused kernel, every detector tested): the lobe's exit lines are more
+    collimated than the Lambertian border's (254 bins per ray against 114), the origin-compat lines all pass through the origin --
+    regimes of the cull that the headline's lines do not reach.  ~5e9 hit decisions each."""
+    _reset(isx)
+    c = _surface(isx, kind)
+    try:
+        isx.set_option("bin_mode", 0)
+        brute, sb = isx.fluxmap(c, n, 13579)
+    finally:
+        _reset(isx)
+    culled, sc = isx.fluxmap(c, n, 13579)
+    assert isx.last_kernel_ms()[2] > 0
+    assert np.array_equal(brute, culled)
+    _same(sb, sc)
+    assert int(culled.sum()) == sc.bin_increments > 0
