@@ -325,3 +325,25 @@ def test_new_pipelines_culled_equals_brute_force_at_scale(isx, kind, n):
     assert np.array_equal(brute, culled)
     _same(sb, sc)
     assert int(culled.sum()) == sc.bin_increments > 0
+
+
+@pytest.mark.parametrize("kind", ["lobe", "rough_0p5", "compat"])
+def test_new_pipelines_are_partition_invariant(isx, kind):
+    """A ray's history -- every try of the lobe sampler, every roughness draw -- is a function of (seed, ray index) alone: 2e7 rays
+    in one call == the sum of five calls over the same index range cut at odd places, histogram and census (what the ray-sharded
+    multi-GPU runs rest on)."""
+    _reset(isx)
+    c = _surface(isx, kind)
+    n, first = 20_000_000, 123_456_789_000
+    whole, sw = isx.fluxmap(c, n, SEED, first)
+    cuts = [0, 1, 3_333_333, 3_333_397, 11_000_000, n]
+    acc = np.zeros_like(whole)
+    tot = {k: 0 for k in CENSUS}
+    for a, b in zip(cuts[:-1], cuts[1:]):
+        h, st = isx.fluxmap(c, b - a, SEED, first + a)
+        acc += h
+        for k in CENSUS:
+            tot[k] += getattr(st, k)
+    assert np.array_equal(whole, acc)
+    for k in CENSUS:
+        assert tot[k] == getattr(sw, k), k
