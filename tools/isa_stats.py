@@ -61,6 +61,31 @@ def census(body):
     }
 
 
+# kernels that may keep scratch OUTSIDE their tracer waves' bounce steps only (the assist wave carries Ray::prev through the generic search)
+SCRATCH_OUTSIDE_STEPS = ("isx_trace_assist_disc_kernel", "isx_trace_assist_discpos_kernel")
+
+
+def scratch_in_steps(body):
+    """scratch instructions between the first and the last Philox block of the TRACER loop (the last four runs of >= 15
+    v_mad_u64_u32: the bounce steps of a trip; the run before them belongs to the assist wave)"""
+    lines = body.splitlines()
+    mads = [i for i, l in enumerate(lines) if "v_mad_u64_u32" in l]
+    blocks, cur = [], mads[:1]
+    for m in mads[1:]:
+        if m - cur[-1] < 12:
+            cur.append(m)
+        else:
+            if len(cur) >= 15:
+                blocks.append((cur[0], cur[-1]))
+            cur = [m]
+    if len(cur) >= 15:
+        blocks.append((cur[0], cur[-1]))
+    if len(blocks) < 5:
+        return -1
+    a, b = blocks[-4][0] - 120, blocks[-1][1] + 300      # (one step before the first block's Philox, one step after the last)
+    return sum(1 for l in lines[a:b] if re.match(r"\s*scratch_", l))
+
+
 def main():
     args = sys.argv[1:]
     check = "--check" in args
@@ -82,6 +107,12 @@ def main():
             bad.append("%s: %d system-scope flat accesses" % (name, c["flat_sys"]))
         if c["flat_ld"] + c["flat_st"] + c["flat_at"]:
             bad.append("%s: %d flat_ accesses" % (name, c["flat_ld"] + c["flat_st"] + c["flat_at"]))
+        if name in SCRATCH_OUTSIDE_STEPS and c["scratch"] > 0:
+            inside = scratch_in_steps(body)
+            if inside != 0:
+                bad.append("%s: %s scratch instructions inside the tracers' bounce steps" % (name, "unlocatable" if inside < 0 else inside))
+            else:
+                report.append("SCRATCH %s: none of its %d scratch instructions lies in the tracers' bounce steps" % (name, c["scr_ld"] + c["scr_st"]))
         if c["scratch"] > 0:
             if name in NO_SCRATCH:
                 bad.append("%s: %d B of scratch (%d loads, %d stores)" % (name, c["scratch"], c["scr_ld"], c["scr_st"]))
